@@ -1,0 +1,255 @@
+"""CodeFormer network, MI355X-native.
+
+API mirror of the reference's basicsr/archs/codeformer_arch.py: `ARCH_REGISTRY.get('CodeFormer')(dim_embd=512,
+codebook_size=1024, n_head=8, n_layers=9, connect_list=[...])`, identical state_dict keys / init order, and
+`net(x, w=..., adain=...)` -> `(out, logits, lq_feat)` (`code_only=True` -> `(logits, lq_feat)`).
+
+On ROCm tensors `CodeFormer.forward` (reference: codeformer_arch.py:223-280) runs entirely on the HIP kernels of
+codeformer_amd/csrc with channels-last activations:
+  encoder (fused GN/swish/conv stacks, taps kept by reference instead of .clone())
+  -> 9 pre-LN Transformer layers on (B*256, 512) token matrices (LayerNorm kernel, fp32-MFMA GEMMs with bias/GELU/
+     residual epilogues, 8-head attention kernel)
+  -> logits GEMM -> wavefront-shuffle argmax (== softmax+topk(1), lowest index on ties) -> codebook gather (+AdaIN)
+  -> generator with the controllable feature transform fused into conv gathers / epilogues.
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import ops
+from ..ops import EPI_GELU, EPI_RESIDUAL, EPI_SFT, PRO_LEAKY
+from ..utils.registry import ARCH_REGISTRY
+from .hip_module import HipModule
+from .vqgan_arch import ResBlock, VQAutoEncoder
+
+
+def calc_mean_std(feat, eps=1e-5):
+    """Per-(b,c) mean and sqrt(unbiased var + eps) of a 4-D tensor (codeformer_arch.py:12-26); host helper."""
+    assert feat.dim() == 4, 'The input feature should be 4D tensor.'
+    b, c = feat.shape[:2]
+    flat = feat.reshape(b, c, -1)
+    std = (flat.var(dim=2) + eps).sqrt().view(b, c, 1, 1)
+    mean = flat.mean(dim=2).view(b, c, 1, 1)
+    return mean, std
+
+
+def adaptive_instance_normalization(content_feat, style_feat):
+    """AdaIN (codeformer_arch.py:29-43).  NCHW in/out; on GPU the statistics + re-normalisation run in
+    cf_codebook_gather_adain only inside CodeFormer.forward -- this free function is the host helper."""
+    size = content_feat.size()
+    style_mean, style_std = calc_mean_std(style_feat)
+    content_mean, content_std = calc_mean_std(content_feat)
+    normalized = (content_feat - content_mean.expand(size)) / content_std.expand(size)
+    return normalized * style_std.expand(size) + style_mean.expand(size)
+
+
+class TransformerSALayer(HipModule):
+    """Pre-LN self-attention + MLP layer (codeformer_arch.py:99-134).
+
+    GPU path works on batch-major token matrices X[(b*256 + t), 512] (the NHWC view of the 16x16 latent), i.e.
+    the reference's (T, B, C) sequence-first tensor with the first two axes swapped.
+    """
+
+    def __init__(self, embed_dim, nhead=8, dim_mlp=2048, dropout=0.0, activation='gelu'):
+        super().__init__()
+        if activation != 'gelu':
+            raise RuntimeError(f'activation should be gelu for the MI355X path, not {activation}.')
+        self.self_attn = nn.MultiheadAttention(embed_dim, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(embed_dim, dim_mlp)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_mlp, embed_dim)
+        self.norm1 = nn.LayerNorm(embed_dim)
+        self.norm2 = nn.LayerNorm(embed_dim)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.embed_dim, self.nhead = embed_dim, nhead
+
+    def with_pos_embed(self, tensor, pos):
+        return tensor if pos is None else tensor + pos
+
+    def forward_tokens(self, X, pos, batch):
+        """X: (batch*256, E) tokens, pos: (256, E) or None.  Returns the layer output, same shape."""
+        E, H = self.embed_dim, self.nhead
+        sa = self.self_attn
+        w, b = sa.in_proj_weight, sa.in_proj_bias
+        pw_qk = self._packed('qk', lambda: ops.pack_weight(w[:2 * E], b[:2 * E]), w, b)
+        pw_v = self._packed('v', lambda: ops.pack_weight(w[2 * E:], b[2 * E:]), w, b)
+        pw_o = self._pw_conv(sa.out_proj)
+        if pos is not None:
+            t2, t2p = ops.layernorm(X, self.norm1.weight, self.norm1.bias, self.norm1.eps, pos=pos)
+        else:
+            t2 = t2p = ops.layernorm(X, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        qk = ops.linear(t2p, pw_qk)                      # q | k share the (LN(x)+pos) input
+        v = ops.linear(t2, pw_v)                         # v = LN(x) without pos (codeformer_arch.py:125-126)
+        hd = E // H
+        a = ops.attention(qk[:, :E], qk[:, E:], v, batch, H, hd, float(hd) ** -0.5)
+        X = ops.linear(a, pw_o, epilogue=EPI_RESIDUAL, res=X)
+        t2 = ops.layernorm(X, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        h = ops.linear(t2, self._pw_conv('linear1'), epilogue=EPI_GELU)
+        return ops.linear(h, self._pw_conv('linear2'), epilogue=EPI_RESIDUAL, res=X)
+
+    def forward(self, tgt, tgt_mask=None, tgt_key_padding_mask=None, query_pos=None):
+        """tgt: (T=256, B, E) sequence-first like the reference."""
+        if tgt.is_cuda:
+            if tgt_mask is not None or tgt_key_padding_mask is not None:
+                raise NotImplementedError('attention masks are not part of the CodeFormer inference path')
+            with torch.no_grad():
+                T, B, E = tgt.shape
+                X = tgt.float().transpose(0, 1).contiguous().view(B * T, E)
+                pos = None
+                if query_pos is not None:
+                    pos = query_pos.float()[:, 0, :].contiguous()   # the reference broadcasts one table over the batch
+                Y = self.forward_tokens(X, pos, B)
+                return Y.view(B, T, E).transpose(0, 1).contiguous()
+        tgt2 = self.norm1(tgt)
+        q = k = self.with_pos_embed(tgt2, query_pos)
+        tgt2 = self.self_attn(q, k, value=tgt2, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask)[0]
+        tgt = tgt + self.dropout1(tgt2)
+        tgt2 = self.norm2(tgt)
+        tgt2 = self.linear2(self.dropout(F.gelu(self.linear1(tgt2))))
+        return tgt + self.dropout2(tgt2)
+
+
+class Fuse_sft_block(HipModule):
+    """Controllable feature transform (codeformer_arch.py:136-157):
+    e = ResBlock(cat[enc, dec]); out = dec + w * (dec * scale(e) + shift(e)).
+
+    GPU: the concat is two base pointers in the conv gather; LeakyReLU(0.2) is the gather prologue of the second
+    conv of each branch; the SFT combine is the epilogue of the last `shift` conv.
+    """
+
+    def __init__(self, in_ch, out_ch):
+        super().__init__()
+        self.encode_enc = ResBlock(2 * in_ch, out_ch)
+        self.scale = nn.Sequential(nn.Conv2d(in_ch, out_ch, kernel_size=3, padding=1), nn.LeakyReLU(0.2, True),
+                                   nn.Conv2d(out_ch, out_ch, kernel_size=3, padding=1))
+        self.shift = nn.Sequential(nn.Conv2d(in_ch, out_ch, kernel_size=3, padding=1), nn.LeakyReLU(0.2, True),
+                                   nn.Conv2d(out_ch, out_ch, kernel_size=3, padding=1))
+
+    def forward_nhwc(self, enc, dec, w=1):
+        e = self.encode_enc.forward_nhwc(enc, dec)
+        s = ops.conv2d(e, self._pw_conv(self.scale[0]))
+        s = ops.conv2d(s, self._pw_conv(self.scale[2]), prologue=PRO_LEAKY)
+        h = ops.conv2d(e, self._pw_conv(self.shift[0]))
+        return ops.conv2d(h, self._pw_conv(self.shift[2]), prologue=PRO_LEAKY, epilogue=EPI_SFT, res=dec, sft_scale=s,
+                          sft_w=float(w))
+
+    def forward(self, enc_feat, dec_feat, w=1):
+        if enc_feat.is_cuda:
+            with torch.no_grad():
+                out = self.forward_nhwc(ops.to_nhwc(enc_feat.float()), ops.to_nhwc(dec_feat.float()), w)
+                return ops.to_nchw(out)
+        enc = self.encode_enc(torch.cat([enc_feat, dec_feat], dim=1))
+        return dec_feat + w * (dec_feat * self.scale(enc) + self.shift(enc))
+
+
+@ARCH_REGISTRY.register()
+class CodeFormer(VQAutoEncoder):
+
+    def __init__(self, dim_embd=512, n_head=8, n_layers=9, codebook_size=1024, latent_size=256,
+                 connect_list=['32', '64', '128', '256'], fix_modules=['quantize', 'generator'], vqgan_path=None):
+        super().__init__(512, 64, [1, 2, 2, 4, 4, 8], 'nearest', 2, [16], codebook_size)
+        if vqgan_path is not None:
+            self.load_state_dict(torch.load(vqgan_path, map_location='cpu')['params_ema'])
+        if fix_modules is not None:
+            for name in fix_modules:
+                for p in getattr(self, name).parameters():
+                    p.requires_grad = False
+
+        self.connect_list = connect_list
+        self.n_layers = n_layers
+        self.n_head = n_head
+        self.dim_embd = dim_embd
+        self.dim_mlp = dim_embd * 2
+        self.latent_size = latent_size
+
+        self.position_emb = nn.Parameter(torch.zeros(latent_size, self.dim_embd))
+        self.feat_emb = nn.Linear(256, self.dim_embd)
+        self.ft_layers = nn.Sequential(*[
+            TransformerSALayer(embed_dim=dim_embd, nhead=n_head, dim_mlp=self.dim_mlp, dropout=0.0)
+            for _ in range(self.n_layers)])
+        self.idx_pred_layer = nn.Sequential(nn.LayerNorm(dim_embd), nn.Linear(dim_embd, codebook_size, bias=False))
+
+        self.channels = {'16': 512, '32': 256, '64': 256, '128': 128, '256': 128, '512': 64}
+        # encoder tap after the 2nd ResBlock of a level; generator fusion after the 1st ResBlock of a level
+        self.fuse_encoder_block = {'512': 2, '256': 5, '128': 8, '64': 11, '32': 14, '16': 18}
+        self.fuse_generator_block = {'16': 6, '32': 9, '64': 12, '128': 15, '256': 18, '512': 21}
+        self.fuse_convs_dict = nn.ModuleDict()
+        for f_size in self.connect_list:
+            ch = self.channels[f_size]
+            self.fuse_convs_dict[f_size] = Fuse_sft_block(ch, ch)
+
+    # ------------------------------------------------------------------ GPU (HIP) path
+    def _forward_hip(self, x, w, code_only, adain):
+        B, _, Himg, Wimg = x.shape
+        if (Himg, Wimg) != (512, 512):
+            raise ValueError(f'CodeFormer expects aligned 512x512 faces, got {Himg}x{Wimg}')
+        x = x.float().contiguous()
+        enc_feat = {}
+        enc_taps = {self.fuse_encoder_block[f]: (lambda t: enc_feat.__setitem__(str(t.shape[2]), t))
+                    for f in self.connect_list}
+        lq = self.encoder.forward_nhwc(x, enc_taps)                       # (B,16,16,256) channels-last
+        T = lq.shape[1] * lq.shape[2]
+        tokens = lq.view(B * T, lq.shape[3])
+
+        X = ops.linear(tokens, self._pw_conv('feat_emb'))
+        for layer in self.ft_layers:
+            X = layer.forward_tokens(X, self.position_emb, B)
+        ln, head = self.idx_pred_layer[0], self.idx_pred_layer[1]
+        logits2d = ops.linear(ops.layernorm(X, ln.weight, ln.bias, ln.eps), self._pw_conv(head))
+        logits = logits2d.view(B, T, -1)
+        lq_feat = ops.to_nchw(lq)
+        if code_only:
+            return logits, lq_feat
+
+        idx = ops.argmax_rows(logits2d)                                     # == topk(softmax(logits), 1)
+        quant = ops.codebook_gather(idx, self.quantize.embedding.weight, B, T,
+                                    lq=tokens.view(B, T, -1) if adain else None)
+        quant = quant.view(B, lq.shape[1], lq.shape[2], -1)
+
+        gen_taps = None
+        if w > 0:
+            def fuse(t):
+                f = str(t.shape[2])
+                return self.fuse_convs_dict[f].forward_nhwc(enc_feat[f], t, w)
+            gen_taps = {self.fuse_generator_block[f]: fuse for f in self.connect_list}
+        out = self.generator.forward_nhwc(quant, gen_taps)                 # (B,3,512,512) NCHW
+        self.last_indices = idx.view(B, T)
+        return out, logits, lq_feat
+
+    # ------------------------------------------------------------------ host (CPU tensors) path
+    def _forward_host(self, x, w, detach_16, code_only, adain):
+        enc_feat = {}
+        out_list = [self.fuse_encoder_block[f] for f in self.connect_list]
+        for i, block in enumerate(self.encoder.blocks):
+            x = block(x)
+            if i in out_list:
+                enc_feat[str(x.shape[-1])] = x.clone()
+        lq_feat = x
+        pos_emb = self.position_emb.unsqueeze(1).repeat(1, x.shape[0], 1)
+        query = self.feat_emb(lq_feat.flatten(2).permute(2, 0, 1))
+        for layer in self.ft_layers:
+            query = layer(query, query_pos=pos_emb)
+        logits = self.idx_pred_layer(query).permute(1, 0, 2)
+        if code_only:
+            return logits, lq_feat
+        _, top_idx = torch.topk(F.softmax(logits, dim=2), 1, dim=2)
+        quant = self.quantize.get_codebook_feat(top_idx, shape=[x.shape[0], 16, 16, 256])
+        if detach_16:
+            quant = quant.detach()
+        if adain:
+            quant = adaptive_instance_normalization(quant, lq_feat)
+        x = quant
+        fuse_list = [self.fuse_generator_block[f] for f in self.connect_list]
+        for i, block in enumerate(self.generator.blocks):
+            x = block(x)
+            if i in fuse_list and w > 0:
+                f = str(x.shape[-1])
+                x = self.fuse_convs_dict[f](enc_feat[f].detach(), x, w)
+        return x, logits, lq_feat
+
+    def forward(self, x, w=0, detach_16=True, code_only=False, adain=False):
+        if x.is_cuda:
+            with torch.no_grad():
+                return self._forward_hip(x, w, code_only, adain)
+        return self._forward_host(x, w, detach_16, code_only, adain)

@@ -1,0 +1,42 @@
+"""Base class shared by the HIP-backed arch modules.
+
+Public contract (same as the reference's nn.Modules): `forward(x)` takes / returns NCHW tensors.
+  * CUDA (ROCm) tensors -> `forward_nhwc`, i.e. the HIP kernels behind the C ABI (channels-last inside);
+  * CPU tensors         -> `forward_host`, stock torch ops, kept for the reference's CPU plumbing config
+                           (inference_codeformer.py on a box without a GPU).  It is selected ONLY by the
+                           tensor's device; a CUDA tensor never reaches it, and a missing native library raises.
+"""
+import torch
+from torch import nn
+
+from .. import ops
+
+
+class HipModule(nn.Module):
+
+    def _packed(self, key, build, *params):
+        """Cache a packed weight until one of its source parameters is modified, replaced or moved."""
+        sig = tuple((p.data_ptr(), p._version, str(p.device)) for p in params if p is not None)
+        cache = self.__dict__.setdefault('_hip_cache', {})
+        ent = cache.get(key)
+        if ent is None or ent[0] != sig:
+            ent = (sig, build())
+            cache[key] = ent
+        return ent[1]
+
+    def _pw_conv(self, name):
+        conv = getattr(self, name) if isinstance(name, str) else name
+        key = name if isinstance(name, str) else id(conv)
+        return self._packed(key, lambda: ops.pack_weight(conv.weight, conv.bias), conv.weight, conv.bias)
+
+    def forward_nhwc(self, x):  # pragma: no cover - abstract
+        raise NotImplementedError
+
+    def forward_host(self, x):  # pragma: no cover - abstract
+        raise NotImplementedError
+
+    def forward(self, x):
+        if x.is_cuda:
+            with torch.no_grad():
+                return ops.to_nchw(self.forward_nhwc(ops.to_nhwc(x.float())))
+        return self.forward_host(x)

@@ -1,0 +1,440 @@
+// Implicit-GEMM convolution / linear on fp32 MFMA (v_mfma_f32_32x32x2_f32) for gfx950.
+//
+// One kernel template covers every dense contraction of the CodeFormer hot path
+// (reference call sites: include/codeformer_hip.h, cf_conv2d):
+//   out[pixel][n] = epilogue( sum_{tap, c} prologue(in[pixel + tap][c]) * W[n][c][tap] + bias[n] )
+// GEMM view: M = batch*hout*wout output pixels, N = cout, K = taps*cin.
+//
+// Data layout in HBM: activations channels-last fp32 ([b][h][w][c]); weights pre-packed as
+// [tap][cin/16][cout_pad][16] so a (tap, k-slab, n-tile) weight slab is one contiguous block.
+//
+// Work decomposition: a 256-thread workgroup (4 waves) owns a BM x BN output tile; BM is a TH x 16
+// spatial patch of ONE image.  For each 16-channel slab the (TH*s+2) x (16*s+2) input halo patch is
+// gathered once into LDS -- with the GroupNorm-apply/swish (or LeakyReLU) prologue, the nearest-x2
+// upsample, the channel concat of two inputs and the zero padding all resolved in that gather -- and
+// is then reused by all 9 taps; the per-tap weight slab is double-buffered in LDS and prefetched
+// through registers while the MFMAs of the previous tap run.  Each wave accumulates a
+// (MI*32) x (NI*32) sub-tile in MI*NI*16 accumulator registers.
+#include "cf_common.h"
+
+namespace {
+
+struct ConvArgs {
+  const float* in0;
+  const float* in1;
+  int c0, c1, cin, nchunks;
+  int batch, hin, win, hout, wout;
+  int cout, cout_pad;
+  int upsample, out_nchw, prologue, epilogue;
+  const float* pro_scale;
+  const float* pro_shift;
+  const float* weight;
+  const float* bias;
+  const float* res;
+  const float* sft_scale;
+  float sft_w;
+  float* out;
+  int tiles_x, tiles_per_img, ntn;
+};
+
+template <int TAPS, int STRIDE, int WM, int WN, int MI, int NI>
+struct Cfg {
+  static constexpr int BM = WM * MI * 32;
+  static constexpr int BN = WN * NI * 32;
+  static constexpr int TW = 16;
+  static constexpr int TH = BM / 16;
+  static constexpr int HH = (TAPS == 9) ? (TH - 1) * STRIDE + 3 : TH;   // halo patch rows
+  static constexpr int HWD = (TAPS == 9) ? (TW - 1) * STRIDE + 3 : TW;  // halo patch cols
+  static constexpr int NPIX = (TAPS == 9) ? HH * HWD : BM;
+  static constexpr int ABUF = (TAPS == 1) ? 2 : 1;
+  static constexpr int APT = (NPIX * 4 + 255) / 256;  // float4 gather items per thread
+  static constexpr int BPT = (BN * 4 + 255) / 256;    // float4 weight items per thread
+  static constexpr int LDS_FLOATS = ABUF * NPIX * CF_LDK + 2 * BN * CF_LDK;
+};
+
+// x * sigmoid(x) with sigmoid = 1/(1+exp(-x)), the operation order of vqgan_arch.py:18-20
+__device__ __forceinline__ float swishf(float y) { return y * (1.0f / (1.0f + expf(-y))); }
+
+template <int TAPS, int STRIDE, int WM, int WN, int MI, int NI, bool IN_NCHW>
+__global__ __launch_bounds__(256) void igemm_kernel(const ConvArgs a) {
+  using C = Cfg<TAPS, STRIDE, WM, WN, MI, NI>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const As = smem;
+  float* const Bs = smem + C::ABUF * C::NPIX * CF_LDK;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN;
+  const int wn = wave % WN;
+  const int half = lane >> 5;
+  const int l31 = lane & 31;
+
+  const int nt = blockIdx.x % a.ntn;
+  const int mt = blockIdx.x / a.ntn;
+  const int n0 = nt * C::BN;
+  int b, y0 = 0, x0 = 0, m0 = 0;
+  if (TAPS == 9) {
+    b = mt / a.tiles_per_img;
+    const int r = mt - b * a.tiles_per_img;
+    const int ty = r / a.tiles_x;
+    y0 = ty * C::TH;
+    x0 = (r - ty * a.tiles_x) * C::TW;
+  } else {
+    m0 = mt * C::BM;
+    b = m0 / (a.hout * a.wout);
+  }
+
+  // ---- gather geometry: item j of this thread is float4 #k4 of halo pixel p = (tid>>2) + 64*j ----
+  const int k4 = tid & 3;
+  int pix[C::APT];  // source pixel index (b*hin+sy)*win+sx (NCHW: sy*win+sx), -1 = zero padding / unused
+#pragma unroll
+  for (int j = 0; j < C::APT; ++j) {
+    const int p = (tid >> 2) + 64 * j;
+    int v = -1;
+    if (p < C::NPIX) {
+      if (TAPS == 9) {
+        const int hy = p / C::HWD;
+        const int hx = p - hy * C::HWD;
+        const int pad = (STRIDE == 1) ? 1 : 0;
+        const int iy = y0 * STRIDE - pad + hy;
+        const int ix = x0 * STRIDE - pad + hx;
+        const int hv = a.hin << a.upsample, wv = a.win << a.upsample;
+        if (iy >= 0 && iy < hv && ix >= 0 && ix < wv) {
+          const int sy = iy >> a.upsample, sx = ix >> a.upsample;
+          v = IN_NCHW ? (sy * a.win + sx) : ((b * a.hin + sy) * a.win + sx);
+        }
+      } else {
+        v = m0 + p;
+      }
+    }
+    pix[j] = v;
+  }
+
+  auto load_A = [&](int chunk, f32x4(&ra)[C::APT]) {
+    const int c = chunk * CF_BK + k4 * 4;
+    if (IN_NCHW) {
+      const size_t plane = (size_t)a.hin * a.win;
+      const float* base = a.in0 + (size_t)b * a.c0 * plane;
+#pragma unroll
+      for (int j = 0; j < C::APT; ++j) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (pix[j] >= 0 && c == 0) {
+          v[0] = base[pix[j]];
+          if (a.c0 > 1) v[1] = base[plane + pix[j]];
+          if (a.c0 > 2) v[2] = base[2 * plane + pix[j]];
+          if (a.c0 > 3) v[3] = base[3 * plane + pix[j]];
+        }
+        ra[j] = v;
+      }
+    } else {
+      const float* src;
+      int cs, cc;
+      if (c < a.c0) {
+        src = a.in0; cs = a.c0; cc = c;
+      } else {
+        src = a.in1; cs = a.c1; cc = c - a.c0;
+      }
+#pragma unroll
+      for (int j = 0; j < C::APT; ++j) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (pix[j] >= 0) v = *reinterpret_cast<const f32x4*>(src + (size_t)pix[j] * cs + cc);
+        ra[j] = v;
+      }
+    }
+  };
+
+  auto store_A = [&](int buf, const f32x4(&ra)[C::APT], int chunk) {
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (a.prologue == CF_PRO_AFFINE || a.prologue == CF_PRO_AFFINE_SWISH) {
+      const int c = chunk * CF_BK + k4 * 4;
+      sc = *reinterpret_cast<const f32x4*>(a.pro_scale + (size_t)b * a.cin + c);
+      sh = *reinterpret_cast<const f32x4*>(a.pro_shift + (size_t)b * a.cin + c);
+    }
+    float* dst = As + buf * (C::NPIX * CF_LDK) + k4 * 4;
+#pragma unroll
+    for (int j = 0; j < C::APT; ++j) {
+      const int p = (tid >> 2) + 64 * j;
+      if (p < C::NPIX) {
+        f32x4 v = ra[j];
+        if (pix[j] >= 0) {  // zero padding stays exactly zero (it pads the conv INPUT, i.e. post-activation)
+          if (a.prologue == CF_PRO_AFFINE) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] * sc[e] + sh[e];
+          } else if (a.prologue == CF_PRO_AFFINE_SWISH) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = swishf(v[e] * sc[e] + sh[e]);
+          } else if (a.prologue == CF_PRO_LEAKY) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+          }
+        }
+        *reinterpret_cast<f32x4*>(dst + p * CF_LDK) = v;
+      }
+    }
+  };
+
+  auto load_B = [&](int step, f32x4(&rb)[C::BPT]) {
+    const int chunk = step / TAPS;
+    const int tap = step - chunk * TAPS;
+    const float* src = a.weight + ((size_t)(tap * a.nchunks + chunk) * a.cout_pad + n0) * CF_BK;
+#pragma unroll
+    for (int j = 0; j < C::BPT; ++j) {
+      const int f = tid + 256 * j;
+      if (f < C::BN * 4) rb[j] = *reinterpret_cast<const f32x4*>(src + f * 4);
+    }
+  };
+  auto store_B = [&](int buf, const f32x4(&rb)[C::BPT]) {
+    float* dst = Bs + buf * (C::BN * CF_LDK);
+#pragma unroll
+    for (int j = 0; j < C::BPT; ++j) {
+      const int f = tid + 256 * j;
+      if (f < C::BN * 4) *reinterpret_cast<f32x4*>(dst + (f >> 2) * CF_LDK + (f & 3) * 4) = rb[j];
+    }
+  };
+
+  // ---- MFMA operand rows of this lane ----
+  int a_off[MI], b_off[NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int row = wm * (MI * 32) + mi * 32 + l31;
+    if (TAPS == 9) {
+      const int py = row >> 4, px = row & 15;
+      a_off[mi] = ((py * STRIDE) * C::HWD + px * STRIDE) * CF_LDK + half * 4;
+    } else {
+      a_off[mi] = row * CF_LDK + half * 4;
+    }
+  }
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) b_off[ni] = (wn * (NI * 32) + ni * 32 + l31) * CF_LDK + half * 4;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int nsteps = a.nchunks * TAPS;
+  f32x4 ra[C::APT];
+  f32x4 rb[C::BPT];
+  load_B(0, rb);
+  load_A(0, ra);
+  int step = 0;
+  for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+    const int abuf = (C::ABUF == 2) ? (chunk & 1) : 0;
+    store_A(abuf, ra, chunk);
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap, ++step) {
+      const int bbuf = step & 1;
+      store_B(bbuf, rb);
+      __syncthreads();
+      if (step + 1 < nsteps) load_B(step + 1, rb);
+      if (tap == TAPS - 1 && chunk + 1 < a.nchunks) load_A(chunk + 1, ra);
+      const int tapoff = (TAPS == 9) ? ((tap / 3) * C::HWD + (tap % 3)) * CF_LDK : 0;
+      const float* ap[MI];
+      const float* bp[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) ap[mi] = As + abuf * (C::NPIX * CF_LDK) + a_off[mi] + tapoff;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bp[ni] = Bs + bbuf * (C::BN * CF_LDK) + b_off[ni];
+      cf_mma_slab<MI, NI>(acc, ap, bp);
+    }
+    if (C::ABUF == 1) __syncthreads();  // all waves done with As before the next slab overwrites it
+  }
+
+  // ---- epilogue: accumulator (row = pixel, col = n = lane&31) -> bias / residual / SFT / GELU -> HBM ----
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = n0 + wn * (NI * 32) + ni * 32 + l31;
+    if (n >= a.cout) continue;
+    const float bias = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * (MI * 32) + mi * 32 + cf_acc_row(r, lane);
+        size_t pixel;
+        int oy = 0, ox = 0;
+        if (TAPS == 9) {
+          oy = y0 + (row >> 4);
+          ox = x0 + (row & 15);
+          pixel = ((size_t)b * a.hout + oy) * a.wout + ox;
+        } else {
+          pixel = (size_t)m0 + row;
+        }
+        const size_t o = pixel * a.cout + n;
+        float v = acc[mi][ni][r] + bias;
+        if (a.epilogue == CF_EPI_RESIDUAL) {
+          v += a.res[o];
+        } else if (a.epilogue == CF_EPI_SFT) {
+          const float dec = a.res[o];
+          v = dec + a.sft_w * (dec * a.sft_scale[o] + v);
+        } else if (a.epilogue == CF_EPI_GELU) {
+          v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        }
+        if (TAPS == 9 && a.out_nchw)
+          a.out[(((size_t)b * a.cout + n) * a.hout + oy) * a.wout + ox] = v;
+        else
+          a.out[o] = v;
+      }
+    }
+  }
+}
+
+template <int TAPS, int STRIDE, int WM, int WN, int MI, int NI, bool IN_NCHW>
+int launch(const ConvArgs& a, hipStream_t stream) {
+  using C = Cfg<TAPS, STRIDE, WM, WN, MI, NI>;
+  ConvArgs k = a;
+  int mtiles;
+  if (TAPS == 9) {
+    if (a.hout % C::TH != 0 || a.wout % C::TW != 0) {
+      cf_set_error("cf_conv2d: %dx%d output not divisible by the %dx%d tile", a.hout, a.wout, C::TH, C::TW);
+      return CF_ERR_ARG;
+    }
+    k.tiles_x = a.wout / C::TW;
+    k.tiles_per_img = k.tiles_x * (a.hout / C::TH);
+    mtiles = k.tiles_per_img * a.batch;
+  } else {
+    const long m = (long)a.batch * a.hout * a.wout;
+    if (m % C::BM != 0 || (a.hout * a.wout) % C::BM != 0) {
+      cf_set_error("cf_conv2d: 1x1 rows %ld (per image %d) not divisible by %d", m, a.hout * a.wout, C::BM);
+      return CF_ERR_ARG;
+    }
+    k.tiles_x = 0;
+    k.tiles_per_img = 0;
+    mtiles = (int)(m / C::BM);
+  }
+  k.ntn = a.cout_pad / C::BN;
+  auto kern = igemm_kernel<TAPS, STRIDE, WM, WN, MI, NI, IN_NCHW>;
+  constexpr size_t lds = C::LDS_FLOATS * sizeof(float);
+  static bool attr_set = false;  // benign race: the attribute call is idempotent
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      cf_set_error("cf_conv2d: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+      return CF_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(mtiles * k.ntn), dim3(256), lds, stream, k);
+  CF_CHECK_LAUNCH("cf_conv2d");
+  return CF_OK;
+}
+
+__global__ void pack_weight_kernel(const float* __restrict__ w, int cout, int cin, int taps, int cout_pad,
+                                   int nchunks, float* __restrict__ packed, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int k = (int)(i % CF_BK);
+  long r = i / CF_BK;
+  const int n = (int)(r % cout_pad);
+  r /= cout_pad;
+  const int chunk = (int)(r % nchunks);
+  const int tap = (int)(r / nchunks);
+  const int c = chunk * CF_BK + k;
+  float v = 0.f;
+  if (n < cout && c < cin) v = w[((long)n * cin + c) * taps + tap];
+  packed[i] = v;
+}
+
+}  // namespace
+
+extern "C" int64_t cf_packed_weight_elems(int cin_pad, int taps, int cout_pad) {
+  return (int64_t)taps * cin_pad * cout_pad;
+}
+
+extern "C" int cf_pack_conv_weight(const float* w, int cout, int cin, int taps, int cout_pad, int cin_pad,
+                                   float* packed, cf_stream_t stream) {
+  CF_REQUIRE(w && packed, "cf_pack_conv_weight: null pointer");
+  CF_REQUIRE(taps == 1 || taps == 9, "cf_pack_conv_weight: taps must be 1 or 9 (got %d)", taps);
+  CF_REQUIRE(cin_pad % CF_BK == 0 && cin_pad >= cin && cout_pad >= cout && cout_pad % 32 == 0,
+             "cf_pack_conv_weight: bad padding cin %d->%d cout %d->%d", cin, cin_pad, cout, cout_pad);
+  const long total = (long)taps * cin_pad * cout_pad;
+  const int blocks = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, cout, cin, taps,
+                     cout_pad, cin_pad / CF_BK, packed, total);
+  CF_CHECK_LAUNCH("cf_pack_conv_weight");
+  return CF_OK;
+}
+
+extern "C" int cf_conv2d(const cf_conv_desc* d, cf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  CF_REQUIRE(d, "cf_conv2d: null descriptor");
+  CF_REQUIRE(d->in0 && d->weight && d->out, "cf_conv2d: null in0/weight/out");
+  CF_REQUIRE(d->taps == 1 || d->taps == 9, "cf_conv2d: taps must be 1 or 9 (got %d)", d->taps);
+  CF_REQUIRE(d->stride == 1 || (d->stride == 2 && d->taps == 9), "cf_conv2d: unsupported stride %d", d->stride);
+  CF_REQUIRE(d->batch > 0 && d->hin > 0 && d->win > 0 && d->cout > 0, "cf_conv2d: bad dims");
+  CF_REQUIRE(!(d->upsample && (d->stride != 1 || d->taps != 9)), "cf_conv2d: upsample needs 3x3 stride 1");
+  const int exp_h = d->stride == 2 ? d->hin / 2 : (d->hin << (d->upsample ? 1 : 0));
+  const int exp_w = d->stride == 2 ? d->win / 2 : (d->win << (d->upsample ? 1 : 0));
+  CF_REQUIRE(d->hout == exp_h && d->wout == exp_w, "cf_conv2d: hout/wout %dx%d, expected %dx%d", d->hout, d->wout,
+             exp_h, exp_w);
+  CF_REQUIRE(d->stride == 1 || (d->hin % 2 == 0 && d->win % 2 == 0), "cf_conv2d: stride 2 needs even input");
+  if (d->in_nchw) {
+    CF_REQUIRE(d->c0 >= 1 && d->c0 <= 4 && d->c1 == 0 && d->taps == 9 && d->stride == 1 && !d->upsample,
+               "cf_conv2d: in_nchw supports 3x3 s1 with <=4 input channels");
+    CF_REQUIRE(d->prologue == CF_PRO_NONE, "cf_conv2d: in_nchw has no prologue");
+  } else {
+    CF_REQUIRE(d->c0 % CF_BK == 0 && d->c1 % CF_BK == 0 && d->c0 > 0, "cf_conv2d: c0=%d c1=%d must be multiples of 16",
+               d->c0, d->c1);
+    CF_REQUIRE(d->c1 == 0 || d->in1, "cf_conv2d: c1 > 0 without in1");
+  }
+  CF_REQUIRE(d->prologue >= 0 && d->prologue <= 3 && d->epilogue >= 0 && d->epilogue <= 3, "cf_conv2d: bad pro/epilogue");
+  if (d->prologue == CF_PRO_AFFINE || d->prologue == CF_PRO_AFFINE_SWISH)
+    CF_REQUIRE(d->pro_scale && d->pro_shift, "cf_conv2d: affine prologue without scale/shift tables");
+  if (d->epilogue == CF_EPI_RESIDUAL || d->epilogue == CF_EPI_SFT) CF_REQUIRE(d->res, "cf_conv2d: epilogue needs res");
+  if (d->epilogue == CF_EPI_SFT) CF_REQUIRE(d->sft_scale, "cf_conv2d: SFT epilogue needs sft_scale");
+  CF_REQUIRE(!(d->out_nchw && (d->taps != 9 || d->epilogue != CF_EPI_NONE)), "cf_conv2d: out_nchw needs 3x3, no epilogue");
+  CF_REQUIRE(d->cout_pad >= d->cout && d->cout_pad % 32 == 0, "cf_conv2d: cout_pad %d invalid for cout %d", d->cout_pad,
+             d->cout);
+
+  ConvArgs a;
+  a.in0 = d->in0;
+  a.in1 = d->in1;
+  a.c0 = d->c0;
+  a.c1 = d->c1;
+  a.cin = d->c0 + d->c1;
+  a.nchunks = (a.cin + CF_BK - 1) / CF_BK;
+  a.batch = d->batch;
+  a.hin = d->hin;
+  a.win = d->win;
+  a.hout = d->hout;
+  a.wout = d->wout;
+  a.cout = d->cout;
+  a.cout_pad = d->cout_pad;
+  a.upsample = d->upsample ? 1 : 0;
+  a.out_nchw = d->out_nchw;
+  a.prologue = d->prologue;
+  a.epilogue = d->epilogue;
+  a.pro_scale = d->pro_scale;
+  a.pro_shift = d->pro_shift;
+  a.weight = d->weight;
+  a.bias = d->bias;
+  a.res = d->res;
+  a.sft_scale = d->sft_scale;
+  a.sft_w = d->sft_w;
+  a.out = d->out;
+  a.tiles_x = a.tiles_per_img = a.ntn = 0;
+
+  const int cp = d->cout_pad;
+  if (d->taps == 9 && d->stride == 1) {
+    if (d->in_nchw) {
+      CF_REQUIRE(cp == 64, "cf_conv2d: in_nchw path is built for cout_pad 64 (got %d)", cp);
+      return launch<9, 1, 4, 1, 2, 2, true>(a, stream);
+    }
+    if (cp % 128 == 0) return launch<9, 1, 2, 2, 2, 2, false>(a, stream);
+    if (cp == 64) return launch<9, 1, 4, 1, 2, 2, false>(a, stream);
+    if (cp == 32) return launch<9, 1, 4, 1, 2, 1, false>(a, stream);
+  } else if (d->taps == 9 && d->stride == 2) {
+    if (cp % 128 == 0) return launch<9, 2, 2, 2, 2, 2, false>(a, stream);
+    if (cp == 64) return launch<9, 2, 2, 2, 2, 1, false>(a, stream);
+  } else {
+    if (cp % 128 == 0) return launch<1, 1, 2, 2, 2, 2, false>(a, stream);
+    if (cp == 64) return launch<1, 1, 4, 1, 2, 2, false>(a, stream);
+  }
+  cf_set_error("cf_conv2d: no kernel for taps=%d stride=%d cout_pad=%d", d->taps, d->stride, cp);
+  return CF_ERR_ARG;
+}

@@ -1,0 +1,319 @@
+// Small HBM-/latency-bound kernels of the CodeFormer path for gfx950: code argmax, codebook gather + AdaIN,
+// nearest-code argmin, layout converters, the u8<->tensor boundary, and the two bundled StyleGAN2 ops.
+#include <stdarg.h>
+
+#include "cf_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// library plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void cf_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int cf_version(void) { return CF_ABI_VERSION; }
+extern "C" const char* cf_last_error(void) { return g_err; }
+extern "C" int cf_device_cu_count(void) {
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+  return n;
+}
+
+namespace {
+
+// ---- argmax over a row: one wave per row, wavefront-shuffle reduction, lowest index wins ties ----
+__device__ __forceinline__ void argbest(float& v, int& i, float ov, int oi, bool want_max) {
+  const bool better = want_max ? (ov > v) : (ov < v);
+  if (better || (ov == v && oi < i)) {
+    v = ov;
+    i = oi;
+  }
+}
+
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, int rows, int n,
+                                                          int64_t* __restrict__ idx) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * n;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = lane * 4; c < n; c += 256) {  // ascending index within a lane
+    const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) argbest(best, bi, v[e], c + e, true);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    argbest(best, bi, ov, oi, true);
+  }
+  if (lane == 0) idx[row] = bi;
+}
+
+// ---- nearest code: d_j = (zz + ee_j) - 2*s_j in the reference's operation order, argmin ----------
+__global__ __launch_bounds__(256) void vq_argmin_kernel(const float* __restrict__ scores, const float* __restrict__ zz,
+                                                        const float* __restrict__ ee, int rows, int n,
+                                                        int64_t* __restrict__ idx, float* __restrict__ dmin) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* sr = scores + (size_t)row * n;
+  const float z2 = zz[row];
+  float best = INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = lane * 4; c < n; c += 256) {
+    const f32x4 s = *reinterpret_cast<const f32x4*>(sr + c);
+    const f32x4 e = *reinterpret_cast<const f32x4*>(ee + c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) argbest(best, bi, (z2 + e[k]) - 2.0f * s[k], c + k, false);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    argbest(best, bi, ov, oi, false);
+  }
+  if (lane == 0) {
+    idx[row] = bi;
+    if (dmin) dmin[row] = best;
+  }
+}
+
+__global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* __restrict__ x, int rows, int dim,
+                                                         float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float s = 0.f;
+  for (int c = lane * 4; c < dim; c += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)row * dim + c);
+    s += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+  }
+  s = cf_wave_sum(s);
+  if (lane == 0) out[row] = s;
+}
+
+// ---- codebook gather (+AdaIN): one workgroup per image, thread = channel -------------------------
+__global__ __launch_bounds__(256) void gather_adain_kernel(const int64_t* __restrict__ idx, const float* __restrict__ cb,
+                                                           int ncodes, const float* __restrict__ lq, int ntok, int dim,
+                                                           int adain, float eps, float* __restrict__ out) {
+  extern __shared__ int s_idx[];
+  const int b = blockIdx.x;
+  for (int p = threadIdx.x; p < ntok; p += blockDim.x) {
+    long v = idx[(size_t)b * ntok + p];
+    s_idx[p] = (int)(v < 0 ? 0 : (v >= ncodes ? ncodes - 1 : v));
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+    float cm = 0.f, cs = 1.f, sm = 0.f, ss = 1.f;
+    if (adain) {
+      double s1 = 0, q1 = 0, s2 = 0, q2 = 0;
+      for (int p = 0; p < ntok; ++p) {
+        const double v1 = cb[(size_t)s_idx[p] * dim + c];
+        const double v2 = lq[((size_t)b * ntok + p) * dim + c];
+        s1 += v1;
+        q1 += v1 * v1;
+        s2 += v2;
+        q2 += v2 * v2;
+      }
+      const double m1 = s1 / ntok, m2 = s2 / ntok;
+      double var1 = (q1 - s1 * m1) / (ntok - 1), var2 = (q2 - s2 * m2) / (ntok - 1);  // unbiased (torch.var)
+      if (var1 < 0) var1 = 0;
+      if (var2 < 0) var2 = 0;
+      cm = (float)m1;
+      sm = (float)m2;
+      cs = sqrtf((float)var1 + eps);
+      ss = sqrtf((float)var2 + eps);
+    }
+    for (int p = 0; p < ntok; ++p) {
+      float v = cb[(size_t)s_idx[p] * dim + c];
+      if (adain) v = ((v - cm) / cs) * ss + sm;  // codeformer_arch.py:42-43 operation order
+      out[((size_t)b * ntok + p) * dim + c] = v;
+    }
+  }
+}
+
+// ---- batched 2-D transpose [B][R][C] -> [B][C][R] through a padded LDS tile ---------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ x, int R, int C, float* __restrict__ y) {
+  __shared__ float t[32][33];
+  const int b = blockIdx.z;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float* xb = x + (size_t)b * R * C;
+  float* yb = y + (size_t)b * R * C;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    if (r < R && c < C) t[ty + 8 * i][tx] = xb[(size_t)r * C + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (r < R && c < C) yb[(size_t)c * R + r] = t[tx][ty + 8 * i];
+  }
+}
+
+// ---- tensor boundary ------------------------------------------------------------------------------
+__global__ void img_u8_to_tensor_kernel(const uint8_t* __restrict__ img, int hw, float* __restrict__ out, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over batch*hw pixels
+  if (i >= total) return;
+  const long b = i / hw, p = i - b * hw;
+  const uint8_t* px = img + i * 3;  // BGR
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float v = (float)((double)px[2 - c] / 255.0);  // img/255. in fp64 then .astype(float32)
+    out[(b * 3 + c) * hw + p] = (v - 0.5f) / 0.5f;      // torchvision normalize
+  }
+}
+
+__global__ void tensor_to_img_u8_kernel(const float* __restrict__ t, int hw, uint8_t* __restrict__ img, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long b = i / hw, p = i - b * hw;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float v = t[(b * 3 + c) * hw + p];
+    v = fminf(fmaxf(v, -1.0f), 1.0f);
+    v = (v - (-1.0f)) / (1.0f - (-1.0f));
+    img[i * 3 + (2 - c)] = (uint8_t)rintf(v * 255.0f);  // np.round = half-to-even
+  }
+}
+
+// ---- bundled ops ----------------------------------------------------------------------------------
+__global__ void fused_bias_act_kernel(const float* __restrict__ x, const float* __restrict__ bias, long numel, int c,
+                                      int hw, float slope, float scale, float* __restrict__ y) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += stride) {
+    float v = x[i];
+    if (bias) v += bias[(i / hw) % c];
+    y[i] = (v > 0.f ? v : v * slope) * scale;
+  }
+}
+
+__global__ void upfirdn2d_kernel(const float* __restrict__ x, int in_h, int in_w, const float* __restrict__ k, int kh,
+                                 int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_y0, int out_h,
+                                 int out_w, float* __restrict__ y, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ox = (int)(i % out_w);
+  const int oy = (int)((i / out_w) % out_h);
+  const long plane = i / ((long)out_w * out_h);
+  const float* xp = x + plane * in_h * in_w;
+  float acc = 0.f;
+  for (int ky = 0; ky < kh; ++ky) {
+    const int uy = oy * down_y + ky - pad_y0;  // coordinate in the zero-stuffed image
+    if (uy < 0 || uy % up_y != 0) continue;
+    const int iy = uy / up_y;
+    if (iy >= in_h) continue;
+    for (int kx = 0; kx < kw; ++kx) {
+      const int ux = ox * down_x + kx - pad_x0;
+      if (ux < 0 || ux % up_x != 0) continue;
+      const int ix = ux / up_x;
+      if (ix >= in_w) continue;
+      acc += xp[(size_t)iy * in_w + ix] * k[(kh - 1 - ky) * kw + (kw - 1 - kx)];  // flipped FIR kernel
+    }
+  }
+  y[i] = acc;
+}
+
+}  // namespace
+
+extern "C" int cf_argmax_rows(const float* logits, int rows, int n, int64_t* idx, cf_stream_t stream) {
+  CF_REQUIRE(logits && idx && rows > 0 && n > 0 && n % 4 == 0, "cf_argmax_rows: bad args (n=%d must be a multiple of 4)", n);
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, rows, n, idx);
+  CF_CHECK_LAUNCH("cf_argmax_rows");
+  return CF_OK;
+}
+
+extern "C" int cf_row_sqnorm(const float* x, int rows, int dim, float* out, cf_stream_t stream) {
+  CF_REQUIRE(x && out && rows > 0 && dim % 4 == 0, "cf_row_sqnorm: bad args");
+  hipLaunchKernelGGL(row_sqnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, rows, dim, out);
+  CF_CHECK_LAUNCH("cf_row_sqnorm");
+  return CF_OK;
+}
+
+extern "C" int cf_vq_argmin(const float* scores, const float* zz, const float* ee, int rows, int ncodes, int64_t* idx,
+                            float* dist_min, cf_stream_t stream) {
+  CF_REQUIRE(scores && zz && ee && idx && rows > 0 && ncodes % 4 == 0, "cf_vq_argmin: bad args");
+  hipLaunchKernelGGL(vq_argmin_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, scores, zz, ee, rows,
+                     ncodes, idx, dist_min);
+  CF_CHECK_LAUNCH("cf_vq_argmin");
+  return CF_OK;
+}
+
+extern "C" int cf_codebook_gather_adain(const int64_t* idx, const float* codebook, int codebook_size, const float* lq,
+                                        int batch, int ntok, int dim, int adain, float eps, float* out,
+                                        cf_stream_t stream) {
+  CF_REQUIRE(idx && codebook && out && (!adain || lq), "cf_codebook_gather_adain: null pointer");
+  CF_REQUIRE(batch > 0 && ntok > 1 && ntok <= 16384 && dim > 0 && codebook_size > 0, "cf_codebook_gather_adain: bad dims");
+  hipLaunchKernelGGL(gather_adain_kernel, dim3(batch), dim3(256), ntok * sizeof(int), (hipStream_t)stream, idx, codebook,
+                     codebook_size, lq, ntok, dim, adain, eps, out);
+  CF_CHECK_LAUNCH("cf_codebook_gather_adain");
+  return CF_OK;
+}
+
+static int launch_transpose(const float* x, int batch, int R, int C, float* y, cf_stream_t stream, const char* name) {
+  CF_REQUIRE(x && y && batch > 0 && R > 0 && C > 0 && batch < 65536, "%s: bad args", name);
+  hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32, batch), dim3(256), 0, (hipStream_t)stream, x, R, C,
+                     y);
+  CF_CHECK_LAUNCH(name);
+  return CF_OK;
+}
+extern "C" int cf_nchw_to_nhwc(const float* x, int batch, int c, int hw, float* y, cf_stream_t stream) {
+  return launch_transpose(x, batch, c, hw, y, stream, "cf_nchw_to_nhwc");
+}
+extern "C" int cf_nhwc_to_nchw(const float* x, int batch, int c, int hw, float* y, cf_stream_t stream) {
+  return launch_transpose(x, batch, hw, c, y, stream, "cf_nhwc_to_nchw");
+}
+
+extern "C" int cf_img_u8_to_tensor(const uint8_t* img, int batch, int h, int w, float* out, cf_stream_t stream) {
+  CF_REQUIRE(img && out && batch > 0 && h > 0 && w > 0, "cf_img_u8_to_tensor: bad args");
+  const long total = (long)batch * h * w;
+  hipLaunchKernelGGL(img_u8_to_tensor_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, img,
+                     h * w, out, total);
+  CF_CHECK_LAUNCH("cf_img_u8_to_tensor");
+  return CF_OK;
+}
+extern "C" int cf_tensor_to_img_u8(const float* t, int batch, int h, int w, uint8_t* img, cf_stream_t stream) {
+  CF_REQUIRE(img && t && batch > 0 && h > 0 && w > 0, "cf_tensor_to_img_u8: bad args");
+  const long total = (long)batch * h * w;
+  hipLaunchKernelGGL(tensor_to_img_u8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t,
+                     h * w, img, total);
+  CF_CHECK_LAUNCH("cf_tensor_to_img_u8");
+  return CF_OK;
+}
+
+extern "C" int cf_fused_bias_act(const float* x, const float* bias, int64_t numel, int c, int hw, float slope, float scale,
+                                 float* y, cf_stream_t stream) {
+  CF_REQUIRE(x && y && numel > 0 && c > 0 && hw > 0, "cf_fused_bias_act: bad args");
+  long blocks = (numel + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(fused_bias_act_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, bias, (long)numel,
+                     c, hw, slope, scale, y);
+  CF_CHECK_LAUNCH("cf_fused_bias_act");
+  return CF_OK;
+}
+
+extern "C" int cf_upfirdn2d(const float* x, int nplanes, int in_h, int in_w, const float* kernel, int kh, int kw, int up_x,
+                            int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, float* y,
+                            cf_stream_t stream) {
+  CF_REQUIRE(x && y && kernel && nplanes > 0 && in_h > 0 && in_w > 0 && kh > 0 && kw > 0, "cf_upfirdn2d: bad args");
+  CF_REQUIRE(up_x > 0 && up_y > 0 && down_x > 0 && down_y > 0, "cf_upfirdn2d: up/down must be positive");
+  const int out_h = (in_h * up_y + pad_y0 + pad_y1 - kh) / down_y + 1;
+  const int out_w = (in_w * up_x + pad_x0 + pad_x1 - kw) / down_x + 1;
+  CF_REQUIRE(out_h > 0 && out_w > 0, "cf_upfirdn2d: empty output");
+  const long total = (long)nplanes * out_h * out_w;
+  hipLaunchKernelGGL(upfirdn2d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, in_h,
+                     in_w, kernel, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0, out_h, out_w, y, total);
+  CF_CHECK_LAUNCH("cf_upfirdn2d");
+  return CF_OK;
+}

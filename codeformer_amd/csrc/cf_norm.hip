@@ -1,0 +1,179 @@
+// GroupNorm statistics (two-stage, deterministic fp64 partials) and LayerNorm for gfx950.
+// HBM-bound kernels: 16-byte coalesced loads along the channel axis of channels-last tensors.
+#include "cf_common.h"
+
+namespace {
+
+// ---- GroupNorm stage 1 --------------------------------------------------------------------------
+// x: [batch][hw][C] fp32.  grid (nblk, batch), 256 threads.  Thread t owns channel quad t % (C/4) and
+// walks pixel rows  row0 + t/(C/4), += 1024/C.  Sums are carried in fp64 (the pass is HBM-bound; the fp64
+// adds hide under the loads) so the later mean / E[x^2]-mean^2 is accurate for any |mean|/std.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, int hw, int C, int cpg,
+                                                       int rows_per_blk, double* __restrict__ part, int gtotal,
+                                                       int g0, int nblk) {
+  __shared__ double red[256][4];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, blk = blockIdx.x;
+  const int cq4 = C >> 2;
+  const int cq = tid % cq4;
+  const int pr = tid / cq4;
+  const int lanes = 256 / cq4;
+  const int row0 = blk * rows_per_blk;
+  const int row1 = min(hw, row0 + rows_per_blk);
+  double s0 = 0, q0 = 0, s1 = 0, q1 = 0;
+  const float* base = x + (size_t)b * hw * C + cq * 4;
+  for (int r = row0 + pr; r < row1; r += lanes) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)r * C);
+    const double a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+    s0 += a0 + a1;
+    q0 += a0 * a0 + a1 * a1;
+    s1 += a2 + a3;
+    q1 += a2 * a2 + a3 * a3;
+  }
+  red[tid][0] = s0;
+  red[tid][1] = q0;
+  red[tid][2] = s1;
+  red[tid][3] = q1;
+  __syncthreads();
+  const int G = C / cpg;
+  if (tid < G) {
+    double s = 0, q = 0;
+    for (int t = 0; t < 256; ++t) {  // fixed order -> bitwise reproducible
+      const int c = (t % cq4) * 4;
+      if (c / cpg == tid) {
+        s += red[t][0];
+        q += red[t][1];
+      }
+      if ((c + 2) / cpg == tid) {
+        s += red[t][2];
+        q += red[t][3];
+      }
+    }
+    double* o = part + (((size_t)b * gtotal + g0 + tid) * nblk + blk) * 2;
+    o[0] = s;
+    o[1] = q;
+  }
+}
+
+// ---- GroupNorm stage 2: fixed-order sum of partials -> per-(b,c) scale/shift --------------------
+// scale = gamma*rstd, shift = beta - mean*scale: the same affine form ATen's CPU GroupNorm kernel applies.
+__global__ void gn_finalize_kernel(const double* __restrict__ part, int gtotal, int nblk, int C, int cpg,
+                                   double inv_count, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float eps, float* __restrict__ scale, float* __restrict__ shift) {
+  __shared__ float s_mean[64], s_rstd[64];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  if (tid < gtotal) {
+    const double* p = part + ((size_t)b * gtotal + tid) * nblk * 2;
+    double s = 0, q = 0;
+    for (int j = 0; j < nblk; ++j) {
+      s += p[2 * j];
+      q += p[2 * j + 1];
+    }
+    const double mean = s * inv_count;
+    double var = q * inv_count - mean * mean;
+    if (var < 0) var = 0;
+    s_mean[tid] = (float)mean;
+    s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += blockDim.x) {
+    const int g = c / cpg;
+    const float sc = s_rstd[g] * gamma[c];
+    scale[(size_t)b * C + c] = sc;
+    shift[(size_t)b * C + c] = -sc * s_mean[g] + beta[c];
+  }
+}
+
+// ---- LayerNorm: one wave per row, C = 256*NV (NV float4 per lane) --------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int rows, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps,
+                                                        const float* __restrict__ pos, int npos, float* __restrict__ y,
+                                                        float* __restrict__ ypos) {
+  constexpr int C = NV * 256;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * C;
+  f32x4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i] = *reinterpret_cast<const f32x4*>(xr + (i * 64 + lane) * 4);
+    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  }
+  const float mean = cf_wave_sum(s) * (1.0f / C);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = v[i][e] - mean;
+      q += d * d;
+    }
+  const float var = cf_wave_sum(q) * (1.0f / C);
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+    const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + bt[e];
+    *reinterpret_cast<f32x4*>(y + (size_t)row * C + c) = o;
+    if (ypos) {
+      const f32x4 pe = *reinterpret_cast<const f32x4*>(pos + (size_t)(row % npos) * C + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] += pe[e];
+      *reinterpret_cast<f32x4*>(ypos + (size_t)row * C + c) = o;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int cf_groupnorm_stats(const float* x, int batch, int hw, int c, int cpg, double* partial, int gtotal,
+                                  int g0, int nblk, cf_stream_t stream) {
+  CF_REQUIRE(x && partial, "cf_groupnorm_stats: null pointer");
+  CF_REQUIRE(c >= 16 && c <= 1024 && (1024 % c) == 0, "cf_groupnorm_stats: C=%d must divide 1024 and be >= 16", c);
+  CF_REQUIRE(cpg >= 2 && (cpg % 2) == 0 && c % cpg == 0 && c / cpg <= 64, "cf_groupnorm_stats: bad cpg %d for C %d", cpg, c);
+  CF_REQUIRE(nblk >= 1 && batch >= 1 && hw >= 1 && g0 >= 0 && g0 + c / cpg <= gtotal, "cf_groupnorm_stats: bad dims");
+  const int rows_per_blk = (hw + nblk - 1) / nblk;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, batch), dim3(256), 0, (hipStream_t)stream, x, hw, c, cpg, rows_per_blk,
+                     partial, gtotal, g0, nblk);
+  CF_CHECK_LAUNCH("cf_groupnorm_stats");
+  return CF_OK;
+}
+
+extern "C" int cf_groupnorm_finalize(const double* partial, int batch, int gtotal, int nblk, int c, int cpg,
+                                     int64_t count, const float* gamma, const float* beta, float eps, float* scale,
+                                     float* shift, cf_stream_t stream) {
+  CF_REQUIRE(partial && gamma && beta && scale && shift, "cf_groupnorm_finalize: null pointer");
+  CF_REQUIRE(gtotal >= 1 && gtotal <= 64 && c == gtotal * cpg && count > 0, "cf_groupnorm_finalize: bad dims");
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, partial, gtotal, nblk, c, cpg,
+                     1.0 / (double)count, gamma, beta, eps, scale, shift);
+  CF_CHECK_LAUNCH("cf_groupnorm_finalize");
+  return CF_OK;
+}
+
+extern "C" int cf_layernorm(const float* x, int rows, int c, const float* gamma, const float* beta, float eps,
+                            const float* pos, int npos, float* y, float* ypos, cf_stream_t stream) {
+  CF_REQUIRE(x && gamma && beta && y, "cf_layernorm: null pointer");
+  CF_REQUIRE(!ypos || (pos && npos > 0), "cf_layernorm: ypos needs pos/npos");
+  CF_REQUIRE(rows > 0, "cf_layernorm: rows");
+  const dim3 grid((rows + 3) / 4), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (c) {
+    case 256: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, rows, gamma, beta, eps, pos, npos, y, ypos); break;
+    case 512: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, rows, gamma, beta, eps, pos, npos, y, ypos); break;
+    case 768: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, s, x, rows, gamma, beta, eps, pos, npos, y, ypos); break;
+    case 1024: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, x, rows, gamma, beta, eps, pos, npos, y, ypos); break;
+    default:
+      cf_set_error("cf_layernorm: C=%d unsupported (256/512/768/1024)", c);
+      return CF_ERR_ARG;
+  }
+  CF_CHECK_LAUNCH("cf_layernorm");
+  return CF_OK;
+}

@@ -1,0 +1,119 @@
+"""ctypes binding of libcodeformer_hip.so (the C ABI declared in include/codeformer_hip.h).
+
+This is the only place where Python touches the native library.  There is NO fallback: if the shared object is
+missing or fails to load, every op raises -- a GPU run can never silently take another path.
+"""
+import ctypes
+import os
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, 'libcodeformer_hip.so')
+
+c_float_p = ctypes.c_void_p  # device pointers are passed as integers
+
+PRO_NONE, PRO_AFFINE, PRO_AFFINE_SWISH, PRO_LEAKY = 0, 1, 2, 3
+EPI_NONE, EPI_RESIDUAL, EPI_SFT, EPI_GELU = 0, 1, 2, 3
+
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of struct cf_conv_desc (include/codeformer_hip.h)."""
+    _fields_ = [
+        ('in0', ctypes.c_void_p), ('in1', ctypes.c_void_p),
+        ('c0', ctypes.c_int32), ('c1', ctypes.c_int32),
+        ('batch', ctypes.c_int32), ('hin', ctypes.c_int32), ('win', ctypes.c_int32),
+        ('hout', ctypes.c_int32), ('wout', ctypes.c_int32),
+        ('cout', ctypes.c_int32), ('cout_pad', ctypes.c_int32),
+        ('taps', ctypes.c_int32), ('stride', ctypes.c_int32), ('upsample', ctypes.c_int32),
+        ('in_nchw', ctypes.c_int32), ('out_nchw', ctypes.c_int32),
+        ('prologue', ctypes.c_int32), ('epilogue', ctypes.c_int32),
+        ('pro_scale', ctypes.c_void_p), ('pro_shift', ctypes.c_void_p),
+        ('weight', ctypes.c_void_p), ('bias', ctypes.c_void_p),
+        ('res', ctypes.c_void_p), ('sft_scale', ctypes.c_void_p),
+        ('sft_w', ctypes.c_float),
+        ('out', ctypes.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); every symbol of include/codeformer_hip.h
+_I, _P, _F, _L = ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctypes.c_int64
+SIGNATURES = {
+    'cf_version': (_I, []),
+    'cf_last_error': (ctypes.c_char_p, []),
+    'cf_device_cu_count': (_I, []),
+    'cf_conv2d': (_I, [ctypes.POINTER(ConvDesc), _P]),
+    'cf_pack_conv_weight': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    'cf_packed_weight_elems': (_L, [_I, _I, _I]),
+    'cf_groupnorm_stats': (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P]),
+    'cf_groupnorm_finalize': (_I, [_P, _I, _I, _I, _I, _I, _L, _P, _P, _F, _P, _P, _P]),
+    'cf_layernorm': (_I, [_P, _I, _I, _P, _P, _F, _P, _I, _P, _P, _P]),
+    'cf_attention': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
+    'cf_argmax_rows': (_I, [_P, _I, _I, _P, _P]),
+    'cf_codebook_gather_adain': (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _F, _P, _P]),
+    'cf_row_sqnorm': (_I, [_P, _I, _I, _P, _P]),
+    'cf_vq_argmin': (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
+    'cf_nchw_to_nhwc': (_I, [_P, _I, _I, _I, _P, _P]),
+    'cf_nhwc_to_nchw': (_I, [_P, _I, _I, _I, _P, _P]),
+    'cf_img_u8_to_tensor': (_I, [_P, _I, _I, _I, _P, _P]),
+    'cf_tensor_to_img_u8': (_I, [_P, _I, _I, _I, _P, _P]),
+    'cf_fused_bias_act': (_I, [_P, _P, _L, _I, _I, _F, _F, _P, _P]),
+    'cf_upfirdn2d': (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+}
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared object (once).  Raises NativeLibraryError if it is absent -- never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f'{LIB_PATH} not found: build it with `python -m codeformer_amd.build` (hipcc --offload-arch=gfx950). '
+            'codeformer_amd has no non-HIP execution path for GPU tensors.')
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise NativeLibraryError(f'cannot load {LIB_PATH}: {e}') from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.cf_version() != 1:
+        raise NativeLibraryError(f'ABI version mismatch: library {lib.cf_version()}, binding 1')
+    _lib = lib
+    return lib
+
+
+def is_available():
+    return os.path.exists(LIB_PATH)
+
+
+def last_error():
+    return load().cf_last_error().decode('utf-8', 'replace')
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError(f'{what} failed ({status}): {last_error()}')
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Tensors must be fp32/int64/uint8/float64 CUDA + contiguous."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ValueError('codeformer_amd ops need CUDA (ROCm) tensors')
+    if not t.is_contiguous():
+        raise ValueError('codeformer_amd ops need contiguous tensors')
+    return t.data_ptr()

@@ -1,0 +1,273 @@
+"""Host-side operator layer: torch tensors in, HIP kernels through the C ABI, torch tensors out.
+
+Activations are fp32 channels-last tensors of shape (B, H, W, C) ("NHWC"); token matrices are (rows, cols).
+PyTorch only provides device memory (torch.empty) and the current stream; every FLOP runs in
+libcodeformer_hip.so.  Nothing here has a CPU/eager fallback.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import lib as L
+from .lib import (EPI_GELU, EPI_NONE, EPI_RESIDUAL, EPI_SFT, PRO_AFFINE, PRO_AFFINE_SWISH, PRO_LEAKY, PRO_NONE)
+
+GN_GROUPS = 32
+GN_EPS = 1e-6
+
+
+def _f32(t):
+    if t.dtype != torch.float32:
+        raise TypeError(f'expected float32, got {t.dtype}')
+    return t
+
+
+class PackedWeight:
+    """A conv / linear weight in the kernel layout [tap][cin_pad/16][cout_pad][16] (+ bias)."""
+
+    __slots__ = ('w', 'bias', 'cout', 'cin', 'taps', 'cout_pad', 'cin_pad')
+
+    def __init__(self, w, bias, cout, cin, taps, cout_pad, cin_pad):
+        self.w, self.bias, self.cout, self.cin, self.taps = w, bias, cout, cin, taps
+        self.cout_pad, self.cin_pad = cout_pad, cin_pad
+
+
+def _cout_pad(cout):
+    if cout <= 32:
+        return 32
+    if cout <= 64:
+        return 64
+    return (cout + 127) // 128 * 128
+
+
+def pack_weight(weight, bias=None):
+    """weight: (cout, cin, 3, 3) | (cout, cin, 1, 1) | (cout, cin) CUDA fp32 -> PackedWeight."""
+    lib = L.load()
+    w = _f32(weight.detach()).contiguous()
+    cout, cin = w.shape[0], w.shape[1]
+    taps = 1
+    if w.dim() == 4:
+        if w.shape[2] != w.shape[3] or w.shape[2] not in (1, 3):
+            raise ValueError(f'unsupported kernel size {tuple(w.shape[2:])}')
+        taps = w.shape[2] * w.shape[3]
+    elif w.dim() != 2:
+        raise ValueError('weight must be 2-D or 4-D')
+    cout_pad, cin_pad = _cout_pad(cout), (cin + 15) // 16 * 16
+    packed = torch.empty(lib.cf_packed_weight_elems(cin_pad, taps, cout_pad), dtype=torch.float32, device=w.device)
+    L.check(lib.cf_pack_conv_weight(L.ptr(w), cout, cin, taps, cout_pad, cin_pad, L.ptr(packed), L.stream_ptr()),
+            'cf_pack_conv_weight')
+    b = None if bias is None else _f32(bias.detach()).contiguous().clone()
+    return PackedWeight(packed, b, cout, cin, taps, cout_pad, cin_pad)
+
+
+def pack_weight_cat(weights, biases):
+    """Row-concatenate several (cout_i, cin[,1,1]) weights into one GEMM (e.g. q|k|v)."""
+    w = torch.cat([x.detach().reshape(x.shape[0], x.shape[1]) for x in weights], dim=0)
+    b = None if biases is None else torch.cat([x.detach() for x in biases], dim=0)
+    return pack_weight(w, b)
+
+
+def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale=None, shift=None,
+           epilogue=EPI_NONE, res=None, sft_scale=None, sft_w=0.0, in_nchw=False, out_nchw=False):
+    """Implicit-GEMM conv (3x3 / 1x1).  x: (B,H,W,C0) [x2: (B,H,W,C1) concatenated after x]; returns (B,Ho,Wo,cout)
+    (or (B,cout,Ho,Wo) when out_nchw).  With in_nchw, x is (B,C<=4,H,W)."""
+    lib = L.load()
+    _f32(x)
+    if in_nchw:
+        B, c0, H, W = x.shape
+    else:
+        B, H, W, c0 = x.shape
+    c1 = 0
+    if x2 is not None:
+        if x2.shape[:3] != x.shape[:3]:
+            raise ValueError('x2 spatial shape mismatch')
+        c1 = x2.shape[3]
+    if c0 + c1 != pw.cin:
+        raise ValueError(f'input channels {c0}+{c1} != weight cin {pw.cin}')
+    if stride == 2:
+        Ho, Wo = H // 2, W // 2
+    else:
+        Ho, Wo = (H * 2, W * 2) if upsample else (H, W)
+    shape = (B, pw.cout, Ho, Wo) if out_nchw else (B, Ho, Wo, pw.cout)
+    out = torch.empty(shape, dtype=torch.float32, device=x.device)
+    for t in (res, sft_scale):
+        if t is not None and tuple(t.shape) != (B, Ho, Wo, pw.cout):
+            raise ValueError(f'epilogue operand shape {tuple(t.shape)} != {(B, Ho, Wo, pw.cout)}')
+    for t in (scale, shift):
+        if t is not None and tuple(t.shape) != (B, c0 + c1):
+            raise ValueError(f'prologue table shape {tuple(t.shape)} != {(B, c0 + c1)}')
+    d = L.ConvDesc(
+        in0=L.ptr(x), in1=L.ptr(x2), c0=c0, c1=c1, batch=B, hin=H, win=W, hout=Ho, wout=Wo, cout=pw.cout,
+        cout_pad=pw.cout_pad, taps=pw.taps, stride=stride, upsample=int(bool(upsample)), in_nchw=int(bool(in_nchw)),
+        out_nchw=int(bool(out_nchw)), prologue=prologue, epilogue=epilogue, pro_scale=L.ptr(scale),
+        pro_shift=L.ptr(shift), weight=L.ptr(pw.w), bias=L.ptr(pw.bias), res=L.ptr(res), sft_scale=L.ptr(sft_scale),
+        sft_w=float(sft_w), out=L.ptr(out))
+    L.check(lib.cf_conv2d(ctypes.byref(d), L.stream_ptr()), 'cf_conv2d')
+    return out
+
+
+def linear(x, pw, *, epilogue=EPI_NONE, res=None):
+    """x: (M, K) -> (M, N) through the 1x1 path of the same kernel (M must be a multiple of 256)."""
+    M, K = x.shape
+    if M % 256:
+        raise ValueError(f'linear: rows {M} must be a multiple of 256')
+    r4 = None if res is None else res.view(1, M // 16, 16, pw.cout)
+    y = conv2d(x.view(1, M // 16, 16, K), pw, epilogue=epilogue, res=r4)
+    return y.view(M, pw.cout)
+
+
+def groupnorm_tables(xs, gamma, beta, eps=GN_EPS, groups=GN_GROUPS):
+    """GroupNorm(groups) statistics of the channel-concatenation of xs (each (B,H,W,Ci)) folded with the affine
+    parameters into per-(b,c) scale / shift tables (B, sum Ci), to be applied by a conv prologue."""
+    lib = L.load()
+    B, H, W, _ = xs[0].shape
+    ctot = sum(t.shape[3] for t in xs)
+    if ctot % groups:
+        raise ValueError(f'{ctot} channels not divisible by {groups} groups')
+    cpg = ctot // groups
+    hw = H * W
+    nblk = max(1, min(64, (hw * max(t.shape[3] for t in xs) * 4 + (1 << 18) - 1) >> 18))
+    part = torch.empty(B * groups * nblk * 2, dtype=torch.float64, device=xs[0].device)
+    g0 = 0
+    for t in xs:
+        _f32(t)
+        c = t.shape[3]
+        if c % cpg:
+            raise ValueError('concat boundary splits a group')
+        L.check(lib.cf_groupnorm_stats(L.ptr(t), B, hw, c, cpg, L.ptr(part), groups, g0, nblk, L.stream_ptr()),
+                'cf_groupnorm_stats')
+        g0 += c // cpg
+    scale = torch.empty(B, ctot, dtype=torch.float32, device=xs[0].device)
+    shift = torch.empty_like(scale)
+    L.check(lib.cf_groupnorm_finalize(L.ptr(part), B, groups, nblk, ctot, cpg, hw * cpg, L.ptr(gamma), L.ptr(beta),
+                                      float(eps), L.ptr(scale), L.ptr(shift), L.stream_ptr()), 'cf_groupnorm_finalize')
+    return scale, shift
+
+
+def layernorm(x, gamma, beta, eps=1e-5, pos=None):
+    """x: (rows, C).  Returns LN(x) and, when pos (npos, C) is given, also LN(x)+pos[row % npos]."""
+    lib = L.load()
+    rows, C = x.shape
+    y = torch.empty_like(x)
+    ypos = torch.empty_like(x) if pos is not None else None
+    npos = 0 if pos is None else pos.shape[0]
+    L.check(lib.cf_layernorm(L.ptr(_f32(x)), rows, C, L.ptr(gamma), L.ptr(beta), float(eps), L.ptr(pos), npos, L.ptr(y),
+                             L.ptr(ypos), L.stream_ptr()), 'cf_layernorm')
+    return (y, ypos) if pos is not None else y
+
+
+def attention(q, k, v, batch, heads, head_dim, scale):
+    """q,k,v: 2-D views (batch*256, >= heads*head_dim) that may be column slices of wider row-major matrices
+    (row stride taken from .stride(0)).  Returns (batch*256, heads*head_dim)."""
+    lib = L.load()
+    rows = batch * 256
+    for t in (q, k, v):
+        if t.shape[0] != rows or t.stride(1) != 1 or t.shape[1] != heads * head_dim:
+            raise ValueError('attention operand must be (batch*256, heads*head_dim) with unit column stride')
+    out = torch.empty(rows, heads * head_dim, dtype=torch.float32, device=q.device)
+    L.check(lib.cf_attention(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
+                             L.ptr(out), out.stride(0), batch, heads, head_dim, 256, float(scale), L.stream_ptr()),
+            'cf_attention')
+    return out
+
+
+def argmax_rows(logits):
+    lib = L.load()
+    rows, n = logits.shape
+    idx = torch.empty(rows, dtype=torch.int64, device=logits.device)
+    L.check(lib.cf_argmax_rows(L.ptr(_f32(logits)), rows, n, L.ptr(idx), L.stream_ptr()), 'cf_argmax_rows')
+    return idx
+
+
+def codebook_gather(idx, codebook, batch, ntok, lq=None, eps=1e-5):
+    """idx: (batch*ntok,) int64 -> (batch, ntok, dim); AdaIN against lq (batch, ntok, dim) when given."""
+    lib = L.load()
+    ncodes, dim = codebook.shape
+    out = torch.empty(batch, ntok, dim, dtype=torch.float32, device=codebook.device)
+    L.check(lib.cf_codebook_gather_adain(L.ptr(idx), L.ptr(_f32(codebook)), ncodes, L.ptr(lq), batch, ntok, dim,
+                                         int(lq is not None), float(eps), L.ptr(out), L.stream_ptr()),
+            'cf_codebook_gather_adain')
+    return out
+
+
+def vq_nearest(z_tokens, codebook, pw_codebook=None):
+    """z_tokens: (rows, dim), rows % 256 == 0.  Returns (idx int64 (rows,), dmin (rows,), (scores, zz, ee))."""
+    lib = L.load()
+    rows, dim = z_tokens.shape
+    ncodes = codebook.shape[0]
+    pw = pw_codebook or pack_weight(codebook)
+    scores = linear(z_tokens, pw)
+    zz = torch.empty(rows, dtype=torch.float32, device=z_tokens.device)
+    ee = torch.empty(ncodes, dtype=torch.float32, device=z_tokens.device)
+    L.check(lib.cf_row_sqnorm(L.ptr(z_tokens), rows, dim, L.ptr(zz), L.stream_ptr()), 'cf_row_sqnorm')
+    L.check(lib.cf_row_sqnorm(L.ptr(_f32(codebook)), ncodes, dim, L.ptr(ee), L.stream_ptr()), 'cf_row_sqnorm')
+    idx = torch.empty(rows, dtype=torch.int64, device=z_tokens.device)
+    dmin = torch.empty(rows, dtype=torch.float32, device=z_tokens.device)
+    L.check(lib.cf_vq_argmin(L.ptr(scores), L.ptr(zz), L.ptr(ee), rows, ncodes, L.ptr(idx), L.ptr(dmin), L.stream_ptr()),
+            'cf_vq_argmin')
+    return idx, dmin, (scores, zz, ee)
+
+
+def to_nhwc(x):
+    """(B,C,H,W) -> (B,H,W,C) by the HIP transpose kernel."""
+    lib = L.load()
+    B, C, H, W = x.shape
+    x = _f32(x).contiguous()
+    y = torch.empty(B, H, W, C, dtype=torch.float32, device=x.device)
+    L.check(lib.cf_nchw_to_nhwc(L.ptr(x), B, C, H * W, L.ptr(y), L.stream_ptr()), 'cf_nchw_to_nhwc')
+    return y
+
+
+def to_nchw(x):
+    """(B,H,W,C) -> (B,C,H,W)."""
+    lib = L.load()
+    B, H, W, C = x.shape
+    y = torch.empty(B, C, H, W, dtype=torch.float32, device=x.device)
+    L.check(lib.cf_nhwc_to_nchw(L.ptr(_f32(x)), B, C, H * W, L.ptr(y), L.stream_ptr()), 'cf_nhwc_to_nchw')
+    return y
+
+
+def img_u8_to_tensor(img):
+    """uint8 (B,H,W,3) BGR on device -> fp32 (B,3,H,W) RGB in [-1,1]."""
+    lib = L.load()
+    B, H, W, _ = img.shape
+    out = torch.empty(B, 3, H, W, dtype=torch.float32, device=img.device)
+    L.check(lib.cf_img_u8_to_tensor(L.ptr(img), B, H, W, L.ptr(out), L.stream_ptr()), 'cf_img_u8_to_tensor')
+    return out
+
+
+def tensor_to_img_u8(t):
+    """fp32 (B,3,H,W) RGB -> uint8 (B,H,W,3) BGR with tensor2img(min_max=(-1,1)) rounding."""
+    lib = L.load()
+    B, _, H, W = t.shape
+    img = torch.empty(B, H, W, 3, dtype=torch.uint8, device=t.device)
+    L.check(lib.cf_tensor_to_img_u8(L.ptr(_f32(t).contiguous()), B, H, W, L.ptr(img), L.stream_ptr()), 'cf_tensor_to_img_u8')
+    return img
+
+
+def fused_bias_act(x, bias, negative_slope=0.2, scale=math.sqrt(2.0)):
+    """x: (N,C,...) NCHW-style contiguous; y = leaky_relu(x + bias[c]) * scale."""
+    lib = L.load()
+    x = _f32(x).contiguous()
+    hw = 1
+    for s in x.shape[2:]:
+        hw *= s
+    y = torch.empty_like(x)
+    L.check(lib.cf_fused_bias_act(L.ptr(x), L.ptr(bias), x.numel(), x.shape[1], hw, float(negative_slope), float(scale),
+                                  L.ptr(y), L.stream_ptr()), 'cf_fused_bias_act')
+    return y
+
+
+def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0)):
+    """x: (N,C,H,W); kernel: (kh,kw)."""
+    lib = L.load()
+    x = _f32(x).contiguous()
+    n, c, h, w = x.shape
+    kh, kw = kernel.shape
+    p0, p1 = pad
+    oh = (h * up + p0 + p1 - kh) // down + 1
+    ow = (w * up + p0 + p1 - kw) // down + 1
+    y = torch.empty(n, c, oh, ow, dtype=torch.float32, device=x.device)
+    L.check(lib.cf_upfirdn2d(L.ptr(x), n * c, h, w, L.ptr(_f32(kernel).contiguous()), kh, kw, up, up, down, down, p0, p1,
+                             p0, p1, L.ptr(y), L.stream_ptr()), 'cf_upfirdn2d')
+    return y

@@ -1,0 +1,112 @@
+"""Image <-> tensor helpers of the tensor boundary (API of the reference's basicsr/utils/img_util.py:9-94,135-149).
+
+cv2 / torchvision are not available on the target image, so decoding / encoding go through PIL and the colour
+swaps through numpy slicing.  Host-side semantics (dtype promotion, clamp, round-half-even) follow the reference;
+the batched on-device versions are ops.img_u8_to_tensor / ops.tensor_to_img_u8.
+"""
+import math
+import os
+
+import numpy as np
+import torch
+
+
+def imread_bgr(path):
+    """cv2.imread(path, cv2.IMREAD_COLOR) equivalent: uint8 HWC BGR (alpha dropped, gray replicated)."""
+    from PIL import Image
+    with Image.open(path) as im:
+        rgb = np.asarray(im.convert('RGB'))
+    return np.ascontiguousarray(rgb[:, :, ::-1])
+
+
+def resize_bilinear(img, size):
+    """cv2.resize(img, size, INTER_LINEAR) stand-in (identity when the size already matches)."""
+    h, w = img.shape[:2]
+    if (w, h) == tuple(size):
+        return img
+    from PIL import Image
+    rgb = Image.fromarray(np.ascontiguousarray(img[:, :, ::-1]))
+    return np.ascontiguousarray(np.asarray(rgb.resize(size, Image.BILINEAR))[:, :, ::-1])
+
+
+def img2tensor(imgs, bgr2rgb=True, float32=True):
+    """HWC (BGR) ndarray(s) -> CHW (RGB) tensor(s); float64 input is narrowed to float32 before the swap."""
+
+    def one(img):
+        if img.ndim == 3 and img.shape[2] == 3 and bgr2rgb:
+            if img.dtype == np.float64:
+                img = img.astype(np.float32)
+            img = img[:, :, ::-1]
+        t = torch.from_numpy(np.ascontiguousarray(img.transpose(2, 0, 1)))
+        return t.float() if float32 else t
+
+    return [one(i) for i in imgs] if isinstance(imgs, list) else one(imgs)
+
+
+def normalize_(t, mean, std):
+    """In-place (t - mean) / std per channel (torchvision.transforms.functional.normalize, inplace=True)."""
+    m = torch.as_tensor(mean, dtype=t.dtype, device=t.device).view(-1, 1, 1)
+    s = torch.as_tensor(std, dtype=t.dtype, device=t.device).view(-1, 1, 1)
+    return t.sub_(m).div_(s)
+
+
+def _grid(t, nrow, padding=2):
+    """Minimal torchvision.utils.make_grid(normalize=False) for (B,C,H,W)."""
+    b, c, h, w = t.shape
+    if c == 1:
+        t = t.expand(b, 3, h, w)
+        c = 3
+    xmaps = min(nrow, b)
+    ymaps = int(math.ceil(b / xmaps))
+    H, W = h + padding, w + padding
+    grid = t.new_zeros((c, H * ymaps + padding, W * xmaps + padding))
+    k = 0
+    for y in range(ymaps):
+        for x in range(xmaps):
+            if k >= b:
+                break
+            grid[:, y * H + padding:y * H + padding + h, x * W + padding:x * W + padding + w] = t[k]
+            k += 1
+    return grid
+
+
+def tensor2img(tensor, rgb2bgr=True, out_type=np.uint8, min_max=(0, 1)):
+    """Tensor(s) (B,3|1,H,W) / (3|1,H,W) / (H,W), RGB -> ndarray(s) HWC BGR.
+
+    clamp to min_max, rescale to [0,1]; uint8 output = round-half-even(x*255) (basicsr/utils/img_util.py:66-90).
+    """
+    if not (torch.is_tensor(tensor) or (isinstance(tensor, list) and all(torch.is_tensor(t) for t in tensor))):
+        raise TypeError(f'tensor or list of tensors expected, got {type(tensor)}')
+    tensors = [tensor] if torch.is_tensor(tensor) else tensor
+    result = []
+    for t in tensors:
+        t = t.squeeze(0).float().detach().cpu().clamp_(*min_max)
+        t = (t - min_max[0]) / (min_max[1] - min_max[0])
+        if t.dim() == 4:
+            t = _grid(t, nrow=int(math.sqrt(t.size(0))))
+        if t.dim() == 3:
+            img = t.numpy().transpose(1, 2, 0)
+            if img.shape[2] == 1:
+                img = np.squeeze(img, axis=2)
+            elif rgb2bgr:
+                img = img[:, :, ::-1]
+        elif t.dim() == 2:
+            img = t.numpy()
+        else:
+            raise TypeError(f'Only support 4D, 3D or 2D tensor. But received with dimension: {t.dim()}')
+        if out_type == np.uint8:
+            img = (img * 255.0).round()
+        result.append(np.ascontiguousarray(img.astype(out_type)))
+    return result[0] if len(result) == 1 else result
+
+
+def imwrite(img, file_path, params=None, auto_mkdir=True):
+    """Write a uint8 HWC BGR (or HW gray) array; format from the extension (cv2.imwrite stand-in)."""
+    from PIL import Image
+    if auto_mkdir:
+        os.makedirs(os.path.abspath(os.path.dirname(file_path)), exist_ok=True)
+    arr = np.asarray(img)
+    if arr.ndim == 3:
+        arr = arr[:, :, ::-1]
+    Image.fromarray(np.ascontiguousarray(arr)).save(file_path)
+    return True

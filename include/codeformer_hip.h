@@ -1,0 +1,163 @@
+/*
+ * codeformer_hip.h -- C ABI of libcodeformer_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the CodeFormer aligned-face hot path
+ * (reference: basicsr/archs/codeformer_arch.py:223-280 CodeFormer.forward and the
+ * VQGAN blocks of basicsr/archs/vqgan_arch.py).  The reference has no FFI on this
+ * path: every arithmetic step is a PyTorch ATen call issued from Python.  Each
+ * entry point below therefore cites the ATen call site(s) of the reference that
+ * it replaces.  The Python host (codeformer_amd/lib.py) binds these with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch.empty allocations);
+ *   - every function only ENQUEUES work on `stream` (a hipStream_t passed as void*);
+ *     nothing synchronises, nothing allocates, there is no global mutable state
+ *     besides the thread-local last-error string;
+ *   - return 0 on success, <0 on error (cf_last_error() describes it);
+ *   - activations are fp32, channels-last ("NHWC": [batch][h][w][c]) unless a flag
+ *     says NCHW; token matrices are row-major [rows][cols] (the same memory).
+ */
+#ifndef CODEFORMER_HIP_H
+#define CODEFORMER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CF_ABI_VERSION 1
+
+typedef void* cf_stream_t; /* hipStream_t */
+
+enum cf_status {
+  CF_OK = 0,
+  CF_ERR_ARG = -1,      /* unsupported shape / null pointer */
+  CF_ERR_LAUNCH = -2,   /* HIP launch error */
+};
+
+int cf_version(void);
+const char* cf_last_error(void);
+/* number of compute units of the current device (for host-side grid heuristics) */
+int cf_device_cu_count(void);
+
+/* ---- convolution / linear as implicit GEMM on fp32 MFMA ------------------------------------
+ * Replaces: F.conv2d 3x3 s1 p1 (vqgan_arch.py:132,147,149,243,266,292,314; codeformer_arch.py:142-149),
+ *           pad(0,1,0,1)+conv 3x3 s2 (vqgan_arch.py:120-126), nearest x2 + conv (vqgan_arch.py:134-138),
+ *           conv 1x1 (vqgan_arch.py:151,173-200), nn.Linear (codeformer_arch.py:104,106,183,192 and the
+ *           MultiheadAttention in/out projections), with the surrounding elementwise work fused:
+ *           GroupNorm-apply + swish (vqgan_arch.py:14-20), LeakyReLU(0.2) (codeformer_arch.py:143,148),
+ *           torch.cat([enc,dec]) (codeformer_arch.py:152), residual adds, GELU (codeformer_arch.py:132),
+ *           the SFT combine dec + w*(dec*scale+shift) (codeformer_arch.py:155-156).
+ */
+enum cf_prologue {
+  CF_PRO_NONE = 0,
+  CF_PRO_AFFINE = 1,        /* x*scale[b][c] + shift[b][c]                (GroupNorm apply)         */
+  CF_PRO_AFFINE_SWISH = 2,  /* y = x*scale+shift ; y*sigmoid(y)           (GroupNorm apply + swish) */
+  CF_PRO_LEAKY = 3,         /* x>0 ? x : 0.2*x                                                       */
+};
+enum cf_epilogue {
+  CF_EPI_NONE = 0,      /* acc + bias                                      */
+  CF_EPI_RESIDUAL = 1,  /* acc + bias + res                                */
+  CF_EPI_SFT = 2,       /* res + sft_w*(res*sft_scale + (acc + bias))      */
+  CF_EPI_GELU = 3,      /* gelu_erf(acc + bias)                            */
+};
+
+typedef struct cf_conv_desc {
+  const float* in0;       /* first input  [batch][hin][win][c0]  (or NCHW when in_nchw) */
+  const float* in1;       /* optional second input, channel-concatenated after in0      */
+  int32_t c0, c1;         /* channels of in0 / in1 (c1 = 0: none); both multiples of 16 unless in_nchw */
+  int32_t batch, hin, win;
+  int32_t hout, wout;     /* s1: hin<<upsample ; s2: hin/2 */
+  int32_t cout;           /* valid output channels */
+  int32_t cout_pad;       /* packed weight rows (multiple of the N tile: 32/64/128) */
+  int32_t taps;           /* 1 or 9 */
+  int32_t stride;         /* 1 or 2 (2: pad right/bottom only, vqgan_arch.py:123) */
+  int32_t upsample;       /* 1: nearest x2 of the input fused into the gather */
+  int32_t in_nchw;        /* 1: in0 is NCHW with c0 <= 4 channels (network input) */
+  int32_t out_nchw;       /* 1: write out as NCHW (network output) */
+  int32_t prologue;       /* enum cf_prologue */
+  int32_t epilogue;       /* enum cf_epilogue */
+  const float* pro_scale; /* [batch][c0+c1] */
+  const float* pro_shift; /* [batch][c0+c1] */
+  const float* weight;    /* packed by cf_pack_conv_weight */
+  const float* bias;      /* [cout] or NULL */
+  const float* res;       /* [batch][hout][wout][cout] (RESIDUAL / SFT: the `dec` tensor) */
+  const float* sft_scale; /* [batch][hout][wout][cout] (SFT) */
+  float sft_w;
+  float* out;
+} cf_conv_desc;
+
+int cf_conv2d(const cf_conv_desc* d, cf_stream_t stream);
+
+/* Pack a PyTorch conv/linear weight [cout][cin][kh*kw] (taps = 1 or 9) into the kernel layout
+ * [tap][cin_pad/16][cout_pad][16] (zero padded). */
+int cf_pack_conv_weight(const float* w, int cout, int cin, int taps, int cout_pad, int cin_pad,
+                        float* packed, cf_stream_t stream);
+int64_t cf_packed_weight_elems(int cin_pad, int taps, int cout_pad);
+
+/* ---- GroupNorm statistics (vqgan_arch.py:14-15: 32 groups, eps 1e-6, biased variance) --------
+ * stats:    partial (sum, sumsq) in fp64 per (batch, group, block) over an NHWC tensor with C channels
+ *           whose groups are `cpg` channels wide; written at group offset g0 of a [batch][gtotal][nblk][2] table.
+ * finalize: fixed-order sum of the partials -> scale[b][c] = gamma*rstd, shift[b][c] = beta - mean*scale.
+ */
+int cf_groupnorm_stats(const float* x, int batch, int hw, int c, int cpg, double* partial, int gtotal, int g0,
+                       int nblk, cf_stream_t stream);
+int cf_groupnorm_finalize(const double* partial, int batch, int gtotal, int nblk, int c, int cpg, int64_t count,
+                          const float* gamma, const float* beta, float eps, float* scale, float* shift,
+                          cf_stream_t stream);
+
+/* ---- LayerNorm over the last dim (codeformer_arch.py:108-109,124,131,191; eps 1e-5) ----------
+ * y = LN(x)*gamma+beta ; optional ypos = y + pos[row % npos]   (with_pos_embed, codeformer_arch.py:113-116) */
+int cf_layernorm(const float* x, int rows, int c, const float* gamma, const float* beta, float eps,
+                 const float* pos, int npos, float* y, float* ypos, cf_stream_t stream);
+
+/* ---- attention over 256 keys (vqgan_arch.py:207-221 AttnBlock bmm/softmax/bmm, and the
+ *      nn.MultiheadAttention core called at codeformer_arch.py:126) --------------------------------
+ * q,k,v: row (b*256 + i), columns [h*head_dim, (h+1)*head_dim) of matrices with leading dimensions
+ * ldq/ldk/ldv; out likewise with ldo.  softmax over keys of (q.k^T * scale).  head_dim in {64, 512}. */
+int cf_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo,
+                 int batch, int heads, int head_dim, int nkeys, float scale, cf_stream_t stream);
+
+/* ---- code prediction (codeformer_arch.py:257-258 softmax+topk(1)) ------------------------------
+ * argmax over each fp32 row, lowest index wins ties; idx is int64 like the reference's top_idx. */
+int cf_argmax_rows(const float* logits, int rows, int n, int64_t* idx, cf_stream_t stream);
+
+/* ---- codebook lookup (+ AdaIN) (vqgan_arch.py:72-84, codeformer_arch.py:12-43,266) -------------
+ * out[b][p][:] = codebook[idx[b][p]][:]; when adain != 0 the per-(b,c) statistics over the ntok positions
+ * (unbiased variance + eps) of `out` are replaced by those of lq (NHWC [batch][ntok][dim]). */
+int cf_codebook_gather_adain(const int64_t* idx, const float* codebook, int codebook_size, const float* lq,
+                             int batch, int ntok, int dim, int adain, float eps, float* out, cf_stream_t stream);
+
+/* ---- nearest-code L2 quantisation (vqgan_arch.py:33-49 VectorQuantizer.forward) ----------------
+ * The z.E^T product runs on cf_conv2d (taps=1, the packed codebook as weight); these two finish it:
+ * cf_row_sqnorm: out[r] = sum_k x[r][k]^2                      ((z**2).sum(1) and (E**2).sum(1), :40)
+ * cf_vq_argmin:  idx[r] = argmin_j (zz[r] + ee[j]) - 2*scores[r][j]   (:40-45; lowest index on ties) */
+int cf_row_sqnorm(const float* x, int rows, int dim, float* out, cf_stream_t stream);
+int cf_vq_argmin(const float* scores, const float* zz, const float* ee, int rows, int ncodes, int64_t* idx,
+                 float* dist_min, cf_stream_t stream);
+
+/* ---- layout converters at the NCHW module boundary ---------------------------------------------- */
+int cf_nchw_to_nhwc(const float* x, int batch, int c, int hw, float* y, cf_stream_t stream);
+int cf_nhwc_to_nchw(const float* x, int batch, int c, int hw, float* y, cf_stream_t stream);
+
+/* ---- tensor boundary (basicsr/utils/img_util.py:9-35 img2tensor + normalize, :38-94 tensor2img) ---
+ * u8 HWC BGR [batch][h][w][3] -> fp32 NCHW RGB in [-1,1] ((x/255 - 0.5)/0.5), and back
+ * (clamp[-1,1], (x+1)/2*255, round-half-even, RGB->BGR). */
+int cf_img_u8_to_tensor(const uint8_t* img, int batch, int h, int w, float* out, cf_stream_t stream);
+int cf_tensor_to_img_u8(const float* t, int batch, int h, int w, uint8_t* img, cf_stream_t stream);
+
+/* ---- bundled StyleGAN2 ops of basicsr/ops (unused by the hot path) ---------------
+ * cf_fused_bias_act: basicsr/ops/fused_act/src/fused_bias_act_kernel.cu:20-50 forward (act=3, grad=0):
+ *    y = leaky_relu(x + bias[(i / hw) % c], slope) * scale                     (x is NCHW)
+ * cf_upfirdn2d: basicsr/ops/upfirdn2d/src/upfirdn2d_kernel.cu:50-208: planes [nplanes][in_h][in_w]. */
+int cf_fused_bias_act(const float* x, const float* bias, int64_t numel, int c, int hw, float slope, float scale,
+                      float* y, cf_stream_t stream);
+int cf_upfirdn2d(const float* x, int nplanes, int in_h, int in_w, const float* kernel, int kh, int kw, int up_x,
+                 int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, float* y,
+                 cf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CODEFORMER_HIP_H */

@@ -1,0 +1,54 @@
+"""Import the reference's own arch files by path (build container only).
+
+TEST INFRASTRUCTURE ONLY.  /root/reference does not exist on the GPU box, so
+this module is used solely by oracle/make_golden.py (run here, outputs committed
+under tests/golden/) and by CPU tests that skip when the reference is absent.
+
+The full ``basicsr`` package of the reference does not import on PyTorch-ROCm
+(SURVEY.md F4/F5), so the three files the hot path needs are loaded under a stub
+package exactly as SURVEY.md Appendix F describes.
+"""
+import importlib.util
+import logging
+import os
+import sys
+import types
+
+REF = os.environ.get('CODEFORMER_REFERENCE', '/root/reference')
+
+
+def available():
+    return os.path.isfile(os.path.join(REF, 'basicsr/archs/codeformer_arch.py'))
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+def load_reference():
+    """Returns (registry_module, vqgan_arch_module, codeformer_arch_module).
+
+    Installs stub ``basicsr*`` entries in sys.modules -- callers that also want
+    this repo's own ``basicsr`` shim must run in a separate process.
+    """
+    if not available():
+        raise RuntimeError(f'reference not found under {REF}')
+    saved = {k: v for k, v in sys.modules.items() if k == 'basicsr' or k.startswith('basicsr.')}
+    for k in saved:
+        del sys.modules[k]
+    for pkg in ('basicsr', 'basicsr.utils', 'basicsr.archs'):
+        m = types.ModuleType(pkg)
+        m.__path__ = []
+        sys.modules[pkg] = m
+    sys.modules['basicsr.utils'].get_root_logger = lambda *a, **k: logging.getLogger('basicsr_ref')
+    reg = _load('basicsr.utils.registry', f'{REF}/basicsr/utils/registry.py')
+    vq = _load('basicsr.archs.vqgan_arch', f'{REF}/basicsr/archs/vqgan_arch.py')
+    cf = _load('basicsr.archs.codeformer_arch', f'{REF}/basicsr/archs/codeformer_arch.py')
+    # detach the stubs again so that this repo's own basicsr shim stays importable
+    ref_mods = {k: sys.modules.pop(k) for k in list(sys.modules) if k == 'basicsr' or k.startswith('basicsr.')}
+    sys.modules.update(saved)
+    return reg, vq, cf, ref_mods

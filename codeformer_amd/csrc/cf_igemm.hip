@@ -15,6 +15,8 @@
 // is then reused by all 9 taps; the per-tap weight slab is double-buffered in LDS and prefetched
 // through registers while the MFMAs of the previous tap run.  Each wave accumulates a
 // (MI*32) x (NI*32) sub-tile in MI*NI*16 accumulator registers.
+#include <type_traits>
+
 #include "cf_common.h"
 
 namespace {
@@ -56,7 +58,7 @@ struct Cfg {
 __device__ __forceinline__ float swishf(float y) { return y * (1.0f / (1.0f + expf(-y))); }
 
 template <int TAPS, int STRIDE, int WM, int WN, int MI, int NI, bool IN_NCHW>
-__global__ __launch_bounds__(256) void igemm_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, 3) void igemm_kernel(const ConvArgs a) {
   using C = Cfg<TAPS, STRIDE, WM, WN, MI, NI>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const As = smem;
@@ -111,42 +113,49 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvArgs a) {
     pix[j] = v;
   }
 
+  // Loads are issued UNCONDITIONALLY from a clamped (always valid) address and zeroed by a select afterwards:
+  // a load under a divergent branch makes hipcc wait for it on the spot, which would serialise the prefetch.
   auto load_A = [&](int chunk, f32x4(&ra)[C::APT]) {
     const int c = chunk * CF_BK + k4 * 4;
     if (IN_NCHW) {
       const size_t plane = (size_t)a.hin * a.win;
       const float* base = a.in0 + (size_t)b * a.c0 * plane;
+      const int c1 = a.c0 > 1 ? 1 : 0, c2 = a.c0 > 2 ? 2 : 0, c3 = a.c0 > 3 ? 3 : 0;
 #pragma unroll
       for (int j = 0; j < C::APT; ++j) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (pix[j] >= 0 && c == 0) {
-          v[0] = base[pix[j]];
-          if (a.c0 > 1) v[1] = base[plane + pix[j]];
-          if (a.c0 > 2) v[2] = base[2 * plane + pix[j]];
-          if (a.c0 > 3) v[3] = base[3 * plane + pix[j]];
-        }
+        const int pj = pix[j] < 0 ? 0 : pix[j];
+        f32x4 v;
+        v[0] = base[pj];
+        v[1] = base[c1 * plane + pj];
+        v[2] = base[c2 * plane + pj];
+        v[3] = base[c3 * plane + pj];
+        const bool ok = pix[j] >= 0 && c == 0;
+        v[0] = ok ? v[0] : 0.f;
+        v[1] = (ok && a.c0 > 1) ? v[1] : 0.f;
+        v[2] = (ok && a.c0 > 2) ? v[2] : 0.f;
+        v[3] = (ok && a.c0 > 3) ? v[3] : 0.f;
         ra[j] = v;
       }
     } else {
-      const float* src;
-      int cs, cc;
-      if (c < a.c0) {
-        src = a.in0; cs = a.c0; cc = c;
-      } else {
-        src = a.in1; cs = a.c1; cc = c - a.c0;
-      }
+      const bool first = c < a.c0;
+      const float* src = first ? a.in0 : a.in1;
+      const int cs = first ? a.c0 : a.c1;
+      const int cc = first ? c : c - a.c0;
 #pragma unroll
       for (int j = 0; j < C::APT; ++j) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (pix[j] >= 0) v = *reinterpret_cast<const f32x4*>(src + (size_t)pix[j] * cs + cc);
+        const int pj = pix[j] < 0 ? 0 : pix[j];
+        f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)pj * cs + cc);
+        if (pix[j] < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
         ra[j] = v;
       }
     }
   };
 
-  auto store_A = [&](int buf, const f32x4(&ra)[C::APT], int chunk) {
+  // zero padding must stay exactly zero: it pads the conv INPUT, i.e. the post-activation tensor
+  auto store_A_mode = [&](int buf, const f32x4(&ra)[C::APT], int chunk, auto mode) {
+    constexpr int PRO = decltype(mode)::value;
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (a.prologue == CF_PRO_AFFINE || a.prologue == CF_PRO_AFFINE_SWISH) {
+    if (PRO == CF_PRO_AFFINE || PRO == CF_PRO_AFFINE_SWISH) {
       const int c = chunk * CF_BK + k4 * 4;
       sc = *reinterpret_cast<const f32x4*>(a.pro_scale + (size_t)b * a.cin + c);
       sh = *reinterpret_cast<const f32x4*>(a.pro_shift + (size_t)b * a.cin + c);
@@ -155,33 +164,40 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < C::APT; ++j) {
       const int p = (tid >> 2) + 64 * j;
-      if (p < C::NPIX) {
+      if ((j + 1) * 64 <= C::NPIX || p < C::NPIX) {
         f32x4 v = ra[j];
-        if (pix[j] >= 0) {  // zero padding stays exactly zero (it pads the conv INPUT, i.e. post-activation)
-          if (a.prologue == CF_PRO_AFFINE) {
+        const bool valid = pix[j] >= 0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] * sc[e] + sh[e];
-          } else if (a.prologue == CF_PRO_AFFINE_SWISH) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = swishf(v[e] * sc[e] + sh[e]);
-          } else if (a.prologue == CF_PRO_LEAKY) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
-          }
+        for (int e = 0; e < 4; ++e) {
+          float y = v[e];
+          if (PRO == CF_PRO_AFFINE) y = y * sc[e] + sh[e];
+          if (PRO == CF_PRO_AFFINE_SWISH) y = swishf(y * sc[e] + sh[e]);
+          if (PRO == CF_PRO_LEAKY) y = y > 0.f ? y : 0.2f * y;
+          v[e] = valid ? y : 0.f;
         }
         *reinterpret_cast<f32x4*>(dst + p * CF_LDK) = v;
       }
     }
   };
+  auto store_A = [&](int buf, const f32x4(&ra)[C::APT], int chunk) {
+    switch (a.prologue) {
+      case CF_PRO_AFFINE: store_A_mode(buf, ra, chunk, std::integral_constant<int, CF_PRO_AFFINE>{}); break;
+      case CF_PRO_AFFINE_SWISH: store_A_mode(buf, ra, chunk, std::integral_constant<int, CF_PRO_AFFINE_SWISH>{}); break;
+      case CF_PRO_LEAKY: store_A_mode(buf, ra, chunk, std::integral_constant<int, CF_PRO_LEAKY>{}); break;
+      default: store_A_mode(buf, ra, chunk, std::integral_constant<int, CF_PRO_NONE>{}); break;
+    }
+  };
 
+  constexpr bool B_FULL = (C::BN * 4) % 256 == 0;  // every thread has BPT items (no tail guard)
   auto load_B = [&](int step, f32x4(&rb)[C::BPT]) {
     const int chunk = step / TAPS;
     const int tap = step - chunk * TAPS;
     const float* src = a.weight + ((size_t)(tap * a.nchunks + chunk) * a.cout_pad + n0) * CF_BK;
 #pragma unroll
     for (int j = 0; j < C::BPT; ++j) {
-      const int f = tid + 256 * j;
-      if (f < C::BN * 4) rb[j] = *reinterpret_cast<const f32x4*>(src + f * 4);
+      int f = tid + 256 * j;
+      if (!B_FULL) f = f < C::BN * 4 ? f : 0;
+      rb[j] = *reinterpret_cast<const f32x4*>(src + f * 4);
     }
   };
   auto store_B = [&](int buf, const f32x4(&rb)[C::BPT]) {
@@ -189,7 +205,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < C::BPT; ++j) {
       const int f = tid + 256 * j;
-      if (f < C::BN * 4) *reinterpret_cast<f32x4*>(dst + (f >> 2) * CF_LDK + (f & 3) * 4) = rb[j];
+      if (B_FULL || f < C::BN * 4) *reinterpret_cast<f32x4*>(dst + (f >> 2) * CF_LDK + (f & 3) * 4) = rb[j];
     }
   };
 
@@ -230,8 +246,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvArgs a) {
       const int bbuf = step & 1;
       store_B(bbuf, rb);
       __syncthreads();
-      if (step + 1 < nsteps) load_B(step + 1, rb);
-      if (tap == TAPS - 1 && chunk + 1 < a.nchunks) load_A(chunk + 1, ra);
+      load_B(step + 1 < nsteps ? step + 1 : step, rb);  // clamped: the last prefetch is a harmless re-read
+      if (tap == TAPS - 1) load_A(chunk + 1 < a.nchunks ? chunk + 1 : chunk, ra);
+      // pin the prefetch loads ABOVE the MFMA block (hipcc otherwise sinks them next to their first use and
+      // exposes the full load latency in front of every barrier)
+      __builtin_amdgcn_sched_barrier(0);
       const int tapoff = (TAPS == 9) ? ((tap / 3) * C::HWD + (tap % 3)) * CF_LDK : 0;
       const float* ap[MI];
       const float* bp[NI];
@@ -245,41 +264,52 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvArgs a) {
   }
 
   // ---- epilogue: accumulator (row = pixel, col = n = lane&31) -> bias / residual / SFT / GELU -> HBM ----
+  auto epilogue = [&](auto mode) {
+    constexpr int EPI = decltype(mode)::value;
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int n = n0 + wn * (NI * 32) + ni * 32 + l31;
-    if (n >= a.cout) continue;
-    const float bias = a.bias ? a.bias[n] : 0.f;
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = n0 + wn * (NI * 32) + ni * 32 + l31;
+      const bool nvalid = n < a.cout;
+      const float bias = (a.bias && nvalid) ? a.bias[n] : 0.f;
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
+      for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * (MI * 32) + mi * 32 + cf_acc_row(r, lane);
-        size_t pixel;
-        int oy = 0, ox = 0;
-        if (TAPS == 9) {
-          oy = y0 + (row >> 4);
-          ox = x0 + (row & 15);
-          pixel = ((size_t)b * a.hout + oy) * a.wout + ox;
-        } else {
-          pixel = (size_t)m0 + row;
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * (MI * 32) + mi * 32 + cf_acc_row(r, lane);
+          size_t pixel;
+          int oy = 0, ox = 0;
+          if (TAPS == 9) {
+            oy = y0 + (row >> 4);
+            ox = x0 + (row & 15);
+            pixel = ((size_t)b * a.hout + oy) * a.wout + ox;
+          } else {
+            pixel = (size_t)m0 + row;
+          }
+          const size_t o = pixel * a.cout + n;
+          float v = acc[mi][ni][r] + bias;
+          if (nvalid) {
+            if (EPI == CF_EPI_RESIDUAL) {
+              v += a.res[o];
+            } else if (EPI == CF_EPI_SFT) {
+              const float dec = a.res[o];
+              v = dec + a.sft_w * (dec * a.sft_scale[o] + v);
+            } else if (EPI == CF_EPI_GELU) {
+              v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+            }
+            if (TAPS == 9 && a.out_nchw)
+              a.out[(((size_t)b * a.cout + n) * a.hout + oy) * a.wout + ox] = v;
+            else
+              a.out[o] = v;
+          }
         }
-        const size_t o = pixel * a.cout + n;
-        float v = acc[mi][ni][r] + bias;
-        if (a.epilogue == CF_EPI_RESIDUAL) {
-          v += a.res[o];
-        } else if (a.epilogue == CF_EPI_SFT) {
-          const float dec = a.res[o];
-          v = dec + a.sft_w * (dec * a.sft_scale[o] + v);
-        } else if (a.epilogue == CF_EPI_GELU) {
-          v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-        }
-        if (TAPS == 9 && a.out_nchw)
-          a.out[(((size_t)b * a.cout + n) * a.hout + oy) * a.wout + ox] = v;
-        else
-          a.out[o] = v;
       }
     }
+  };
+  switch (a.epilogue) {
+    case CF_EPI_RESIDUAL: epilogue(std::integral_constant<int, CF_EPI_RESIDUAL>{}); break;
+    case CF_EPI_SFT: epilogue(std::integral_constant<int, CF_EPI_SFT>{}); break;
+    case CF_EPI_GELU: epilogue(std::integral_constant<int, CF_EPI_GELU>{}); break;
+    default: epilogue(std::integral_constant<int, CF_EPI_NONE>{}); break;
   }
 }
 

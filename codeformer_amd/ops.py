@@ -15,6 +15,10 @@ from .lib import (EPI_GELU, EPI_NONE, EPI_RESIDUAL, EPI_SFT, PRO_AFFINE, PRO_AFF
 GN_GROUPS = 32
 GN_EPS = 1e-6
 
+# Optional per-launch timing for bench.py's roofline leg: when a list is installed here, conv2d brackets every
+# kernel launch with events on the launch stream and appends (kind, algorithmic_flops, algorithmic_bytes, start, end).
+PROFILE = None
+
 
 def _f32(t):
     if t.dtype != torch.float32:
@@ -102,7 +106,19 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
         out_nchw=int(bool(out_nchw)), prologue=prologue, epilogue=epilogue, pro_scale=L.ptr(scale),
         pro_shift=L.ptr(shift), weight=L.ptr(pw.w), bias=L.ptr(pw.bias), res=L.ptr(res), sft_scale=L.ptr(sft_scale),
         sft_w=float(sft_w), out=L.ptr(out))
+    if PROFILE is None:
+        L.check(lib.cf_conv2d(ctypes.byref(d), L.stream_ptr()), 'cf_conv2d')
+        return out
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     L.check(lib.cf_conv2d(ctypes.byref(d), L.stream_ptr()), 'cf_conv2d')
+    e1.record()
+    cin = c0 + c1
+    flops = 2.0 * B * Ho * Wo * pw.cout * cin * pw.taps
+    nbytes = 4.0 * (x.numel() + (0 if x2 is None else x2.numel()) + pw.cout * cin * pw.taps + out.numel()
+                    + (0 if res is None else res.numel()) + (0 if sft_scale is None else sft_scale.numel()))
+    kind = ('conv3x3_s2' if stride == 2 else 'conv3x3') if pw.taps == 9 else ('linear' if x.shape[0] == 1 and W == 16 and B == 1 else 'conv1x1')
+    PROFILE.append((kind, flops, nbytes, e0, e1, (B, H, W, cin, pw.cout)))
     return out
 
 

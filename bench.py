@@ -1,0 +1,190 @@
+"""bench.py -- aligned 512x512 faces/sec of the MI355X-native CodeFormer path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N=1: plain python; N>1: launched by torchrun, one rank per GPU)
+
+A "step" is one CodeFormer.forward(x, w=0.5, adain=True) over one batch of 16 synthetic faces per GPU (config 2 of
+BASELINE.json: fp32, seeded rand(16,3,512,512)*2-1, seed-0 random-init weights unless weights/CodeFormer/codeformer.pth
+exists) followed, for N>1, by the single gather of the restored faces to rank 0.  Inputs are resident in HBM before the
+timed region; host PNG decode/encode is outside the path and outside the timed region.  Weak scaling: 16 faces per GPU.
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline:     dominant kernel = the 3x3 implicit-GEMM convolution (95 % of the FLOPs, compute-bound in fp32:
+                AI ~ 233 FLOP/B vs ridge ~ 20).  achieved = algorithmic FLOPs of all 3x3 launches of one forward
+                (2*B*Ho*Wo*Cout*Cin*9 each) / their summed durations, measured live with events on the launch stream;
+                peak = 157.3 TFLOP/s (fp32 MFMA, MI355X_MICROARCH.md).
+  cpu_baseline: the CPU oracle (oracle/codeformer_oracle.py, torch CPU fp32, all host threads) timed on a bounded sample
+                (batch-1 forwards for ~10-30 s) on rank 0 at N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+HBM_PEAK_GBS = 8000.0
+GFLOP_PER_FACE = 809.77            # BASELINE.md section 3 (restoration, w>0, 4 fuse levels)
+FUSED_MIN_GB_PER_FACE = 4.155
+
+
+def build_net(device):
+    import codeformer_amd.archs  # noqa: F401
+    from codeformer_amd.utils.registry import ARCH_REGISTRY
+    torch.manual_seed(0)
+    net = ARCH_REGISTRY.get('CodeFormer')(dim_embd=512, codebook_size=1024, n_head=8, n_layers=9,
+                                          connect_list=['32', '64', '128', '256']).eval()
+    ckpt = os.path.join(ROOT, 'weights', 'CodeFormer', 'codeformer.pth')
+    weights = 'seed-0 random-init'
+    if os.path.exists(ckpt):
+        net.load_state_dict(torch.load(ckpt, map_location='cpu')['params_ema'])
+        weights = 'codeformer.pth'
+    sd_cpu = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    return net.to(device), sd_cpu, weights
+
+
+def roofline_leg(net, x, w):
+    """Per-launch event timing of every implicit-GEMM launch of one forward; returns the roofline object + a table."""
+    from codeformer_amd import ops
+    for _ in range(2):
+        net(x, w=w, adain=True)
+    torch.cuda.synchronize()
+    reps = 3
+    agg = {}
+    shapes = {}
+    for _ in range(reps):
+        ops.PROFILE = []
+        net(x, w=w, adain=True)
+        torch.cuda.synchronize()
+        rec, ops.PROFILE = ops.PROFILE, None
+        for kind, flops, nbytes, e0, e1, shape in rec:
+            a = agg.setdefault(kind, [0.0, 0.0, 0.0, 0])
+            a[0] += flops
+            a[1] += nbytes
+            a[2] += e0.elapsed_time(e1) * 1e-3
+            a[3] += 1
+            sh = shapes.setdefault((kind,) + tuple(shape), [0.0, 0.0, 0])
+            sh[0] += flops
+            sh[1] += e0.elapsed_time(e1) * 1e-3
+            sh[2] += 1
+    table = {k: {'launches_per_forward': v[3] // reps, 'gflop_per_forward': v[0] / reps / 1e9,
+                 'ms_per_forward': v[2] / reps * 1e3, 'tflops': v[0] / v[2] / 1e12, 'alg_gbs': v[1] / v[2] / 1e9}
+             for k, v in agg.items()}
+    table['by_shape (kind,B,H,W,Cin,Cout): launches, ms_total, TFLOP/s'] = {
+        str(k): [v[2] // reps, round(v[1] / reps * 1e3, 3), round(v[0] / v[1] / 1e12, 1)]
+        for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1])}
+    c = agg['conv3x3']
+    achieved = c[0] / c[2] / 1e12
+    roof = {'bound': 'mfma', 'kernel': 'igemm_kernel<9,1,...> (3x3 s1 implicit GEMM, fp32 MFMA)', 'achieved': round(achieved, 2),
+            'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+            'traffic': None, 'avg_launch_ms': round(c[2] / c[3] * 1e3, 4), 'launches_per_step': c[3] // reps,
+            'gflop_per_step': round(c[0] / reps / 1e9, 1)}
+    return roof, table
+
+
+def cpu_baseline_leg(sd_cpu, w, budget_s=25.0):
+    """CPU oracle, batch-1 forwards, bounded: at most ~budget_s of timed work (>= 1 forward) after one warm-up.
+    Threads = the CPUs this process may run on, capped at 64 (torch's intra-op pool stops scaling well before that on
+    conv workloads and oversubscribed boxes get dramatically slower); the count used is reported in `cores`."""
+    from oracle import codeformer_oracle as O
+    from oracle.synth import seeded_input
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 64))
+    torch.set_num_threads(cores)
+    x = seeded_input(1)
+    t0 = time.perf_counter()
+    O.codeformer_forward(x, sd_cpu, w=w, adain_flag=True)  # warm-up (first call pays oneDNN primitive creation)
+    warm = time.perf_counter() - t0
+    n, t0 = 0, time.perf_counter()
+    while n < 1 or (time.perf_counter() - t0 + warm * 0.8 < budget_s and n < 16):
+        O.codeformer_forward(x, sd_cpu, w=w, adain_flag=True)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {'value': round(n / dt, 4), 'unit': 'faces/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n} batch-1 forward(s) of the CPU oracle (torch {torch.__version__} CPU fp32, {cores} threads of {avail} '
+                      f'available) on the seeded 512x512 input, w={w}, adain=True, after 1 warm-up ({warm:.1f} s)'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch-per-gpu', type=int, default=16)
+    ap.add_argument('--w', type=float, default=0.5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--details', action='store_true', help='print the per-kernel-class table to stderr')
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from codeformer_amd import lib, parallel
+    from oracle.synth import seeded_input
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X (there is no CPU execution path to benchmark)'
+    lib.load()
+    rank, world, dev = parallel.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {args.gpus}')
+
+    net, sd_cpu, weights = build_net(dev)
+    B = args.batch_per_gpu
+    x = seeded_input(B, seed=1234 + rank).to(dev)     # weak scaling: every rank restores its own 16 faces
+    total = B * world
+
+    def step():
+        faces, _ = parallel.restore_sharded(net, x, total, w=args.w, adain=True, dst=0)
+        return faces
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        faces_per_s = args.steps * total / dt
+        line = {
+            'metric': 'aligned 512x512 faces/sec (whole node) at w=0.5', 'value': round(faces_per_s, 2), 'unit': 'faces/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'BASELINE config 2: batch={B} aligned 512x512 faces per GPU, w={args.w}, adain=True, fp32, '
+                                   f'CodeFormer(codebook 1024, 4 fuse levels), {weights} weights', 'global_batch': total,
+                       'parallelism': f'faces sharded x{world}, one gather to rank 0' if world > 1 else 'single GPU'},
+            'whole_path': {'tflops_fp32': round(faces_per_s * GFLOP_PER_FACE / 1e3, 2),
+                           'frac_fp32_mfma_peak': round(faces_per_s * GFLOP_PER_FACE / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world), 4),
+                           'frac_hbm_peak_fused_min_bytes': round(faces_per_s * FUSED_MIN_GB_PER_FACE / (HBM_PEAK_GBS * world), 4)},
+        }
+        if not args.no_roofline:
+            roof, table = roofline_leg(net, x, args.w)
+            line['roofline'] = roof
+            if args.details:
+                print(json.dumps(table, indent=1), file=sys.stderr)
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline_leg(sd_cpu, args.w)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

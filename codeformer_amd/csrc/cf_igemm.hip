@@ -51,7 +51,8 @@ struct Cfg {
   static constexpr int ABUF = (TAPS == 1) ? 2 : 1;
   static constexpr int APT = (NPIX * 4 + 255) / 256;  // float4 gather items per thread
   static constexpr int BPT = (BN * 4 + 255) / 256;    // float4 weight items per thread
-  static constexpr int LDS_FLOATS = ABUF * NPIX * CF_LDK + 2 * BN * CF_LDK;
+  static constexpr int BBUF = (TAPS == 9) ? 3 : 2;    // weight-slab ring depth in LDS
+  static constexpr int LDS_FLOATS = ABUF * NPIX * CF_LDK + BBUF * BN * CF_LDK;
 };
 
 // x * sigmoid(x) with sigmoid = 1/(1+exp(-x)), the operation order of vqgan_arch.py:18-20
@@ -235,32 +236,93 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const ConvArgs a) {
   const int nsteps = a.nchunks * TAPS;
   f32x4 ra[C::APT];
   f32x4 rb[C::BPT];
-  load_B(0, rb);
-  load_A(0, ra);
-  int step = 0;
-  for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-    const int abuf = (C::ABUF == 2) ? (chunk & 1) : 0;
-    store_A(abuf, ra, chunk);
+
+  if constexpr (TAPS == 9) {
+    // ---- software-pipelined schedule (3x3) -----------------------------------------------------------------
+    // Weight slabs live in a 3-deep LDS ring: slab t is fetched from HBM/L2 at the start of step t-2, written to
+    // LDS at the end of step t-2, made visible by the barrier that opens step t-1, and its first fragments are read
+    // in the MIDDLE of step t-1 -- so no wave ever waits on an LDS round trip between two MFMA blocks:
+    //     step s:  [barrier] issue loads B(s+2) | read frags(s, k 8..15) | 16 MFMA on frags(s, k 0..7)
+    //                        read frags(s+1, k 0..7) | 16 MFMA on frags(s, k 8..15) | LDS write B(s+2)
+    // RAW: B(s+1) was written before the barrier opening step s.  WAR: ring slot (s+2)%3 last held B(s-1), whose
+    // reads every wave finished before arriving at the barrier opening step s.  The halo patch is single-buffered,
+    // so the slab boundary (1 step in 9) drains: barrier, patch write, barrier, fragment read.
+    auto read_frags = [&](f32x4(&af)[MI], f32x4(&bf)[NI], int tapoff, int bslot, int kg) {
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap, ++step) {
+      for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const f32x4*>(As + a_off[mi] + tapoff + kg * 8);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        bf[ni] = *reinterpret_cast<const f32x4*>(Bs + bslot * (C::BN * CF_LDK) + b_off[ni] + kg * 8);
+    };
+    auto mma16 = [&](const f32x4(&af)[MI], const f32x4(&bf)[NI]) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
+    };
+    auto tap_off = [](int tap) { return ((tap / 3) * C::HWD + (tap % 3)) * CF_LDK; };
+
+    load_A(0, ra);
+    load_B(0, rb);
+    store_A(0, ra, 0);
+    store_B(0, rb);
+    load_B(1 < nsteps ? 1 : 0, rb);
+    store_B(1, rb);
+    __syncthreads();
+    f32x4 ax[MI], bx[NI], ay[MI], by[NI];
+    read_frags(ax, bx, tap_off(0), 0, 0);
+    int slot = 0;  // ring slot of the current step's weight slab
+    int step = 0;
+    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap, ++step) {
+        const int slot1 = slot == 2 ? 0 : slot + 1;
+        const int slot2 = slot1 == 2 ? 0 : slot1 + 1;
+        load_B(step + 2 < nsteps ? step + 2 : nsteps - 1, rb);  // clamped: the tail prefetches are harmless re-reads
+        if (tap == TAPS - 1) load_A(chunk + 1 < a.nchunks ? chunk + 1 : chunk, ra);
+        read_frags(ay, by, tap_off(tap), slot, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma16(ax, bx);
+        __builtin_amdgcn_sched_barrier(0);
+        if (tap != TAPS - 1) read_frags(ax, bx, tap_off(tap + 1), slot1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma16(ay, by);
+        __builtin_amdgcn_sched_barrier(0);
+        store_B(slot2, rb);
+        __syncthreads();
+        if (tap == TAPS - 1 && chunk + 1 < a.nchunks) {
+          store_A(0, ra, chunk + 1);
+          __syncthreads();
+          read_frags(ax, bx, tap_off(0), slot1, 0);
+        }
+        slot = slot1;
+      }
+    }
+  } else {
+    load_B(0, rb);
+    load_A(0, ra);
+    int step = 0;
+    for (int chunk = 0; chunk < a.nchunks; ++chunk, ++step) {
+      const int abuf = chunk & 1;
       const int bbuf = step & 1;
+      store_A(abuf, ra, chunk);
       store_B(bbuf, rb);
       __syncthreads();
       load_B(step + 1 < nsteps ? step + 1 : step, rb);  // clamped: the last prefetch is a harmless re-read
-      if (tap == TAPS - 1) load_A(chunk + 1 < a.nchunks ? chunk + 1 : chunk, ra);
-      // pin the prefetch loads ABOVE the MFMA block (hipcc otherwise sinks them next to their first use and
-      // exposes the full load latency in front of every barrier)
+      load_A(chunk + 1 < a.nchunks ? chunk + 1 : chunk, ra);
+      // pin the prefetch loads ABOVE the MFMA block (hipcc otherwise sinks them next to their first use)
       __builtin_amdgcn_sched_barrier(0);
-      const int tapoff = (TAPS == 9) ? ((tap / 3) * C::HWD + (tap % 3)) * CF_LDK : 0;
       const float* ap[MI];
       const float* bp[NI];
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) ap[mi] = As + abuf * (C::NPIX * CF_LDK) + a_off[mi] + tapoff;
+      for (int mi = 0; mi < MI; ++mi) ap[mi] = As + abuf * (C::NPIX * CF_LDK) + a_off[mi];
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) bp[ni] = Bs + bbuf * (C::BN * CF_LDK) + b_off[ni];
       cf_mma_slab<MI, NI>(acc, ap, bp);
     }
-    if (C::ABUF == 1) __syncthreads();  // all waves done with As before the next slab overwrites it
   }
 
   // ---- epilogue: accumulator (row = pixel, col = n = lane&31) -> bias / residual / SFT / GELU -> HBM ----
@@ -450,11 +512,22 @@ extern "C" int cf_conv2d(const cf_conv_desc* d, cf_stream_t stream_) {
   a.tiles_x = a.tiles_per_img = a.ntn = 0;
 
   const int cp = d->cout_pad;
+  // Small-M layers (16x16 / 32x32 latents): a 128x128 tiling yields fewer workgroups than 1.5x the CU count, so half the
+  // chip idles.  Halving the N tile doubles the workgroup count at the price of gathering the halo patch twice.
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0, v = 0;
+    n_cu = (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  const long wg128 = ((long)d->batch * d->hout * d->wout / 128) * (cp / 128);
+  const bool narrow = cp % 128 == 0 && wg128 * 2 <= 3L * n_cu;
   if (d->taps == 9 && d->stride == 1) {
     if (d->in_nchw) {
       CF_REQUIRE(cp == 64, "cf_conv2d: in_nchw path is built for cout_pad 64 (got %d)", cp);
       return launch<9, 1, 4, 1, 2, 2, true>(a, stream);
     }
+    if (narrow) return launch<9, 1, 2, 2, 2, 1, false>(a, stream);
     if (cp % 128 == 0) return launch<9, 1, 2, 2, 2, 2, false>(a, stream);
     if (cp == 64) return launch<9, 1, 4, 1, 2, 2, false>(a, stream);
     if (cp == 32) return launch<9, 1, 4, 1, 2, 1, false>(a, stream);
@@ -462,6 +535,7 @@ extern "C" int cf_conv2d(const cf_conv_desc* d, cf_stream_t stream_) {
     if (cp % 128 == 0) return launch<9, 2, 2, 2, 2, 2, false>(a, stream);
     if (cp == 64) return launch<9, 2, 2, 2, 2, 1, false>(a, stream);
   } else {
+    if (narrow) return launch<1, 1, 2, 2, 2, 1, false>(a, stream);
     if (cp % 128 == 0) return launch<1, 1, 2, 2, 2, 2, false>(a, stream);
     if (cp == 64) return launch<1, 1, 4, 1, 2, 2, false>(a, stream);
   }

@@ -22,14 +22,26 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
   const int row1 = min(hw, row0 + rows_per_blk);
   double s0 = 0, q0 = 0, s1 = 0, q1 = 0;
   const float* base = x + (size_t)b * hw * C + cq * 4;
-  for (int r = row0 + pr; r < row1; r += lanes) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)r * C);
+  auto accum = [&](const f32x4& v) {
     const double a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
     s0 += a0 + a1;
     q0 += a0 * a0 + a1 * a1;
     s1 += a2 + a3;
     q1 += a2 * a2 + a3 * a3;
+  };
+  int r = row0 + pr;
+  // 4 independent 16-byte loads in flight per thread (the pass is HBM-bound; one load per iteration starves it)
+  for (; r + 3 * lanes < row1; r += 4 * lanes) {
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(base + (size_t)r * C);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(base + (size_t)(r + lanes) * C);
+    const f32x4 v2 = *reinterpret_cast<const f32x4*>(base + (size_t)(r + 2 * lanes) * C);
+    const f32x4 v3 = *reinterpret_cast<const f32x4*>(base + (size_t)(r + 3 * lanes) * C);
+    accum(v0);
+    accum(v1);
+    accum(v2);
+    accum(v3);
   }
+  for (; r < row1; r += lanes) accum(*reinterpret_cast<const f32x4*>(base + (size_t)r * C));
   red[tid][0] = s0;
   red[tid][1] = q0;
   red[tid][2] = s1;

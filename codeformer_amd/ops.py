@@ -142,7 +142,8 @@ def groupnorm_tables(xs, gamma, beta, eps=GN_EPS, groups=GN_GROUPS):
         raise ValueError(f'{ctot} channels not divisible by {groups} groups')
     cpg = ctot // groups
     hw = H * W
-    nblk = max(1, min(64, (hw * max(t.shape[3] for t in xs) * 4 + (1 << 18) - 1) >> 18))
+    # ~128 KB of input per block, enough blocks to cover 256 CUs several times over, at most 256 partials per group
+    nblk = max(1, min(256, (hw * max(t.shape[3] for t in xs) * 4 + (1 << 17) - 1) >> 17))
     part = torch.empty(B * groups * nblk * 2, dtype=torch.float64, device=xs[0].device)
     g0 = 0
     for t in xs:

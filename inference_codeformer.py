@@ -1,0 +1,186 @@
+"""CodeFormer face restoration -- MI355X-native drop-in for the reference's inference_codeformer.py.
+
+Same flags, same result tree (results/<input>_<w>/restored_faces/<basename>.png) for the `--has_aligned` path
+(reference: inference_codeformer.py:55-274).  What is new underneath:
+  * faces are restored in BATCHES (--batch_size, default 16 on GPU) instead of one forward per face;
+  * on an MI355X the uint8<->tensor boundary (img2tensor+normalize, tensor2img) runs as HIP kernels on the device
+    (cf_img_u8_to_tensor / cf_tensor_to_img_u8) and the network is codeformer_amd's HIP path;
+  * under torchrun the face list is sharded over ranks (one process per GPU) -- each rank writes its own results.
+Whole-image / video inputs need the reference's host-side facelib (detection, alignment, paste-back), which is outside
+this package's scope: run that stage with the reference and feed the aligned crops here.
+"""
+import argparse
+import glob
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from basicsr.utils import img2tensor, imwrite, tensor2img  # noqa: E402
+from basicsr.utils.download_util import load_file_from_url  # noqa: E402
+from basicsr.utils.img_util import imread_bgr, normalize_, resize_bilinear  # noqa: E402
+from basicsr.utils.misc import get_device  # noqa: E402
+from basicsr.utils.registry import ARCH_REGISTRY  # noqa: E402
+from codeformer_amd.utils.face_misc import AlignedFaceHelper, is_gray  # noqa: E402
+
+pretrain_model_url = {
+    'restoration': 'https://github.com/sczhou/CodeFormer/releases/download/v0.1.0/codeformer.pth',
+}
+IMAGE_EXT = ('jpg', 'jpeg', 'png', 'JPG', 'JPEG', 'PNG')
+VIDEO_EXT = ('mp4', 'mov', 'avi', 'MP4', 'MOV', 'AVI')
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument('-i', '--input_path', type=str, default='./inputs/whole_imgs',
+                   help='Input image, video or folder. Default: inputs/whole_imgs')
+    p.add_argument('-o', '--output_path', type=str, default=None, help='Output folder. Default: results/<input_name>_<w>')
+    p.add_argument('-w', '--fidelity_weight', type=float, default=0.5, help='Balance the quality and fidelity. Default: 0.5')
+    p.add_argument('-s', '--upscale', type=int, default=2, help='The final upsampling scale of the image. Default: 2')
+    p.add_argument('--has_aligned', action='store_true', help='Input are cropped and aligned faces. Default: False')
+    p.add_argument('--only_center_face', action='store_true', help='Only restore the center face. Default: False')
+    p.add_argument('--draw_box', action='store_true', help='Draw the bounding box for the detected faces. Default: False')
+    p.add_argument('--detection_model', type=str, default='retinaface_resnet50')
+    p.add_argument('--bg_upsampler', type=str, default='None', help='Background upsampler. Optional: realesrgan')
+    p.add_argument('--face_upsample', action='store_true', help='Face upsampler after enhancement. Default: False')
+    p.add_argument('--bg_tile', type=int, default=400, help='Tile size for background sampler. Default: 400')
+    p.add_argument('--suffix', type=str, default=None, help='Suffix of the restored faces. Default: None')
+    p.add_argument('--save_video_fps', type=float, default=None, help='Frame rate for saving video. Default: None')
+    # --- additions (do not change the behaviour of the flags above) ---
+    p.add_argument('--batch_size', type=int, default=None, help='Faces per forward. Default: 16 on GPU, 1 on CPU')
+    p.add_argument('--device', type=str, default=None, help="Override the device pick (e.g. 'cpu')")
+    p.add_argument('--random_init_seed', type=int, default=None,
+                   help='Use torch.manual_seed(SEED) random weights when weights/CodeFormer/codeformer.pth is absent '
+                        '(plumbing runs on boxes without the checkpoint)')
+    p.add_argument('--strict', action='store_true', help='Raise on inference errors instead of returning the input face')
+    return p.parse_args(argv)
+
+
+def collect_inputs(args):
+    w = args.fidelity_weight
+    path = args.input_path
+    if path.endswith(IMAGE_EXT):
+        return [path], f'results/test_img_{w}'
+    if path.endswith(VIDEO_EXT):
+        raise NotImplementedError('video input needs the host-side facelib + ffmpeg stage of the reference; '
+                                  'this entrypoint covers aligned faces (--has_aligned)')
+    path = path[:-1] if path.endswith('/') else path
+    return sorted(glob.glob(os.path.join(path, '*.[jpJP][pnPN]*[gG]'))), f'results/{os.path.basename(path)}_{w}'
+
+
+def build_net(device, args):
+    net = ARCH_REGISTRY.get('CodeFormer')(dim_embd=512, codebook_size=1024, n_head=8, n_layers=9,
+                                          connect_list=['32', '64', '128', '256'])
+    try:
+        ckpt_path = load_file_from_url(url=pretrain_model_url['restoration'], model_dir='weights/CodeFormer', progress=True,
+                                       file_name=None)
+        net.load_state_dict(torch.load(ckpt_path, map_location='cpu')['params_ema'])
+    except FileNotFoundError:
+        if args.random_init_seed is None:
+            raise
+        print(f'WARNING: codeformer.pth not found -- using torch.manual_seed({args.random_init_seed}) random weights')
+        torch.manual_seed(args.random_init_seed)
+        net = ARCH_REGISTRY.get('CodeFormer')(dim_embd=512, codebook_size=1024, n_head=8, n_layers=9,
+                                              connect_list=['32', '64', '128', '256'])
+    return net.to(device).eval()
+
+
+def faces_to_tensor(faces, device):
+    """List of uint8 512x512x3 BGR -> (B,3,512,512) fp32 RGB in [-1,1] on `device`."""
+    if device.type == 'cuda':
+        from codeformer_amd import ops
+        batch = torch.from_numpy(np.stack(faces)).to(device, non_blocking=True)
+        return ops.img_u8_to_tensor(batch)
+    ts = []
+    for f in faces:
+        t = img2tensor(f / 255., bgr2rgb=True, float32=True)
+        ts.append(normalize_(t, (0.5, 0.5, 0.5), (0.5, 0.5, 0.5)))
+    return torch.stack(ts).to(device)
+
+
+def tensor_to_faces(t):
+    """(B,3,512,512) -> list of uint8 HWC BGR (tensor2img(rgb2bgr=True, min_max=(-1,1)) per face)."""
+    if t.is_cuda:
+        from codeformer_amd import ops
+        return list(ops.tensor_to_img_u8(t).cpu().numpy())
+    return [tensor2img(t[i], rgb2bgr=True, min_max=(-1, 1)) for i in range(t.shape[0])]
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    device = torch.device(args.device) if args.device else get_device()
+    w = args.fidelity_weight
+    input_img_list, result_root = collect_inputs(args)
+    if args.output_path is not None:
+        result_root = args.output_path
+    if len(input_img_list) == 0:
+        raise FileNotFoundError('No input image/video is found...\n'
+                                '\tNote that --input_path for video should end with .mp4|.mov|.avi')
+    if not args.has_aligned:
+        raise NotImplementedError('whole-image inputs need face detection / alignment / paste-back (the reference keeps '
+                                  'these on the host in facelib); pass aligned 512x512 crops with --has_aligned')
+    if args.bg_upsampler == 'realesrgan' or args.face_upsample:
+        raise NotImplementedError('Real-ESRGAN upsampling is never used on the --has_aligned path and is not provided')
+
+    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    if world > 1:
+        from codeformer_amd import parallel
+        _, _, device = parallel.init_distributed(device=device)
+        b = parallel.shard_bounds(len(input_img_list), world)
+        my_list = input_img_list[b[rank]:b[rank + 1]]
+        first = b[rank]
+    else:
+        my_list, first = input_img_list, 0
+
+    net = build_net(device, args)
+    print(f'Background upsampling: False, Face upsampling: {args.face_upsample}')
+    face_helper = AlignedFaceHelper()
+    bs = args.batch_size or (16 if device.type == 'cuda' else 1)
+    total = len(input_img_list)
+    failures = 0
+
+    for s in range(0, len(my_list), bs):
+        chunk = my_list[s:s + bs]
+        faces, names, grays = [], [], []
+        for j, img_path in enumerate(chunk):
+            img_name = os.path.basename(img_path)
+            print(f'[{first + s + j + 1}/{total}] Processing: {img_name}')
+            img = resize_bilinear(imread_bgr(img_path), (512, 512))
+            g = is_gray(img, threshold=10)
+            if g:
+                print('Grayscale input: True')
+            faces.append(img)
+            names.append(os.path.splitext(img_name)[0])
+            grays.append(g)
+        x = faces_to_tensor(faces, device)
+        try:
+            with torch.no_grad():
+                restored = tensor_to_faces(net(x, w=w, adain=True)[0])
+        except Exception as error:  # the reference swallows the error and returns the input face (F7)
+            if args.strict:
+                raise
+            print(f'\tFailed inference for CodeFormer: {error}')
+            failures += len(faces)
+            restored = tensor_to_faces(x)
+        for face, out, name, g in zip(faces, restored, names, grays):
+            face_helper.clean_all()
+            face_helper.is_gray = g
+            face_helper.cropped_faces = [face]
+            face_helper.add_restored_face(out.astype('uint8'), face)
+            save_face_name = f'{name}.png' if args.suffix is None else f'{name}_{args.suffix}.png'
+            imwrite(np.clip(np.round(face_helper.restored_faces[0]), 0, 255).astype('uint8')
+                    if face_helper.restored_faces[0].dtype != np.uint8 else face_helper.restored_faces[0],
+                    os.path.join(result_root, 'restored_faces', save_face_name))
+    if failures:
+        print(f'WARNING: {failures} face(s) fell back to the unrestored input')
+    print(f'\nAll results are saved in {result_root}')
+    return failures
+
+
+if __name__ == '__main__':
+    sys.exit(1 if main() else 0)

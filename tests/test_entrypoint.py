@@ -1,0 +1,47 @@
+"""BASELINE config 1: the --has_aligned entrypoint on CPU with random-init weights (plumbing, no GPU)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _faces(d, n):
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    os.makedirs(d, exist_ok=True)
+    for i in range(n):
+        Image.fromarray(rng.integers(0, 256, (512, 512, 3), dtype=np.uint8)).save(os.path.join(d, f'f{i}.png'))
+
+
+def test_has_aligned_cpu_plumbing(tmp_path):
+    src, dst = tmp_path / 'cropped_faces', tmp_path / 'out'
+    _faces(str(src), 2)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'inference_codeformer.py'), '--has_aligned', '-i', str(src), '-o',
+                        str(dst), '-w', '0.5', '--device', 'cpu', '--random_init_seed', '0', '--batch_size', '2',
+                        '--suffix', 'r'], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert 'Failed inference' not in r.stdout                       # the reference's swallowed-exception marker (F7)
+    assert sorted(os.listdir(dst / 'restored_faces')) == ['f0_r.png', 'f1_r.png']
+    from PIL import Image
+    assert Image.open(dst / 'restored_faces' / 'f0_r.png').size == (512, 512)
+    assert 'All results are saved in' in r.stdout
+
+
+def test_missing_checkpoint_is_an_error_without_opt_in(tmp_path):
+    src = tmp_path / 'faces'
+    _faces(str(src), 1)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'inference_codeformer.py'), '--has_aligned', '-i', str(src),
+                        '--device', 'cpu'], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode != 0 and 'codeformer.pth' in (r.stdout + r.stderr)
+
+
+def test_whole_image_path_is_explicitly_out_of_scope(tmp_path):
+    src = tmp_path / 'faces'
+    _faces(str(src), 1)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'inference_codeformer.py'), '-i', str(src), '--device', 'cpu',
+                        '--random_init_seed', '0'], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode != 0 and '--has_aligned' in (r.stdout + r.stderr)

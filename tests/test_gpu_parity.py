@@ -1,0 +1,83 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle / the reference's golden fixtures.
+
+The checks themselves live in tools/gpu_check.py (also runnable stand-alone with a full per-check report):
+  basic   transposes, weight packing, LayerNorm, argmax (incl. ties), codebook gather + AdaIN, GroupNorm tables
+  conv    every instantiation of the implicit-GEMM kernel (3x3 s1/s2, 1x1, upsample, concat, NCHW in/out,
+          prologues, epilogues) against fp64 torch CPU references, tolerance 2e-5 + 1e-5*|ref|
+  attn    attention kernel (8x64 and 1x512, mixed leading dimensions) vs fp64 softmax attention, 5e-6
+  blocks  ResBlock / AttnBlock / TransformerSALayer / Fuse_sft_block / Down / Upsample / VectorQuantizer modules
+          against outputs of the REFERENCE's modules (tests/golden/blocks_seed7.npz), 2e-5
+  net     whole CodeFormer.forward against the reference golden: pixels atol 1e-3 (north-star tolerance),
+          logits 1e-4, code indices bit-exact; batch-of-4 == batch-of-1 bitwise; run-to-run bitwise
+"""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def chk():
+    import torch
+    assert torch.cuda.is_available(), 'gpu tests need an MI355X'
+    from codeformer_amd import lib
+    lib.load()   # loud failure if the native library did not travel
+    spec = importlib.util.spec_from_file_location('gpu_check', os.path.join(ROOT, 'tools', 'gpu_check.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize('group', ['basic', 'conv', 'attn', 'blocks', 'net'])
+def test_group(chk, group):
+    chk.RESULTS.clear()
+    chk.GROUPS[group]()
+    bad = [r for r in chk.RESULTS if not r[1]]
+    assert chk.RESULTS and not bad, bad
+
+
+def test_tensor_boundary_kernels(chk):
+    import numpy as np
+    import torch
+    from codeformer_amd import ops
+    from oracle import codeformer_oracle as O
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (2, 64, 48, 3), dtype=np.uint8)
+    t = ops.img_u8_to_tensor(torch.from_numpy(img).cuda())
+    ref = torch.from_numpy(((img[..., ::-1] / 255.).astype(np.float32).transpose(0, 3, 1, 2) - 0.5) / 0.5)
+    assert torch.equal(t.cpu(), ref)
+    x = torch.randn(2, 3, 64, 48, generator=torch.Generator().manual_seed(2)) * 1.2
+    x[0, :, 0, 0] = torch.tensor([0.5 / 255 * 2 - 1, 1.5 / 255 * 2 - 1, 2.5 / 255 * 2 - 1])
+    got = ops.tensor_to_img_u8(x.cuda()).cpu().numpy()
+    for b in range(2):
+        assert np.array_equal(got[b], O.tensor2img_u8(x[b]))
+
+
+def test_bundled_ops(chk):
+    import torch
+    from codeformer_amd import ops
+    from oracle import codeformer_oracle as O
+    from oracle.synth import seeded_randn
+    x, b = seeded_randn((2, 5, 9, 7), 1), seeded_randn((5,), 2)
+    assert torch.allclose(ops.fused_bias_act(x.cuda(), b.cuda()).cpu(), O.fused_bias_act(x, b), atol=1e-6)
+    k = seeded_randn((4, 4), 3)
+    for up, down, pad in ((1, 1, (1, 2)), (2, 1, (2, 1)), (1, 2, (1, 1)), (2, 2, (0, 3)), (1, 1, (-1, 2))):
+        got = ops.upfirdn2d(x.cuda(), k.cuda(), up=up, down=down, pad=pad).cpu()
+        ref = O.upfirdn2d(x, k, up=up, down=down, pad=pad)
+        assert got.shape == ref.shape and torch.allclose(got, ref, atol=2e-6), (up, down, pad)
+
+
+def test_inpainting_config(chk):
+    """Config 5 network shape (codebook 512, 3 fuse levels, w=1, adain=False) against the reference golden."""
+    import numpy as np
+    import torch
+    from oracle.synth import seeded_input
+    net = chk.build_net(512, ('32', '64', '128')).cuda()
+    g = np.load(os.path.join(ROOT, 'tests/golden/inpaint_seed0_face0.npz'))
+    out, logits, _ = net(seeded_input(1).cuda(), w=1, adain=False)
+    assert float((logits.cpu() - torch.from_numpy(g['logits'])).abs().max()) <= 1e-4
+    assert np.array_equal(net.last_indices.cpu().numpy(), g['idx'])
+    assert float((out.cpu()[:, :, ::4, ::4] - torch.from_numpy(g['out_sub'])).abs().max()) <= 1e-3

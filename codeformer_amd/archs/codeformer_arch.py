@@ -132,7 +132,7 @@ class Fuse_sft_block(HipModule):
         s = ops.conv2d(s, self._pw_conv(self.scale[2]), prologue=PRO_LEAKY)
         h = ops.conv2d(e, self._pw_conv(self.shift[0]))
         return ops.conv2d(h, self._pw_conv(self.shift[2]), prologue=PRO_LEAKY, epilogue=EPI_SFT, res=dec, sft_scale=s,
-                          sft_w=float(w))
+                          sft_w=float(w), emit_stats=True)
 
     def forward(self, enc_feat, dec_feat, w=1):
         if enc_feat.is_cuda:

@@ -109,7 +109,7 @@ class Downsample(HipModule):
         self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=2, padding=0)
 
     def forward_nhwc(self, x):
-        return ops.conv2d(x, self._pw_conv('conv'), stride=2)
+        return ops.conv2d(x, self._pw_conv('conv'), stride=2, emit_stats=True)
 
     def forward_host(self, x):
         return self.conv(F.pad(x, (0, 1, 0, 1), mode='constant', value=0))
@@ -123,7 +123,7 @@ class Upsample(HipModule):
         self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
 
     def forward_nhwc(self, x):
-        return ops.conv2d(x, self._pw_conv('conv'), upsample=True)
+        return ops.conv2d(x, self._pw_conv('conv'), upsample=True, emit_stats=True)
 
     def forward_host(self, x):
         return self.conv(F.interpolate(x, scale_factor=2.0, mode='nearest'))
@@ -151,14 +151,14 @@ class ResBlock(HipModule):
     def forward_nhwc(self, x, x2=None):
         xs = (x,) if x2 is None else (x, x2)
         sc, sh = _gn_tables(self.norm1, *xs)
-        h = ops.conv2d(x, self._pw_conv('conv1'), x2=x2, prologue=PRO_AFFINE_SWISH, scale=sc, shift=sh)
+        h = ops.conv2d(x, self._pw_conv('conv1'), x2=x2, prologue=PRO_AFFINE_SWISH, scale=sc, shift=sh, emit_stats=True)
         sc, sh = _gn_tables(self.norm2, h)
         if self.in_channels != self.out_channels:
             skip = ops.conv2d(x, self._pw_conv('conv_out'), x2=x2)
         else:
             skip = x
         return ops.conv2d(h, self._pw_conv('conv2'), prologue=PRO_AFFINE_SWISH, scale=sc, shift=sh,
-                          epilogue=EPI_RESIDUAL, res=skip)
+                          epilogue=EPI_RESIDUAL, res=skip, emit_stats=True)
 
     def forward_host(self, x_in):
         x = self.conv1(swish(self.norm1(x_in)))
@@ -194,7 +194,7 @@ class AttnBlock(HipModule):
         pw = self._packed('qkv', lambda: ops.pack_weight_cat(qkv_w, qkv_b), *qkv_w, *qkv_b)
         qkv = ops.conv2d(x, pw, prologue=PRO_AFFINE, scale=sc, shift=sh).view(B * 256, 3 * C)
         o = ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, 1, C, int(C) ** (-0.5))
-        return ops.conv2d(o.view(B, H, W, C), self._pw_conv('proj_out'), epilogue=EPI_RESIDUAL, res=x)
+        return ops.conv2d(o.view(B, H, W, C), self._pw_conv('proj_out'), epilogue=EPI_RESIDUAL, res=x, emit_stats=True)
 
     def forward_host(self, x):
         h_ = self.norm(x)
@@ -259,6 +259,7 @@ def _run_blocks_nhwc(blocks, x, taps=None, first_nchw=False, last_nchw=False):
                 kw['in_nchw'] = True
             if i == n - 1 and last_nchw:
                 kw['out_nchw'] = True
+            kw['emit_stats'] = i != n - 1      # every inner conv feeds a GroupNorm of the next block
             x = blk.forward_nhwc(x, **kw)
         else:
             if pending is not None:

@@ -36,6 +36,8 @@ struct ConvArgs {
   const float* sft_scale;
   float sft_w;
   float* out;
+  double* stats_out;  // optional [batch][cout/stats_cpg][nparts][2] partial (sum, sumsq) of the OUTPUT
+  int stats_cpg, nparts;
   int tiles_x, tiles_per_img, ntn;
 };
 
@@ -333,6 +335,7 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const ConvArgs a) {
       const int n = n0 + wn * (NI * 32) + ni * 32 + l31;
       const bool nvalid = n < a.cout;
       const float bias = (a.bias && nvalid) ? a.bias[n] : 0.f;
+      float ssum = 0.f, ssq = 0.f;  // GroupNorm statistics of this lane's output column (MI*16 rows)
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -362,7 +365,28 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const ConvArgs a) {
               a.out[(((size_t)b * a.cout + n) * a.hout + oy) * a.wout + ox] = v;
             else
               a.out[o] = v;
+            ssum += v;
+            ssq += v * v;
           }
+        }
+      }
+      if (a.stats_out) {
+        // Fold the statistics the NEXT GroupNorm needs into this epilogue: lane halves hold the same column,
+        // a group is stats_cpg adjacent columns; one fp64 partial per (image, group, tile, wave row) in a fixed
+        // order -> the later finalize is a deterministic sum and the tensor is never re-read for its norm.
+        double ds = ssum, dq = ssq;
+        ds += __shfl_xor(ds, 32, 64);
+        dq += __shfl_xor(dq, 32, 64);
+        for (int o = 1; o < a.stats_cpg; o <<= 1) {
+          ds += __shfl_xor(ds, o, 64);
+          dq += __shfl_xor(dq, o, 64);
+        }
+        if (lane < 32 && nvalid && (n % a.stats_cpg) == 0) {
+          const int tile_in_img = (TAPS == 9) ? (mt - b * a.tiles_per_img) : (m0 - b * (a.hout * a.wout)) / C::BM;
+          const size_t pidx = (size_t)tile_in_img * WM + wm;
+          double* o = a.stats_out + (((size_t)b * (a.cout / a.stats_cpg) + n / a.stats_cpg) * a.nparts + pidx) * 2;
+          o[0] = ds;
+          o[1] = dq;
         }
       }
     }
@@ -376,7 +400,7 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const ConvArgs a) {
 }
 
 template <int TAPS, int STRIDE, int WM, int WN, int MI, int NI, bool IN_NCHW>
-int launch(const ConvArgs& a, hipStream_t stream) {
+int launch(const ConvArgs& a, hipStream_t stream, int* parts_query) {
   using C = Cfg<TAPS, STRIDE, WM, WN, MI, NI>;
   ConvArgs k = a;
   int mtiles;
@@ -397,6 +421,11 @@ int launch(const ConvArgs& a, hipStream_t stream) {
     k.tiles_x = 0;
     k.tiles_per_img = 0;
     mtiles = (int)(m / C::BM);
+  }
+  k.nparts = (mtiles / a.batch) * WM;  // statistics partials per (image, group): tiles per image x wave rows
+  if (parts_query) {
+    *parts_query = k.nparts;
+    return CF_OK;
   }
   k.ntn = a.cout_pad / C::BN;
   auto kern = igemm_kernel<TAPS, STRIDE, WM, WN, MI, NI, IN_NCHW>;
@@ -452,10 +481,9 @@ extern "C" int cf_pack_conv_weight(const float* w, int cout, int cin, int taps, 
   return CF_OK;
 }
 
-extern "C" int cf_conv2d(const cf_conv_desc* d, cf_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
   CF_REQUIRE(d, "cf_conv2d: null descriptor");
-  CF_REQUIRE(d->in0 && d->weight && d->out, "cf_conv2d: null in0/weight/out");
+  CF_REQUIRE(pq || (d->in0 && d->weight && d->out), "cf_conv2d: null in0/weight/out");
   CF_REQUIRE(d->taps == 1 || d->taps == 9, "cf_conv2d: taps must be 1 or 9 (got %d)", d->taps);
   CF_REQUIRE(d->stride == 1 || (d->stride == 2 && d->taps == 9), "cf_conv2d: unsupported stride %d", d->stride);
   CF_REQUIRE(d->batch > 0 && d->hin > 0 && d->win > 0 && d->cout > 0, "cf_conv2d: bad dims");
@@ -465,6 +493,11 @@ extern "C" int cf_conv2d(const cf_conv_desc* d, cf_stream_t stream_) {
   CF_REQUIRE(d->hout == exp_h && d->wout == exp_w, "cf_conv2d: hout/wout %dx%d, expected %dx%d", d->hout, d->wout,
              exp_h, exp_w);
   CF_REQUIRE(d->stride == 1 || (d->hin % 2 == 0 && d->win % 2 == 0), "cf_conv2d: stride 2 needs even input");
+  if (d->stats_out || (pq && d->stats_cpg)) {
+    const int g = d->stats_cpg;
+    CF_REQUIRE(g >= 2 && g <= 32 && (g & (g - 1)) == 0 && d->cout % g == 0 && !d->out_nchw,
+               "cf_conv2d: stats_cpg %d must be a power of two in [2,32] dividing cout %d (NHWC output)", g, d->cout);
+  }
   if (d->in_nchw) {
     CF_REQUIRE(d->c0 >= 1 && d->c0 <= 4 && d->c1 == 0 && d->taps == 9 && d->stride == 1 && !d->upsample,
                "cf_conv2d: in_nchw supports 3x3 s1 with <=4 input channels");
@@ -509,6 +542,9 @@ extern "C" int cf_conv2d(const cf_conv_desc* d, cf_stream_t stream_) {
   a.sft_scale = d->sft_scale;
   a.sft_w = d->sft_w;
   a.out = d->out;
+  a.stats_out = d->stats_out;
+  a.stats_cpg = d->stats_cpg > 0 ? d->stats_cpg : 1;
+  a.nparts = 0;
   a.tiles_x = a.tiles_per_img = a.ntn = 0;
 
   const int cp = d->cout_pad;
@@ -525,20 +561,28 @@ extern "C" int cf_conv2d(const cf_conv_desc* d, cf_stream_t stream_) {
   if (d->taps == 9 && d->stride == 1) {
     if (d->in_nchw) {
       CF_REQUIRE(cp == 64, "cf_conv2d: in_nchw path is built for cout_pad 64 (got %d)", cp);
-      return launch<9, 1, 4, 1, 2, 2, true>(a, stream);
+      return launch<9, 1, 4, 1, 2, 2, true>(a, stream, pq);
     }
-    if (narrow) return launch<9, 1, 2, 2, 2, 1, false>(a, stream);
-    if (cp % 128 == 0) return launch<9, 1, 2, 2, 2, 2, false>(a, stream);
-    if (cp == 64) return launch<9, 1, 4, 1, 2, 2, false>(a, stream);
-    if (cp == 32) return launch<9, 1, 4, 1, 2, 1, false>(a, stream);
+    if (narrow) return launch<9, 1, 2, 2, 2, 1, false>(a, stream, pq);
+    if (cp % 128 == 0) return launch<9, 1, 2, 2, 2, 2, false>(a, stream, pq);
+    if (cp == 64) return launch<9, 1, 4, 1, 2, 2, false>(a, stream, pq);
+    if (cp == 32) return launch<9, 1, 4, 1, 2, 1, false>(a, stream, pq);
   } else if (d->taps == 9 && d->stride == 2) {
-    if (cp % 128 == 0) return launch<9, 2, 2, 2, 2, 2, false>(a, stream);
-    if (cp == 64) return launch<9, 2, 2, 2, 2, 1, false>(a, stream);
+    if (cp % 128 == 0) return launch<9, 2, 2, 2, 2, 2, false>(a, stream, pq);
+    if (cp == 64) return launch<9, 2, 2, 2, 2, 1, false>(a, stream, pq);
   } else {
-    if (narrow) return launch<1, 1, 2, 2, 2, 1, false>(a, stream);
-    if (cp % 128 == 0) return launch<1, 1, 2, 2, 2, 2, false>(a, stream);
-    if (cp == 64) return launch<1, 1, 4, 1, 2, 2, false>(a, stream);
+    if (narrow) return launch<1, 1, 2, 2, 2, 1, false>(a, stream, pq);
+    if (cp % 128 == 0) return launch<1, 1, 2, 2, 2, 2, false>(a, stream, pq);
+    if (cp == 64) return launch<1, 1, 4, 1, 2, 2, false>(a, stream, pq);
   }
   cf_set_error("cf_conv2d: no kernel for taps=%d stride=%d cout_pad=%d", d->taps, d->stride, cp);
   return CF_ERR_ARG;
+}
+
+extern "C" int cf_conv2d(const cf_conv_desc* d, cf_stream_t stream) { return conv_dispatch(d, (hipStream_t)stream, nullptr); }
+
+extern "C" int cf_conv2d_stats_parts(const cf_conv_desc* d) {
+  int parts = 0;
+  const int rc = conv_dispatch(d, nullptr, &parts);
+  return rc == CF_OK ? parts : rc;
 }

@@ -9,8 +9,7 @@ namespace {
 // walks pixel rows  row0 + t/(C/4), += 1024/C.  Sums are carried in fp64 (the pass is HBM-bound; the fp64
 // adds hide under the loads) so the later mean / E[x^2]-mean^2 is accurate for any |mean|/std.
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, int hw, int C, int cpg,
-                                                       int rows_per_blk, double* __restrict__ part, int gtotal,
-                                                       int g0, int nblk) {
+                                                       int rows_per_blk, double* __restrict__ part, int nblk) {
   __shared__ double red[256][4];
   const int tid = threadIdx.x;
   const int b = blockIdx.y, blk = blockIdx.x;
@@ -61,39 +60,71 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
         q += red[t][3];
       }
     }
-    double* o = part + (((size_t)b * gtotal + g0 + tid) * nblk + blk) * 2;
+    double* o = part + (((size_t)b * G + tid) * nblk + blk) * 2;
     o[0] = s;
     o[1] = q;
   }
 }
 
 // ---- GroupNorm stage 2: fixed-order sum of partials -> per-(b,c) scale/shift --------------------
+// One workgroup per image.  G fine groups (<= 64) x nparts partials; FT = 256/G' threads cooperate on each fine
+// group (strided, then an ordered LDS sum) so long partial lists (conv-epilogue statistics: up to thousands of
+// tiles) do not serialise on one thread.  gmerge adjacent fine groups then form one normalisation group.
 // scale = gamma*rstd, shift = beta - mean*scale: the same affine form ATen's CPU GroupNorm kernel applies.
-__global__ void gn_finalize_kernel(const double* __restrict__ part, int gtotal, int nblk, int C, int cpg,
-                                   double inv_count, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float eps, float* __restrict__ scale, float* __restrict__ shift) {
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ part, int nparts, int C, int cpg,
+                                                          int gmerge, double inv_count, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps,
+                                                          float* __restrict__ scale, float* __restrict__ shift, int ld) {
+  __shared__ double red[256][2];
+  __shared__ double fine[64][2];
   __shared__ float s_mean[64], s_rstd[64];
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
-  if (tid < gtotal) {
-    const double* p = part + ((size_t)b * gtotal + tid) * nblk * 2;
-    double s = 0, q = 0;
-    for (int j = 0; j < nblk; ++j) {
+  const int G = C / cpg;                   // fine groups, <= 64
+  int ft = 1;                              // threads per fine group: largest power of two with G*ft <= 256
+  while (G * ft * 2 <= 256) ft *= 2;
+  const int g = tid / ft, sub = tid % ft;
+  double s = 0, q = 0;
+  if (g < G) {
+    const double* p = part + ((size_t)b * G + g) * nparts * 2;
+    for (int j = sub; j < nparts; j += ft) {
       s += p[2 * j];
       q += p[2 * j + 1];
     }
-    const double mean = s * inv_count;
-    double var = q * inv_count - mean * mean;
+  }
+  red[tid][0] = s;
+  red[tid][1] = q;
+  __syncthreads();
+  if (tid < G) {
+    double fs = 0, fq = 0;
+    for (int j = 0; j < ft; ++j) {
+      fs += red[tid * ft + j][0];
+      fq += red[tid * ft + j][1];
+    }
+    fine[tid][0] = fs;
+    fine[tid][1] = fq;
+  }
+  __syncthreads();
+  const int GM = G / gmerge;
+  if (tid < GM) {
+    double ms = 0, mq = 0;
+    for (int j = 0; j < gmerge; ++j) {
+      ms += fine[tid * gmerge + j][0];
+      mq += fine[tid * gmerge + j][1];
+    }
+    const double mean = ms * inv_count;
+    double var = mq * inv_count - mean * mean;
     if (var < 0) var = 0;
     s_mean[tid] = (float)mean;
     s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
   }
   __syncthreads();
-  for (int c = tid; c < C; c += blockDim.x) {
-    const int g = c / cpg;
-    const float sc = s_rstd[g] * gamma[c];
-    scale[(size_t)b * C + c] = sc;
-    shift[(size_t)b * C + c] = -sc * s_mean[g] + beta[c];
+  const int cpm = cpg * gmerge;
+  for (int c = tid; c < C; c += 256) {
+    const int m = c / cpm;
+    const float sc = s_rstd[m] * gamma[c];
+    scale[(size_t)b * ld + c] = sc;
+    shift[(size_t)b * ld + c] = -sc * s_mean[m] + beta[c];
   }
 }
 
@@ -146,26 +177,28 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 
 }  // namespace
 
-extern "C" int cf_groupnorm_stats(const float* x, int batch, int hw, int c, int cpg, double* partial, int gtotal,
-                                  int g0, int nblk, cf_stream_t stream) {
+extern "C" int cf_groupnorm_stats(const float* x, int batch, int hw, int c, int cpg, double* partial, int parts,
+                                  cf_stream_t stream) {
   CF_REQUIRE(x && partial, "cf_groupnorm_stats: null pointer");
   CF_REQUIRE(c >= 16 && c <= 1024 && (1024 % c) == 0, "cf_groupnorm_stats: C=%d must divide 1024 and be >= 16", c);
   CF_REQUIRE(cpg >= 2 && (cpg % 2) == 0 && c % cpg == 0 && c / cpg <= 64, "cf_groupnorm_stats: bad cpg %d for C %d", cpg, c);
-  CF_REQUIRE(nblk >= 1 && batch >= 1 && hw >= 1 && g0 >= 0 && g0 + c / cpg <= gtotal, "cf_groupnorm_stats: bad dims");
-  const int rows_per_blk = (hw + nblk - 1) / nblk;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, batch), dim3(256), 0, (hipStream_t)stream, x, hw, c, cpg, rows_per_blk,
-                     partial, gtotal, g0, nblk);
+  CF_REQUIRE(parts >= 1 && batch >= 1 && hw >= 1, "cf_groupnorm_stats: bad dims");
+  const int rows_per_blk = (hw + parts - 1) / parts;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(parts, batch), dim3(256), 0, (hipStream_t)stream, x, hw, c, cpg, rows_per_blk,
+                     partial, parts);
   CF_CHECK_LAUNCH("cf_groupnorm_stats");
   return CF_OK;
 }
 
-extern "C" int cf_groupnorm_finalize(const double* partial, int batch, int gtotal, int nblk, int c, int cpg,
+extern "C" int cf_groupnorm_finalize(const double* partial, int batch, int parts, int c, int cpg, int gmerge,
                                      int64_t count, const float* gamma, const float* beta, float eps, float* scale,
-                                     float* shift, cf_stream_t stream) {
+                                     float* shift, int ld, cf_stream_t stream) {
   CF_REQUIRE(partial && gamma && beta && scale && shift, "cf_groupnorm_finalize: null pointer");
-  CF_REQUIRE(gtotal >= 1 && gtotal <= 64 && c == gtotal * cpg && count > 0, "cf_groupnorm_finalize: bad dims");
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, partial, gtotal, nblk, c, cpg,
-                     1.0 / (double)count, gamma, beta, eps, scale, shift);
+  CF_REQUIRE(cpg >= 1 && c % cpg == 0 && c / cpg <= 64 && gmerge >= 1 && (c / cpg) % gmerge == 0 && count > 0 &&
+                 parts >= 1 && ld >= c,
+             "cf_groupnorm_finalize: bad dims (c=%d cpg=%d gmerge=%d parts=%d ld=%d)", c, cpg, gmerge, parts, ld);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, partial, parts, c, cpg, gmerge,
+                     1.0 / (double)count, gamma, beta, eps, scale, shift, ld);
   CF_CHECK_LAUNCH("cf_groupnorm_finalize");
   return CF_OK;
 }

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_PKG, 'libcodeformer_hip.so')
 
 c_float_p = ctypes.c_void_p  # device pointers are passed as integers
 
+ABI_VERSION = 2
 PRO_NONE, PRO_AFFINE, PRO_AFFINE_SWISH, PRO_LEAKY = 0, 1, 2, 3
 EPI_NONE, EPI_RESIDUAL, EPI_SFT, EPI_GELU = 0, 1, 2, 3
 
@@ -33,6 +34,7 @@ class ConvDesc(ctypes.Structure):
         ('res', ctypes.c_void_p), ('sft_scale', ctypes.c_void_p),
         ('sft_w', ctypes.c_float),
         ('out', ctypes.c_void_p),
+        ('stats_out', ctypes.c_void_p), ('stats_cpg', ctypes.c_int32),
     ]
 
 
@@ -43,10 +45,11 @@ SIGNATURES = {
     'cf_last_error': (ctypes.c_char_p, []),
     'cf_device_cu_count': (_I, []),
     'cf_conv2d': (_I, [ctypes.POINTER(ConvDesc), _P]),
+    'cf_conv2d_stats_parts': (_I, [ctypes.POINTER(ConvDesc)]),
     'cf_pack_conv_weight': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     'cf_packed_weight_elems': (_L, [_I, _I, _I]),
-    'cf_groupnorm_stats': (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P]),
-    'cf_groupnorm_finalize': (_I, [_P, _I, _I, _I, _I, _I, _L, _P, _P, _F, _P, _P, _P]),
+    'cf_groupnorm_stats': (_I, [_P, _I, _I, _I, _I, _P, _I, _P]),
+    'cf_groupnorm_finalize': (_I, [_P, _I, _I, _I, _I, _I, _L, _P, _P, _F, _P, _P, _I, _P]),
     'cf_layernorm': (_I, [_P, _I, _I, _P, _P, _F, _P, _I, _P, _P, _P]),
     'cf_attention': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
     'cf_argmax_rows': (_I, [_P, _I, _I, _P, _P]),
@@ -85,8 +88,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.cf_version() != 1:
-        raise NativeLibraryError(f'ABI version mismatch: library {lib.cf_version()}, binding 1')
+    if lib.cf_version() != ABI_VERSION:
+        raise NativeLibraryError(f'ABI version mismatch: library {lib.cf_version()}, binding {ABI_VERSION}')
     _lib = lib
     return lib
 

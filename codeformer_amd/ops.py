@@ -26,6 +26,16 @@ def _f32(t):
     return t
 
 
+class GNStats:
+    """fp64 (sum, sumsq) partials of one NHWC tensor: [batch][channels/cpg][parts][2] (see cf_groupnorm_finalize).
+    Produced by a conv epilogue (attached to the conv's output tensor as `._cf_stats`) or by the stand-alone pass."""
+
+    __slots__ = ('part', 'parts', 'cpg')
+
+    def __init__(self, part, parts, cpg):
+        self.part, self.parts, self.cpg = part, parts, cpg
+
+
 class PackedWeight:
     """A conv / linear weight in the kernel layout [tap][cin_pad/16][cout_pad][16] (+ bias)."""
 
@@ -72,9 +82,11 @@ def pack_weight_cat(weights, biases):
 
 
 def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale=None, shift=None,
-           epilogue=EPI_NONE, res=None, sft_scale=None, sft_w=0.0, in_nchw=False, out_nchw=False):
+           epilogue=EPI_NONE, res=None, sft_scale=None, sft_w=0.0, in_nchw=False, out_nchw=False, emit_stats=False):
     """Implicit-GEMM conv (3x3 / 1x1).  x: (B,H,W,C0) [x2: (B,H,W,C1) concatenated after x]; returns (B,Ho,Wo,cout)
-    (or (B,cout,Ho,Wo) when out_nchw).  With in_nchw, x is (B,C<=4,H,W)."""
+    (or (B,cout,Ho,Wo) when out_nchw).  With in_nchw, x is (B,C<=4,H,W).
+    emit_stats: also write the GroupNorm(32) partial statistics of the output in the epilogue and attach them to the
+    returned tensor (`._cf_stats`), so a following groupnorm_tables() does not re-read the tensor."""
     lib = L.load()
     _f32(x)
     if in_nchw:
@@ -106,6 +118,14 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
         out_nchw=int(bool(out_nchw)), prologue=prologue, epilogue=epilogue, pro_scale=L.ptr(scale),
         pro_shift=L.ptr(shift), weight=L.ptr(pw.w), bias=L.ptr(pw.bias), res=L.ptr(res), sft_scale=L.ptr(sft_scale),
         sft_w=float(sft_w), out=L.ptr(out))
+    if emit_stats and not out_nchw and pw.cout % GN_GROUPS == 0 and pw.cout // GN_GROUPS >= 2:
+        d.stats_cpg = pw.cout // GN_GROUPS
+        parts = lib.cf_conv2d_stats_parts(ctypes.byref(d))
+        if parts <= 0:
+            raise RuntimeError(f'cf_conv2d_stats_parts failed ({parts}): {L.last_error()}')
+        part = torch.empty(B * GN_GROUPS * parts * 2, dtype=torch.float64, device=x.device)
+        d.stats_out = L.ptr(part)
+        out._cf_stats = GNStats(part, parts, d.stats_cpg)
     if PROFILE is None:
         L.check(lib.cf_conv2d(ctypes.byref(d), L.stream_ptr()), 'cf_conv2d')
         return out
@@ -134,7 +154,10 @@ def linear(x, pw, *, epilogue=EPI_NONE, res=None):
 
 def groupnorm_tables(xs, gamma, beta, eps=GN_EPS, groups=GN_GROUPS):
     """GroupNorm(groups) statistics of the channel-concatenation of xs (each (B,H,W,Ci)) folded with the affine
-    parameters into per-(b,c) scale / shift tables (B, sum Ci), to be applied by a conv prologue."""
+    parameters into per-(b,c) scale / shift tables (B, sum Ci), to be applied by a conv prologue.
+
+    Tensors that carry epilogue statistics (`._cf_stats`, see conv2d(emit_stats=True)) are not read again; the others
+    go through the stand-alone statistics pass."""
     lib = L.load()
     B, H, W, _ = xs[0].shape
     ctot = sum(t.shape[3] for t in xs)
@@ -142,22 +165,27 @@ def groupnorm_tables(xs, gamma, beta, eps=GN_EPS, groups=GN_GROUPS):
         raise ValueError(f'{ctot} channels not divisible by {groups} groups')
     cpg = ctot // groups
     hw = H * W
-    # ~128 KB of input per block, enough blocks to cover 256 CUs several times over, at most 256 partials per group
-    nblk = max(1, min(256, (hw * max(t.shape[3] for t in xs) * 4 + (1 << 17) - 1) >> 17))
-    part = torch.empty(B * groups * nblk * 2, dtype=torch.float64, device=xs[0].device)
-    g0 = 0
+    dev = xs[0].device
+    scale = torch.empty(B, ctot, dtype=torch.float32, device=dev)
+    shift = torch.empty_like(scale)
+    g_ptr, b_ptr, sc_ptr, sh_ptr = L.ptr(gamma), L.ptr(beta), L.ptr(scale), L.ptr(shift)
+    coff = 0
     for t in xs:
         _f32(t)
         c = t.shape[3]
         if c % cpg:
             raise ValueError('concat boundary splits a group')
-        L.check(lib.cf_groupnorm_stats(L.ptr(t), B, hw, c, cpg, L.ptr(part), groups, g0, nblk, L.stream_ptr()),
-                'cf_groupnorm_stats')
-        g0 += c // cpg
-    scale = torch.empty(B, ctot, dtype=torch.float32, device=xs[0].device)
-    shift = torch.empty_like(scale)
-    L.check(lib.cf_groupnorm_finalize(L.ptr(part), B, groups, nblk, ctot, cpg, hw * cpg, L.ptr(gamma), L.ptr(beta),
-                                      float(eps), L.ptr(scale), L.ptr(shift), L.stream_ptr()), 'cf_groupnorm_finalize')
+        st = getattr(t, '_cf_stats', None)
+        if st is None or cpg % st.cpg:
+            # ~128 KB of input per block, enough blocks to cover 256 CUs several times, at most 256 partials per group
+            nblk = max(1, min(256, (hw * c * 4 + (1 << 17) - 1) >> 17))
+            part = torch.empty(B * (c // cpg) * nblk * 2, dtype=torch.float64, device=dev)
+            L.check(lib.cf_groupnorm_stats(L.ptr(t), B, hw, c, cpg, L.ptr(part), nblk, L.stream_ptr()), 'cf_groupnorm_stats')
+            st = GNStats(part, nblk, cpg)
+        L.check(lib.cf_groupnorm_finalize(L.ptr(st.part), B, st.parts, c, st.cpg, cpg // st.cpg, hw * cpg,
+                                          g_ptr + 4 * coff, b_ptr + 4 * coff, float(eps), sc_ptr + 4 * coff,
+                                          sh_ptr + 4 * coff, ctot, L.stream_ptr()), 'cf_groupnorm_finalize')
+        coff += c
     return scale, shift
 
 

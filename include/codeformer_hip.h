@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 1
+#define CF_ABI_VERSION 2
 
 typedef void* cf_stream_t; /* hipStream_t */
 
@@ -86,9 +86,15 @@ typedef struct cf_conv_desc {
   const float* sft_scale; /* [batch][hout][wout][cout] (SFT) */
   float sft_w;
   float* out;
+  double* stats_out;      /* optional: fp64 partial (sum, sumsq) of the OUTPUT per (image, group of stats_cpg channels,
+                             tile part), layout [batch][cout/stats_cpg][parts][2], parts = cf_conv2d_stats_parts(d);
+                             feeds cf_groupnorm_finalize so the next GroupNorm never re-reads the tensor */
+  int32_t stats_cpg;      /* channels per statistics group: power of two in [2,32] dividing cout */
 } cf_conv_desc;
 
 int cf_conv2d(const cf_conv_desc* d, cf_stream_t stream);
+/* number of statistics partials per (image, group) the launch described by d will write (>0), or <0 on error */
+int cf_conv2d_stats_parts(const cf_conv_desc* d);
 
 /* Pack a PyTorch conv/linear weight [cout][cin][kh*kw] (taps = 1 or 9) into the kernel layout
  * [tap][cin_pad/16][cout_pad][16] (zero padded). */
@@ -97,14 +103,19 @@ int cf_pack_conv_weight(const float* w, int cout, int cin, int taps, int cout_pa
 int64_t cf_packed_weight_elems(int cin_pad, int taps, int cout_pad);
 
 /* ---- GroupNorm statistics (vqgan_arch.py:14-15: 32 groups, eps 1e-6, biased variance) --------
- * stats:    partial (sum, sumsq) in fp64 per (batch, group, block) over an NHWC tensor with C channels
- *           whose groups are `cpg` channels wide; written at group offset g0 of a [batch][gtotal][nblk][2] table.
- * finalize: fixed-order sum of the partials -> scale[b][c] = gamma*rstd, shift[b][c] = beta - mean*scale.
+ * Partials are fp64 (sum, sumsq) tables [batch][groups][parts][2] over an NHWC tensor with c channels whose (fine)
+ * groups are cpg channels wide.  They come from a conv epilogue (cf_conv_desc.stats_out) or from
+ * cf_groupnorm_stats (stand-alone pass, `parts` blocks per image).
+ * finalize: fixed-order sum of the partials; `gmerge` adjacent fine groups form one GroupNorm group (the CFT block
+ *           normalises cat[enc, dec]: its groups are pairs of each tensor's own 32 groups); writes, for the c
+ *           channels of THIS tensor, scale[b*ld + i] = gamma[i]*rstd, shift[b*ld + i] = beta[i] - mean*scale
+ *           (callers pre-offset gamma/beta/scale/shift to the tensor's first channel inside a concatenation;
+ *           ld = row stride of the tables = total channels).  count = elements per merged group.
  */
-int cf_groupnorm_stats(const float* x, int batch, int hw, int c, int cpg, double* partial, int gtotal, int g0,
-                       int nblk, cf_stream_t stream);
-int cf_groupnorm_finalize(const double* partial, int batch, int gtotal, int nblk, int c, int cpg, int64_t count,
-                          const float* gamma, const float* beta, float eps, float* scale, float* shift,
+int cf_groupnorm_stats(const float* x, int batch, int hw, int c, int cpg, double* partial, int parts,
+                       cf_stream_t stream);
+int cf_groupnorm_finalize(const double* partial, int batch, int parts, int c, int cpg, int gmerge, int64_t count,
+                          const float* gamma, const float* beta, float eps, float* scale, float* shift, int ld,
                           cf_stream_t stream);
 
 /* ---- LayerNorm over the last dim (codeformer_arch.py:108-109,124,131,191; eps 1e-5) ----------

@@ -136,6 +136,36 @@ def g_basic():
         report('groupnorm concat', y, F.group_norm(xc, 32, g.double(), b.double(), 1e-6), 3e-6, 3e-6)
     run('groupnorm', t_gn)
 
+    def t_gn_epilogue():
+        """GroupNorm tables from conv-epilogue statistics == tables from the stand-alone pass == fp64 group_norm."""
+        cases = [(64, 64, 32, 3, 1, False), (64, 128, 32, 3, 1, False), (128, 256, 16, 3, 1, False), (64, 64, 64, 3, 2, False),
+                 (64, 64, 16, 3, 1, True), (128, 128, 16, 1, 1, False), (512, 512, 16, 3, 1, False), (128, 64, 32, 1, 1, False)]
+        for i, (cin, cout, H, k, stride, up) in enumerate(cases):
+            x = rnd((2, cin, H, H), 300 + i)
+            w = rnd((cout, cin, k, k), 320 + i, 1.0 / (cin * k * k) ** 0.5)
+            bias = rnd((cout,), 340 + i, 0.3) + 0.5
+            g, b = rnd((cout,), 360 + i), rnd((cout,), 380 + i)
+            pw = ops.pack_weight(w.to(DEV), bias.to(DEV))
+            y = ops.conv2d(nhwc(x).to(DEV), pw, stride=stride, upsample=up, emit_stats=True)
+            assert getattr(y, '_cf_stats', None) is not None, 'conv2d did not attach statistics'
+            sc, sh = ops.groupnorm_tables([y], g.to(DEV), b.to(DEV))
+            yc = nchw(y).double().cpu()
+            got = yc * sc.double().cpu().view(2, cout, 1, 1) + sh.double().cpu().view(2, cout, 1, 1)
+            report(f'epilogue-stats GN cin{cin} cout{cout} H{H} k{k} s{stride} up{int(up)} (parts={y._cf_stats.parts})', got,
+                   F.group_norm(yc, 32, g.double(), b.double(), 1e-6), 5e-6, 5e-6)
+        # concat of two conv outputs: pairs of fine groups are merged by the finalize
+        xa, xb = rnd((2, 64, 32, 32), 401), rnd((2, 64, 32, 32), 402)
+        pwa = ops.pack_weight(rnd((128, 64, 3, 3), 403, 0.05).to(DEV), rnd((128,), 404).to(DEV))
+        pwb = ops.pack_weight(rnd((128, 64, 3, 3), 405, 0.08).to(DEV), rnd((128,), 406).to(DEV))
+        ya = ops.conv2d(nhwc(xa).to(DEV), pwa, emit_stats=True)
+        yb = ops.conv2d(nhwc(xb).to(DEV), pwb, emit_stats=True)
+        g, b = rnd((256,), 407), rnd((256,), 408)
+        sc, sh = ops.groupnorm_tables([ya, yb], g.to(DEV), b.to(DEV))
+        yc = torch.cat([nchw(ya), nchw(yb)], 1).double().cpu()
+        got = yc * sc.double().cpu().view(2, 256, 1, 1) + sh.double().cpu().view(2, 256, 1, 1)
+        report('epilogue-stats GN concat (gmerge=2)', got, F.group_norm(yc, 32, g.double(), b.double(), 1e-6), 5e-6, 5e-6)
+    run('groupnorm-epilogue', t_gn_epilogue)
+
 
 # ----------------------------------------------------------------------------------------------------
 def conv_case(name, cin, cout, H, *, B=2, k=3, stride=1, upsample=False, c_split=None, prologue=PRO_NONE,

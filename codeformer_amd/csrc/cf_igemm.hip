@@ -54,7 +54,9 @@ struct Cfg {
   static constexpr int APT = (NPIX * 4 + 255) / 256;  // float4 gather items per thread
   static constexpr int BPT = (BN * 4 + 255) / 256;    // float4 weight items per thread
   static constexpr int BBUF = (TAPS == 9) ? 3 : 2;    // weight-slab ring depth in LDS
-  static constexpr int LDS_FLOATS = ABUF * NPIX * CF_LDK + BBUF * BN * CF_LDK;
+  static constexpr int LDS_MAIN = ABUF * NPIX * CF_LDK + BBUF * BN * CF_LDK;
+  static constexpr int LDS_EPI = 4 * 32 * (NI * 32 + 4);  // per-wave 32-row transpose buffers of the epilogue
+  static constexpr int LDS_FLOATS = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
 };
 
 // x * sigmoid(x) with sigmoid = 1/(1+exp(-x)), the operation order of vqgan_arch.py:18-20
@@ -267,12 +269,15 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const ConvArgs a) {
     };
     auto tap_off = [](int tap) { return ((tap / 3) * C::HWD + (tap % 3)) * CF_LDK; };
 
-    load_A(0, ra);
-    load_B(0, rb);
-    store_A(0, ra, 0);
-    store_B(0, rb);
-    load_B(1 < nsteps ? 1 : 0, rb);
-    store_B(1, rb);
+    {
+      f32x4 rb1[C::BPT];  // all three prologue fetches in flight together: one exposed HBM/L2 latency, not two
+      load_A(0, ra);
+      load_B(0, rb);
+      load_B(1 < nsteps ? 1 : 0, rb1);
+      store_A(0, ra, 0);
+      store_B(0, rb);
+      store_B(1, rb1);
+    }
     __syncthreads();
     f32x4 ax[MI], bx[NI], ay[MI], by[NI];
     read_frags(ax, bx, tap_off(0), 0, 0);
@@ -327,15 +332,117 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const ConvArgs a) {
     }
   }
 
-  // ---- epilogue: accumulator (row = pixel, col = n = lane&31) -> bias / residual / SFT / GELU -> HBM ----
-  auto epilogue = [&](auto mode) {
+  // ---- epilogue ------------------------------------------------------------------------------------------
+  // The accumulator layout (lane = one output channel, 16 rows per register file) would need 64 scalar stores
+  // (+64 residual loads) per lane and the store tail is ISSUE-bound.  Instead each wave transposes its tile through
+  // LDS (free after the main loop) 32 rows at a time and touches HBM with 16-byte accesses: lane -> 4 consecutive
+  // channels of one pixel; bias / residual / SFT / GELU and the GroupNorm statistics are applied in that layout.
+  constexpr int LDW = NI * 32 + 4;       // padded row of the per-wave transpose buffer
+  constexpr int Q = NI * 8;              // float4 per tile row
+  constexpr int RPP = 64 / Q;            // rows per pass
+  constexpr int PASSES = 32 / RPP;
+  const bool vec_ok = !(TAPS == 9 && a.out_nchw) && (a.cout % 4) == 0;
+
+  auto epilogue_vec = [&](auto mode) {
+    constexpr int EPI = decltype(mode)::value;
+    float* stage = smem + wave * (32 * LDW);
+    const int cq = lane % Q, rl = lane / Q;
+    const int n = n0 + wn * (NI * 32) + cq * 4;
+    const bool nvalid = n < a.cout;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias && nvalid) bias4 = *reinterpret_cast<const f32x4*>(a.bias + n);
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      __syncthreads();  // main loop (or the previous half) is done with this LDS region
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stage[cf_acc_row(r, lane) * LDW + ni * 32 + l31] = acc[mi][ni][r];
+      __syncthreads();
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p) {
+        const int trow = p * RPP + rl;
+        f32x4 v = *reinterpret_cast<const f32x4*>(stage + trow * LDW + cq * 4);
+        const int row = wm * (MI * 32) + mi * 32 + trow;
+        size_t pixel;
+        if (TAPS == 9)
+          pixel = ((size_t)b * a.hout + (y0 + (row >> 4))) * a.wout + (x0 + (row & 15));
+        else
+          pixel = (size_t)m0 + row;
+        const size_t o = pixel * a.cout + n;
+        if (nvalid) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bias4[e];
+          if (EPI == CF_EPI_RESIDUAL) {
+            const f32x4 rr = *reinterpret_cast<const f32x4*>(a.res + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += rr[e];
+          } else if (EPI == CF_EPI_SFT) {
+            const f32x4 dec = *reinterpret_cast<const f32x4*>(a.res + o);
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.sft_scale + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = dec[e] + a.sft_w * (dec[e] * sc[e] + v[e]);
+          } else if (EPI == CF_EPI_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+          }
+          *reinterpret_cast<f32x4*>(a.out + o) = v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            ssum[e] += v[e];
+            ssq[e] += v[e] * v[e];
+          }
+        }
+      }
+    }
+    if (a.stats_out) {
+      // GroupNorm statistics of the values just written, for the NEXT norm: one fp64 partial per (image, group,
+      // tile, wave row), combined in a fixed shuffle order -> the later finalize is a deterministic sum.
+      const int cpg = a.stats_cpg;
+      double d0, q0, d1 = 0, q1 = 0;
+      if (cpg == 2) {  // two groups per lane
+        d0 = (double)ssum[0] + ssum[1];
+        q0 = (double)ssq[0] + ssq[1];
+        d1 = (double)ssum[2] + ssum[3];
+        q1 = (double)ssq[2] + ssq[3];
+      } else {
+        d0 = ((double)ssum[0] + ssum[1]) + ((double)ssum[2] + ssum[3]);
+        q0 = ((double)ssq[0] + ssq[1]) + ((double)ssq[2] + ssq[3]);
+      }
+      for (int o = Q; o < 64; o <<= 1) {  // lanes holding the same channels, different rows
+        d0 += __shfl_xor(d0, o, 64);
+        q0 += __shfl_xor(q0, o, 64);
+        d1 += __shfl_xor(d1, o, 64);
+        q1 += __shfl_xor(q1, o, 64);
+      }
+      for (int o = 1; o * 4 < cpg; o <<= 1) {  // adjacent channel quads of one group (cpg >= 8)
+        d0 += __shfl_xor(d0, o, 64);
+        q0 += __shfl_xor(q0, o, 64);
+      }
+      if (rl == 0 && nvalid && (n % cpg) == 0) {
+        const int tile_in_img = (TAPS == 9) ? (mt - b * a.tiles_per_img) : (m0 - b * (a.hout * a.wout)) / C::BM;
+        const size_t pidx = (size_t)tile_in_img * WM + wm;
+        const int ng = a.cout / cpg;
+        double* o = a.stats_out + (((size_t)b * ng + n / cpg) * a.nparts + pidx) * 2;
+        o[0] = d0;
+        o[1] = q0;
+        if (cpg == 2) {
+          o[(size_t)a.nparts * 2] = d1;      // group n/2 + 1
+          o[(size_t)a.nparts * 2 + 1] = q1;
+        }
+      }
+    }
+  };
+
+  // scalar path: NCHW scatter of the 3-channel image (and any cout that is not a multiple of 4)
+  auto epilogue_scalar = [&](auto mode) {
     constexpr int EPI = decltype(mode)::value;
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       const int n = n0 + wn * (NI * 32) + ni * 32 + l31;
       const bool nvalid = n < a.cout;
       const float bias = (a.bias && nvalid) ? a.bias[n] : 0.f;
-      float ssum = 0.f, ssq = 0.f;  // GroupNorm statistics of this lane's output column (MI*16 rows)
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -365,37 +472,20 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const ConvArgs a) {
               a.out[(((size_t)b * a.cout + n) * a.hout + oy) * a.wout + ox] = v;
             else
               a.out[o] = v;
-            ssum += v;
-            ssq += v * v;
           }
-        }
-      }
-      if (a.stats_out) {
-        // Fold the statistics the NEXT GroupNorm needs into this epilogue: lane halves hold the same column,
-        // a group is stats_cpg adjacent columns; one fp64 partial per (image, group, tile, wave row) in a fixed
-        // order -> the later finalize is a deterministic sum and the tensor is never re-read for its norm.
-        double ds = ssum, dq = ssq;
-        ds += __shfl_xor(ds, 32, 64);
-        dq += __shfl_xor(dq, 32, 64);
-        for (int o = 1; o < a.stats_cpg; o <<= 1) {
-          ds += __shfl_xor(ds, o, 64);
-          dq += __shfl_xor(dq, o, 64);
-        }
-        if (lane < 32 && nvalid && (n % a.stats_cpg) == 0) {
-          const int tile_in_img = (TAPS == 9) ? (mt - b * a.tiles_per_img) : (m0 - b * (a.hout * a.wout)) / C::BM;
-          const size_t pidx = (size_t)tile_in_img * WM + wm;
-          double* o = a.stats_out + (((size_t)b * (a.cout / a.stats_cpg) + n / a.stats_cpg) * a.nparts + pidx) * 2;
-          o[0] = ds;
-          o[1] = dq;
         }
       }
     }
   };
-  switch (a.epilogue) {
-    case CF_EPI_RESIDUAL: epilogue(std::integral_constant<int, CF_EPI_RESIDUAL>{}); break;
-    case CF_EPI_SFT: epilogue(std::integral_constant<int, CF_EPI_SFT>{}); break;
-    case CF_EPI_GELU: epilogue(std::integral_constant<int, CF_EPI_GELU>{}); break;
-    default: epilogue(std::integral_constant<int, CF_EPI_NONE>{}); break;
+  if (vec_ok) {
+    switch (a.epilogue) {
+      case CF_EPI_RESIDUAL: epilogue_vec(std::integral_constant<int, CF_EPI_RESIDUAL>{}); break;
+      case CF_EPI_SFT: epilogue_vec(std::integral_constant<int, CF_EPI_SFT>{}); break;
+      case CF_EPI_GELU: epilogue_vec(std::integral_constant<int, CF_EPI_GELU>{}); break;
+      default: epilogue_vec(std::integral_constant<int, CF_EPI_NONE>{}); break;
+    }
+  } else {
+    epilogue_scalar(std::integral_constant<int, CF_EPI_NONE>{});  // host guarantees: no epilogue op, no statistics
   }
 }
 
@@ -493,6 +583,9 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
   CF_REQUIRE(d->hout == exp_h && d->wout == exp_w, "cf_conv2d: hout/wout %dx%d, expected %dx%d", d->hout, d->wout,
              exp_h, exp_w);
   CF_REQUIRE(d->stride == 1 || (d->hin % 2 == 0 && d->win % 2 == 0), "cf_conv2d: stride 2 needs even input");
+  if (d->out_nchw || d->cout % 4 != 0)
+    CF_REQUIRE(d->epilogue == CF_EPI_NONE && !d->stats_out, "cf_conv2d: cout %d / NCHW output supports no epilogue op or statistics",
+               d->cout);
   if (d->stats_out || (pq && d->stats_cpg)) {
     const int g = d->stats_cpg;
     CF_REQUIRE(g >= 2 && g <= 32 && (g & (g - 1)) == 0 && d->cout % g == 0 && !d->out_nchw,
@@ -548,16 +641,11 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
   a.tiles_x = a.tiles_per_img = a.ntn = 0;
 
   const int cp = d->cout_pad;
-  // Small-M layers (16x16 / 32x32 latents): a 128x128 tiling yields fewer workgroups than 1.5x the CU count, so half the
-  // chip idles.  Halving the N tile doubles the workgroup count at the price of gathering the halo patch twice.
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0, v = 0;
-    n_cu = (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-  }
-  const long wg128 = ((long)d->batch * d->hout * d->wout / 128) * (cp / 128);
-  const bool narrow = cp % 128 == 0 && wg128 * 2 <= 3L * n_cu;
+  // Small-M layers (16x16 / 32x32 latents): at batch 16 a 128x128 tiling yields only 128-256 workgroups for 256 CUs;
+  // halving the N tile doubles the workgroup count at the price of gathering the halo patch twice.  The choice depends
+  // on the per-image shape ONLY, never on the batch: tiling (and with it the order of the statistics partials) must be
+  // the same for a face whether it is restored alone or inside any batch / shard, so results stay bitwise batch-invariant.
+  const bool narrow = cp % 128 == 0 && (long)d->hout * d->wout <= 1024;
   if (d->taps == 9 && d->stride == 1) {
     if (d->in_nchw) {
       CF_REQUIRE(cp == 64, "cf_conv2d: in_nchw path is built for cout_pad 64 (got %d)", cp);

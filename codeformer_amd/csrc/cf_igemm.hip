@@ -19,6 +19,11 @@
 
 #include "cf_common.h"
 
+// CF_ABLATE: timing-only ablation builds (tools/ablate.sh); 0 / undefined in every product build.
+#ifndef CF_ABLATE
+#define CF_ABLATE 0
+#endif
+
 namespace {
 
 struct ConvArgs {
@@ -288,18 +293,28 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const ConvArgs a) {
       for (int tap = 0; tap < TAPS; ++tap, ++step) {
         const int slot1 = slot == 2 ? 0 : slot + 1;
         const int slot2 = slot1 == 2 ? 0 : slot1 + 1;
+#if CF_ABLATE != 4
         load_B(step + 2 < nsteps ? step + 2 : nsteps - 1, rb);  // clamped: the tail prefetches are harmless re-reads
+#endif
         if (tap == TAPS - 1) load_A(chunk + 1 < a.nchunks ? chunk + 1 : chunk, ra);
+#if CF_ABLATE != 5
         read_frags(ay, by, tap_off(tap), slot, 1);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         mma16(ax, bx);
         __builtin_amdgcn_sched_barrier(0);
+#if CF_ABLATE != 5
         if (tap != TAPS - 1) read_frags(ax, bx, tap_off(tap + 1), slot1, 0);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         mma16(ay, by);
         __builtin_amdgcn_sched_barrier(0);
+#if CF_ABLATE != 4
         store_B(slot2, rb);
+#endif
+#if CF_ABLATE != 3
         __syncthreads();
+#endif
         if (tap == TAPS - 1 && chunk + 1 < a.nchunks) {
           store_A(0, ra, chunk + 1);
           __syncthreads();
@@ -477,6 +492,19 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const ConvArgs a) {
       }
     }
   };
+#if CF_ABLATE == 1
+  {  // no epilogue: keep the accumulators live, write one value
+    float t = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[mi][ni][r];
+    if (t == 12345.678f) a.out[0] = t;
+    return;
+  }
+#endif
   if (vec_ok) {
     switch (a.epilogue) {
       case CF_EPI_RESIDUAL: epilogue_vec(std::integral_constant<int, CF_EPI_RESIDUAL>{}); break;

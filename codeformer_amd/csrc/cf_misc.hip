@@ -188,6 +188,23 @@ __global__ void tensor_to_img_u8_kernel(const float* __restrict__ t, int hw, uin
   }
 }
 
+// inpainting composite (inference_inpainting.py:68-74): mask = (sum_c x == 3), i.e. pure-white pixels of the normalised
+// input; out = (1-mask)*x + mask*y  ==  mask ? y : x  for finite values.
+__global__ void mask_composite_kernel(const float* __restrict__ x, const float* __restrict__ y, int hw, float* __restrict__ out,
+                                      long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long b = i / hw, p = i - b * hw;
+  const float* xb = x + b * 3 * hw + p;
+  const float x0 = xb[0], x1 = xb[hw], x2 = xb[2 * (long)hw];
+  const bool m = ((x0 + x1) + x2) == 3.0f;
+  const float* yb = y + b * 3 * hw + p;
+  float* ob = out + b * 3 * hw + p;
+  ob[0] = m ? yb[0] : x0;
+  ob[hw] = m ? yb[hw] : x1;
+  ob[2 * (long)hw] = m ? yb[2 * (long)hw] : x2;
+}
+
 // ---- bundled ops ----------------------------------------------------------------------------------
 __global__ void fused_bias_act_kernel(const float* __restrict__ x, const float* __restrict__ bias, long numel, int c,
                                       int hw, float slope, float scale, float* __restrict__ y) {
@@ -289,6 +306,15 @@ extern "C" int cf_tensor_to_img_u8(const float* t, int batch, int h, int w, uint
   hipLaunchKernelGGL(tensor_to_img_u8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t,
                      h * w, img, total);
   CF_CHECK_LAUNCH("cf_tensor_to_img_u8");
+  return CF_OK;
+}
+
+extern "C" int cf_mask_composite(const float* x, const float* y, int batch, int h, int w, float* out, cf_stream_t stream) {
+  CF_REQUIRE(x && y && out && batch > 0 && h > 0 && w > 0, "cf_mask_composite: bad args");
+  const long total = (long)batch * h * w;
+  hipLaunchKernelGGL(mask_composite_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, h * w,
+                     out, total);
+  CF_CHECK_LAUNCH("cf_mask_composite");
   return CF_OK;
 }
 

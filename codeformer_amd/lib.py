@@ -9,7 +9,8 @@ import os
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, 'libcodeformer_hip.so')
+# CF_LIB_PATH overrides the in-tree library (used only by tools/ablate.sh timing experiments)
+LIB_PATH = os.environ.get('CF_LIB_PATH') or os.path.join(_PKG, 'libcodeformer_hip.so')
 
 c_float_p = ctypes.c_void_p  # device pointers are passed as integers
 
@@ -60,6 +61,7 @@ SIGNATURES = {
     'cf_nhwc_to_nchw': (_I, [_P, _I, _I, _I, _P, _P]),
     'cf_img_u8_to_tensor': (_I, [_P, _I, _I, _I, _P, _P]),
     'cf_tensor_to_img_u8': (_I, [_P, _I, _I, _I, _P, _P]),
+    'cf_mask_composite': (_I, [_P, _P, _I, _I, _I, _P, _P]),
     'cf_fused_bias_act': (_I, [_P, _P, _L, _I, _I, _F, _F, _P, _P]),
     'cf_upfirdn2d': (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
 }

@@ -137,7 +137,7 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
     flops = 2.0 * B * Ho * Wo * pw.cout * cin * pw.taps
     nbytes = 4.0 * (x.numel() + (0 if x2 is None else x2.numel()) + pw.cout * cin * pw.taps + out.numel()
                     + (0 if res is None else res.numel()) + (0 if sft_scale is None else sft_scale.numel()))
-    kind = ('conv3x3_s2' if stride == 2 else 'conv3x3') if pw.taps == 9 else ('linear' if x.shape[0] == 1 and W == 16 and B == 1 else 'conv1x1')
+    kind = ('conv3x3_s2' if stride == 2 else 'conv3x3') if pw.taps == 9 else 'gemm1x1'
     PROFILE.append((kind, flops, nbytes, e0, e1, (B, H, W, cin, pw.cout)))
     return out
 
@@ -147,8 +147,9 @@ def linear(x, pw, *, epilogue=EPI_NONE, res=None):
     M, K = x.shape
     if M % 256:
         raise ValueError(f'linear: rows {M} must be a multiple of 256')
-    r4 = None if res is None else res.view(1, M // 16, 16, pw.cout)
-    y = conv2d(x.view(1, M // 16, 16, K), pw, epilogue=epilogue, res=r4)
+    # present the token matrix as (M/256) "images" of 16x16 tokens: tile selection keys on the per-image shape only
+    r4 = None if res is None else res.view(M // 256, 16, 16, pw.cout)
+    y = conv2d(x.view(M // 256, 16, 16, K), pw, epilogue=epilogue, res=r4)
     return y.view(M, pw.cout)
 
 
@@ -288,6 +289,16 @@ def tensor_to_img_u8(t):
     img = torch.empty(B, H, W, 3, dtype=torch.uint8, device=t.device)
     L.check(lib.cf_tensor_to_img_u8(L.ptr(_f32(t).contiguous()), B, H, W, L.ptr(img), L.stream_ptr()), 'cf_tensor_to_img_u8')
     return img
+
+
+def mask_composite(x, y):
+    """Inpainting composite: where the normalised input pixel is pure white (x0+x1+x2 == 3) take y, else keep x."""
+    lib = L.load()
+    B, _, H, W = x.shape
+    out = torch.empty_like(x)
+    L.check(lib.cf_mask_composite(L.ptr(_f32(x).contiguous()), L.ptr(_f32(y).contiguous()), B, H, W, L.ptr(out), L.stream_ptr()),
+            'cf_mask_composite')
+    return out
 
 
 def fused_bias_act(x, bias, negative_slope=0.2, scale=math.sqrt(2.0)):

@@ -157,6 +157,9 @@ int cf_nhwc_to_nchw(const float* x, int batch, int c, int hw, float* y, cf_strea
  * (clamp[-1,1], (x+1)/2*255, round-half-even, RGB->BGR). */
 int cf_img_u8_to_tensor(const uint8_t* img, int batch, int h, int w, float* out, cf_stream_t stream);
 int cf_tensor_to_img_u8(const float* t, int batch, int h, int w, uint8_t* img, cf_stream_t stream);
+/* inpainting composite (inference_inpainting.py:68-74): x, y, out are [batch][3][h][w]; mask = (x0+x1+x2 == 3);
+ * out = (1-mask)*x + mask*y */
+int cf_mask_composite(const float* x, const float* y, int batch, int h, int w, float* out, cf_stream_t stream);
 
 /* ---- bundled StyleGAN2 ops of basicsr/ops (unused by the hot path) ---------------
  * cf_fused_bias_act: basicsr/ops/fused_act/src/fused_bias_act_kernel.cu:20-50 forward (act=3, grad=0):

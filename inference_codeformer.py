@@ -21,11 +21,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from basicsr.utils import img2tensor, imwrite, tensor2img  # noqa: E402
+from basicsr.utils import imwrite  # noqa: E402
 from basicsr.utils.download_util import load_file_from_url  # noqa: E402
-from basicsr.utils.img_util import imread_bgr, normalize_, resize_bilinear  # noqa: E402
+from basicsr.utils.img_util import imread_bgr, resize_bilinear  # noqa: E402
 from basicsr.utils.misc import get_device  # noqa: E402
 from basicsr.utils.registry import ARCH_REGISTRY  # noqa: E402
+from codeformer_amd.cli import faces_to_tensor, tensor_to_faces  # noqa: E402
 from codeformer_amd.utils.face_misc import AlignedFaceHelper, is_gray  # noqa: E402
 
 pretrain_model_url = {
@@ -88,27 +89,6 @@ def build_net(device, args):
         net = ARCH_REGISTRY.get('CodeFormer')(dim_embd=512, codebook_size=1024, n_head=8, n_layers=9,
                                               connect_list=['32', '64', '128', '256'])
     return net.to(device).eval()
-
-
-def faces_to_tensor(faces, device):
-    """List of uint8 512x512x3 BGR -> (B,3,512,512) fp32 RGB in [-1,1] on `device`."""
-    if device.type == 'cuda':
-        from codeformer_amd import ops
-        batch = torch.from_numpy(np.stack(faces)).to(device, non_blocking=True)
-        return ops.img_u8_to_tensor(batch)
-    ts = []
-    for f in faces:
-        t = img2tensor(f / 255., bgr2rgb=True, float32=True)
-        ts.append(normalize_(t, (0.5, 0.5, 0.5), (0.5, 0.5, 0.5)))
-    return torch.stack(ts).to(device)
-
-
-def tensor_to_faces(t):
-    """(B,3,512,512) -> list of uint8 HWC BGR (tensor2img(rgb2bgr=True, min_max=(-1,1)) per face)."""
-    if t.is_cuda:
-        from codeformer_amd import ops
-        return list(ops.tensor_to_img_u8(t).cpu().numpy())
-    return [tensor2img(t[i], rgb2bgr=True, min_max=(-1, 1)) for i in range(t.shape[0])]
 
 
 def main(argv=None):

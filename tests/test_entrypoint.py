@@ -45,3 +45,30 @@ def test_whole_image_path_is_explicitly_out_of_scope(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'inference_codeformer.py'), '-i', str(src), '--device', 'cpu',
                         '--random_init_seed', '0'], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
     assert r.returncode != 0 and '--has_aligned' in (r.stdout + r.stderr)
+
+
+def test_inpainting_entrypoint_cpu(tmp_path):
+    """BASELINE config 5 plumbing: only pure-white pixels are replaced (inference_inpainting.py:68-74)."""
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    src = tmp_path / 'masked_faces'
+    os.makedirs(src)
+    a = rng.integers(0, 250, (512, 512, 3), dtype=np.uint8)
+    a[100:200, 150:300] = 255
+    Image.fromarray(a).save(src / 'm0.png')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'inference_inpainting.py'), '-i', str(src), '-o', str(tmp_path / 'o'),
+                        '--device', 'cpu', '--random_init_seed', '0'], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0 and 'Failed inference' not in r.stdout, r.stdout + r.stderr
+    b = np.asarray(Image.open(tmp_path / 'o' / 'm0.png'))
+    m = (a == 255).all(-1)
+    assert np.array_equal(a[~m], b[~m]) and (a[m] != b[m]).any()
+
+
+def test_colorization_entrypoint_cpu(tmp_path):
+    src = tmp_path / 'gray_faces'
+    _faces(str(src), 1)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'inference_colorization.py'), '-i', str(src), '-o', str(tmp_path / 'o'),
+                        '--device', 'cpu', '--random_init_seed', '0', '--suffix', 'c'], capture_output=True, text=True, timeout=600,
+                       cwd=str(tmp_path))
+    assert r.returncode == 0 and 'Failed inference' not in r.stdout, r.stdout + r.stderr
+    assert os.listdir(tmp_path / 'o') == ['f0_c.png']

@@ -37,6 +37,11 @@ def bench(name, cin, cout, H, k=3, prologue=PRO_NONE, epilogue=EPI_NONE, upsampl
     print(f'{name:52s} {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s', flush=True)
 
 
+if len(sys.argv) > 2 and sys.argv[2] == 'brief':
+    for cin, cout, H in ((128, 128, 256), (64, 64, 512)):
+        bench(f'3x3 {cin}->{cout} @{H} plain', cin, cout, H)
+        bench(f'3x3 {cin}->{cout} @{H} swish+res', cin, cout, H, prologue=PRO_AFFINE_SWISH, epilogue=EPI_RESIDUAL)
+    sys.exit(0)
 for cin, cout, H in ((64, 64, 512), (128, 128, 256), (256, 256, 64), (512, 512, 16), (256, 256, 32)):
     bench(f'3x3 {cin}->{cout} @{H} plain', cin, cout, H)
     bench(f'3x3 {cin}->{cout} @{H} swish', cin, cout, H, prologue=PRO_AFFINE_SWISH)

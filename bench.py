@@ -47,6 +47,25 @@ def build_net(device):
     return net.to(device), sd_cpu, weights
 
 
+def recorded_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_bench.json,
+    produced by tools/pmc_bench.sh on this same bench step; bench.py cannot profile itself).  Per the MI355X guide:
+    FETCH_SIZE / WRITE_SIZE are in KiB, and on gfx950 FETCH_SIZE reports half of the bytes of wide (16 B/lane) reads, so
+    bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024, launch-weighted over every 3x3 stride-1 instantiation."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_bench.json')))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    n = tot = 0
+    for k, v in d.items():
+        if k.startswith('igemm_kernel<9, 1') and 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
+            ln = v['FETCH_SIZE']['launches']
+            n += ln
+            tot += ln * (2.0 * v['FETCH_SIZE']['mean'] + v['WRITE_SIZE']['mean']) * 1024.0
+    return {'bytes_per_launch': round(tot / n), 'source': os.path.relpath(files[-1], ROOT)} if n else None
+
+
 def roofline_leg(net, x, w):
     """Per-launch event timing of every implicit-GEMM launch of one forward; returns the roofline object + a table."""
     from codeformer_amd import ops
@@ -81,7 +100,7 @@ def roofline_leg(net, x, w):
     achieved = c[0] / c[2] / 1e12
     roof = {'bound': 'mfma', 'kernel': 'igemm_kernel<9,1,...> (3x3 s1 implicit GEMM, fp32 MFMA)', 'achieved': round(achieved, 2),
             'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-            'traffic': None, 'avg_launch_ms': round(c[2] / c[3] * 1e3, 4), 'launches_per_step': c[3] // reps,
+            'traffic': recorded_traffic(), 'alg_bytes_per_launch': round(c[1] / c[3]), 'avg_launch_ms': round(c[2] / c[3] * 1e3, 4), 'launches_per_step': c[3] // reps,
             'gflop_per_step': round(c[0] / reps / 1e9, 1)}
     return roof, table
 
@@ -119,6 +138,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch-per-gpu', type=int, default=16)
     ap.add_argument('--w', type=float, default=0.5)
+    ap.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32',
+                    help="fp32 = BASELINE config 2 (the headline); bf16 = generator + CFT on bf16 MFMA operands (configs 3/5), "
+                         "encoder / Transformer / argmax stay fp32")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--details', action='store_true', help='print the per-kernel-class table to stderr')
@@ -134,6 +156,7 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {args.gpus}')
 
     net, sd_cpu, weights = build_net(dev)
+    net.precision = args.precision
     B = args.batch_per_gpu
     x = seeded_input(B, seed=1234 + rank).to(dev)     # weak scaling: every rank restores its own 16 faces
     total = B * world
@@ -165,7 +188,9 @@ def main():
         line = {
             'metric': 'aligned 512x512 faces/sec (whole node) at w=0.5', 'value': round(faces_per_s, 2), 'unit': 'faces/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if args.precision == 'fp32' else 'bf16 operands / f32 accumulate (generator+CFT); f32 (encoder, Transformer)',
+            'data': 'synthetic',
             'config': {'workload': f'BASELINE config 2: batch={B} aligned 512x512 faces per GPU, w={args.w}, adain=True, fp32, '
                                    f'CodeFormer(codebook 1024, 4 fuse levels), {weights} weights', 'global_batch': total,
                        'parallelism': f'faces sharded x{world}, one gather to rank 0' if world > 1 else 'single GPU'},
@@ -173,7 +198,7 @@ def main():
                            'frac_fp32_mfma_peak': round(faces_per_s * GFLOP_PER_FACE / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world), 4),
                            'frac_hbm_peak_fused_min_bytes': round(faces_per_s * FUSED_MIN_GB_PER_FACE / (HBM_PEAK_GBS * world), 4)},
         }
-        if not args.no_roofline:
+        if not args.no_roofline and args.precision == 'fp32':
             roof, table = roofline_leg(net, x, args.w)
             line['roofline'] = roof
             if args.details:

@@ -12,6 +12,8 @@ codeformer_amd/csrc with channels-last activations:
   -> logits GEMM -> wavefront-shuffle argmax (== softmax+topk(1), lowest index on ties) -> codebook gather (+AdaIN)
   -> generator with the controllable feature transform fused into conv gathers / epilogues.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -126,12 +128,12 @@ class Fuse_sft_block(HipModule):
         self.shift = nn.Sequential(nn.Conv2d(in_ch, out_ch, kernel_size=3, padding=1), nn.LeakyReLU(0.2, True),
                                    nn.Conv2d(out_ch, out_ch, kernel_size=3, padding=1))
 
-    def forward_nhwc(self, enc, dec, w=1):
-        e = self.encode_enc.forward_nhwc(enc, dec)
-        s = ops.conv2d(e, self._pw_conv(self.scale[0]))
-        s = ops.conv2d(s, self._pw_conv(self.scale[2]), prologue=PRO_LEAKY)
-        h = ops.conv2d(e, self._pw_conv(self.shift[0]))
-        return ops.conv2d(h, self._pw_conv(self.shift[2]), prologue=PRO_LEAKY, epilogue=EPI_SFT, res=dec, sft_scale=s,
+    def forward_nhwc(self, enc, dec, w=1, bf16=False):
+        e = self.encode_enc.forward_nhwc(enc, dec, bf16=bf16)
+        s = ops.conv2d(e, self._pw_conv(self.scale[0], bf16))
+        s = ops.conv2d(s, self._pw_conv(self.scale[2], bf16), prologue=PRO_LEAKY)
+        h = ops.conv2d(e, self._pw_conv(self.shift[0], bf16))
+        return ops.conv2d(h, self._pw_conv(self.shift[2], bf16), prologue=PRO_LEAKY, epilogue=EPI_SFT, res=dec, sft_scale=s,
                           sft_w=float(w), emit_stats=True)
 
     def forward(self, enc_feat, dec_feat, w=1):
@@ -156,6 +158,9 @@ class CodeFormer(VQAutoEncoder):
                 for p in getattr(self, name).parameters():
                     p.requires_grad = False
 
+        # 'fp32': everything on exact fp32 MFMA.  'bf16' (BASELINE configs 3/5): generator + CFT 3x3 convs on bf16 MFMA
+        # operands with fp32 accumulate; encoder, Transformer and the code argmax stay fp32 so the indices stay exact.
+        self.precision = os.environ.get('CODEFORMER_HIP_PRECISION', 'fp32')
         self.connect_list = connect_list
         self.n_layers = n_layers
         self.n_head = n_head
@@ -207,13 +212,16 @@ class CodeFormer(VQAutoEncoder):
                                     lq=tokens.view(B, T, -1) if adain else None)
         quant = quant.view(B, lq.shape[1], lq.shape[2], -1)
 
+        if self.precision not in ('fp32', 'bf16'):
+            raise ValueError(f"precision must be 'fp32' or 'bf16', got {self.precision!r}")
+        bf16 = self.precision == 'bf16'
         gen_taps = None
         if w > 0:
             def fuse(t):
                 f = str(t.shape[2])
-                return self.fuse_convs_dict[f].forward_nhwc(enc_feat[f], t, w)
+                return self.fuse_convs_dict[f].forward_nhwc(enc_feat[f], t, w, bf16=bf16)
             gen_taps = {self.fuse_generator_block[f]: fuse for f in self.connect_list}
-        out = self.generator.forward_nhwc(quant, gen_taps)                 # (B,3,512,512) NCHW
+        out = self.generator.forward_nhwc(quant, gen_taps, bf16=bf16)      # (B,3,512,512) NCHW
         self.last_indices = idx.view(B, T)
         return out, logits, lq_feat
 

@@ -24,10 +24,10 @@ class HipModule(nn.Module):
             cache[key] = ent
         return ent[1]
 
-    def _pw_conv(self, name):
+    def _pw_conv(self, name, bf16=False):
         conv = getattr(self, name) if isinstance(name, str) else name
-        key = name if isinstance(name, str) else id(conv)
-        return self._packed(key, lambda: ops.pack_weight(conv.weight, conv.bias), conv.weight, conv.bias)
+        key = (name if isinstance(name, str) else id(conv), bool(bf16))
+        return self._packed(key, lambda: ops.pack_weight(conv.weight, conv.bias, bf16=bf16), conv.weight, conv.bias)
 
     def forward_nhwc(self, x):  # pragma: no cover - abstract
         raise NotImplementedError

@@ -122,8 +122,8 @@ class Upsample(HipModule):
         super().__init__()
         self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
 
-    def forward_nhwc(self, x):
-        return ops.conv2d(x, self._pw_conv('conv'), upsample=True, emit_stats=True)
+    def forward_nhwc(self, x, bf16=False):
+        return ops.conv2d(x, self._pw_conv('conv', bf16), upsample=True, emit_stats=True)
 
     def forward_host(self, x):
         return self.conv(F.interpolate(x, scale_factor=2.0, mode='nearest'))
@@ -148,16 +148,17 @@ class ResBlock(HipModule):
         if self.in_channels != oc:
             self.conv_out = nn.Conv2d(in_channels, oc, kernel_size=1, stride=1, padding=0)
 
-    def forward_nhwc(self, x, x2=None):
+    def forward_nhwc(self, x, x2=None, bf16=False):
+        """bf16=True: both 3x3 convs run on bf16 MFMA operands (fp32 accumulate / storage); the 1x1 skip stays fp32."""
         xs = (x,) if x2 is None else (x, x2)
         sc, sh = _gn_tables(self.norm1, *xs)
-        h = ops.conv2d(x, self._pw_conv('conv1'), x2=x2, prologue=PRO_AFFINE_SWISH, scale=sc, shift=sh, emit_stats=True)
+        h = ops.conv2d(x, self._pw_conv('conv1', bf16), x2=x2, prologue=PRO_AFFINE_SWISH, scale=sc, shift=sh, emit_stats=True)
         sc, sh = _gn_tables(self.norm2, h)
         if self.in_channels != self.out_channels:
             skip = ops.conv2d(x, self._pw_conv('conv_out'), x2=x2)
         else:
             skip = x
-        return ops.conv2d(h, self._pw_conv('conv2'), prologue=PRO_AFFINE_SWISH, scale=sc, shift=sh,
+        return ops.conv2d(h, self._pw_conv('conv2', bf16), prologue=PRO_AFFINE_SWISH, scale=sc, shift=sh,
                           epilogue=EPI_RESIDUAL, res=skip, emit_stats=True)
 
     def forward_host(self, x_in):
@@ -216,11 +217,14 @@ class _Conv3x3(HipModule):
         self.weight, self.bias = conv.weight, conv.bias
         self.in_channels, self.out_channels = cin, cout
 
-    def pw(self):
-        return self._packed('w', lambda: ops.pack_weight(self.weight, self.bias), self.weight, self.bias)
+    def pw(self, bf16=False):
+        return self._packed(('w', bool(bf16)), lambda: ops.pack_weight(self.weight, self.bias, bf16=bf16), self.weight,
+                            self.bias)
 
-    def forward_nhwc(self, x, **kw):
-        return ops.conv2d(x, self.pw(), **kw)
+    def forward_nhwc(self, x, bf16=False, **kw):
+        bf16 = bf16 and self.in_channels % 32 == 0 and self.out_channels % 4 == 0 and not kw.get('out_nchw') \
+            and not kw.get('in_nchw')
+        return ops.conv2d(x, self.pw(bf16), **kw)
 
     def forward_host(self, x):
         return F.conv2d(x, self.weight, self.bias, stride=1, padding=1)
@@ -239,7 +243,7 @@ class _GroupNorm(nn.GroupNorm):
         return super().forward(x)
 
 
-def _run_blocks_nhwc(blocks, x, taps=None, first_nchw=False, last_nchw=False):
+def _run_blocks_nhwc(blocks, x, taps=None, first_nchw=False, last_nchw=False, bf16=False):
     """Execute a block list on channels-last activations, folding GroupNorm entries into the following conv.
 
     taps: optional {block index: callable(x)} invoked after that block (encoder feature taps / generator fusions;
@@ -260,11 +264,11 @@ def _run_blocks_nhwc(blocks, x, taps=None, first_nchw=False, last_nchw=False):
             if i == n - 1 and last_nchw:
                 kw['out_nchw'] = True
             kw['emit_stats'] = i != n - 1      # every inner conv feeds a GroupNorm of the next block
-            x = blk.forward_nhwc(x, **kw)
+            x = blk.forward_nhwc(x, bf16=bf16, **kw)
         else:
             if pending is not None:
                 raise RuntimeError('GroupNorm must be followed by a conv in the block list')
-            x = blk.forward_nhwc(x)
+            x = blk.forward_nhwc(x, bf16=bf16) if isinstance(blk, (ResBlock, Upsample)) else blk.forward_nhwc(x)
         if taps and i in taps:
             r = taps[i](x)
             if r is not None:
@@ -351,9 +355,10 @@ class Generator(HipModule):
         with torch.no_grad():
             return self.forward_nhwc(ops.to_nhwc(x.float()))
 
-    def forward_nhwc(self, x, taps=None):
-        """x: (B,16,16,C) NHWC latent; returns the (B,3,H,W) NCHW image (written directly by the last conv)."""
-        return _run_blocks_nhwc(self.blocks, x, taps, last_nchw=True)
+    def forward_nhwc(self, x, taps=None, bf16=False):
+        """x: (B,16,16,C) NHWC latent; returns the (B,3,H,W) NCHW image (written directly by the last conv).
+        bf16=True: every 3x3 conv except the final 64->3 one uses bf16 MFMA operands."""
+        return _run_blocks_nhwc(self.blocks, x, taps, last_nchw=True, bf16=bf16)
 
     def forward_host(self, x):
         for blk in self.blocks:

@@ -67,9 +67,16 @@ struct Cfg {
 // x * sigmoid(x) with sigmoid = 1/(1+exp(-x)), the operation order of vqgan_arch.py:18-20
 __device__ __forceinline__ float swishf(float y) { return y * (1.0f / (1.0f + expf(-y))); }
 
-template <int TAPS, int STRIDE, int WM, int WN, int MI, int NI, bool IN_NCHW>
+// BF16 = true: the same schedule on v_mfma_f32_32x32x16_bf16 -- a K slab is 32 channels stored as bf16 (the LDS row is
+// still 64 B + 16 B pad, so every LDS address below is unchanged), activations are rounded to bf16 (RNE) in the gather
+// after the prologue, weights are pre-packed bf16, accumulation stays fp32.  Used for the generator / CFT convs of the
+// bf16 configurations only; the fp32 instantiations are bit-for-bit what they were.
+template <int TAPS, int STRIDE, int WM, int WN, int MI, int NI, bool IN_NCHW, bool BF16 = false>
 __global__ __launch_bounds__(256, 3) void igemm_kernel(const ConvArgs a) {
   using C = Cfg<TAPS, STRIDE, WM, WN, MI, NI>;
+  static_assert(!BF16 || (TAPS == 9 && STRIDE == 1 && !IN_NCHW), "bf16 path: 3x3 stride 1 NHWC only");
+  constexpr int KC = BF16 ? 32 : CF_BK;  // channels per K slab
+  constexpr int AV = BF16 ? 2 : 1;       // float4 fetched per gather item (8 / 4 channels)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const As = smem;
   float* const Bs = smem + C::ABUF * C::NPIX * CF_LDK;
@@ -125,8 +132,8 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const ConvArgs a) {
 
   // Loads are issued UNCONDITIONALLY from a clamped (always valid) address and zeroed by a select afterwards:
   // a load under a divergent branch makes hipcc wait for it on the spot, which would serialise the prefetch.
-  auto load_A = [&](int chunk, f32x4(&ra)[C::APT]) {
-    const int c = chunk * CF_BK + k4 * 4;
+  auto load_A = [&](int chunk, f32x4(&ra)[C::APT * AV]) {
+    const int c = chunk * KC + k4 * (KC / 4);
     if (IN_NCHW) {
       const size_t plane = (size_t)a.hin * a.win;
       const float* base = a.in0 + (size_t)b * a.c0 * plane;
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const ConvArgs a) {
         v[1] = (ok && a.c0 > 1) ? v[1] : 0.f;
         v[2] = (ok && a.c0 > 2) ? v[2] : 0.f;
         v[3] = (ok && a.c0 > 3) ? v[3] : 0.f;
-        ra[j] = v;
+        ra[j * AV] = v;
       }
     } else {
       const bool first = c < a.c0;
@@ -154,42 +161,72 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const ConvArgs a) {
 #pragma unroll
       for (int j = 0; j < C::APT; ++j) {
         const int pj = pix[j] < 0 ? 0 : pix[j];
-        f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)pj * cs + cc);
-        if (pix[j] < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        ra[j] = v;
+#pragma unroll
+        for (int u = 0; u < AV; ++u) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)pj * cs + cc + 4 * u);
+          if (pix[j] < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
+          ra[j * AV + u] = v;
+        }
       }
     }
   };
 
   // zero padding must stay exactly zero: it pads the conv INPUT, i.e. the post-activation tensor
-  auto store_A_mode = [&](int buf, const f32x4(&ra)[C::APT], int chunk, auto mode) {
+  auto store_A_mode = [&](int buf, const f32x4(&ra)[C::APT * AV], int chunk, auto mode) {
     constexpr int PRO = decltype(mode)::value;
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (PRO == CF_PRO_AFFINE || PRO == CF_PRO_AFFINE_SWISH) {
-      const int c = chunk * CF_BK + k4 * 4;
-      sc = *reinterpret_cast<const f32x4*>(a.pro_scale + (size_t)b * a.cin + c);
-      sh = *reinterpret_cast<const f32x4*>(a.pro_shift + (size_t)b * a.cin + c);
+    f32x4 sc[AV], sh[AV];
+#pragma unroll
+    for (int u = 0; u < AV; ++u) {
+      sc[u] = f32x4{1.f, 1.f, 1.f, 1.f};
+      sh[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (PRO == CF_PRO_AFFINE || PRO == CF_PRO_AFFINE_SWISH) {
+        const int c = chunk * KC + k4 * (KC / 4) + 4 * u;
+        sc[u] = *reinterpret_cast<const f32x4*>(a.pro_scale + (size_t)b * a.cin + c);
+        sh[u] = *reinterpret_cast<const f32x4*>(a.pro_shift + (size_t)b * a.cin + c);
+      }
     }
     float* dst = As + buf * (C::NPIX * CF_LDK) + k4 * 4;
 #pragma unroll
     for (int j = 0; j < C::APT; ++j) {
       const int p = (tid >> 2) + 64 * j;
       if ((j + 1) * 64 <= C::NPIX || p < C::NPIX) {
-        f32x4 v = ra[j];
         const bool valid = pix[j] >= 0;
+        f32x4 v[AV];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float y = v[e];
-          if (PRO == CF_PRO_AFFINE) y = y * sc[e] + sh[e];
-          if (PRO == CF_PRO_AFFINE_SWISH) y = swishf(y * sc[e] + sh[e]);
-          if (PRO == CF_PRO_LEAKY) y = y > 0.f ? y : 0.2f * y;
-          v[e] = valid ? y : 0.f;
+        for (int u = 0; u < AV; ++u) {
+          v[u] = ra[j * AV + u];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float y = v[u][e];
+            if (PRO == CF_PRO_AFFINE) y = y * sc[u][e] + sh[u][e];
+            if (PRO == CF_PRO_AFFINE_SWISH) {
+              y = y * sc[u][e] + sh[u][e];
+              y = BF16 ? y * __frcp_rn(1.0f + __expf(-y)) : swishf(y);  // bf16 operands: fast exp/rcp are far below the rounding
+            }
+            if (PRO == CF_PRO_LEAKY) y = y > 0.f ? y : 0.2f * y;
+            v[u][e] = valid ? y : 0.f;
+          }
         }
-        *reinterpret_cast<f32x4*>(dst + p * CF_LDK) = v;
+        if constexpr (BF16) {
+          f32x4 packed;  // 8 channels -> 8 bf16 (round-to-nearest-even) in 16 bytes, channel order preserved
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            // (copy the lanes out first: __builtin_bit_cast on a vector-element lvalue reads element 0)
+            const float flo = v[h >> 1][(h & 1) * 2], fhi = v[h >> 1][(h & 1) * 2 + 1];
+            unsigned lo = __builtin_bit_cast(unsigned, flo);
+            unsigned hi = __builtin_bit_cast(unsigned, fhi);
+            lo += 0x7fffu + ((lo >> 16) & 1u);
+            hi += 0x7fffu + ((hi >> 16) & 1u);
+            packed[h] = __builtin_bit_cast(float, (lo >> 16) | (hi & 0xffff0000u));
+          }
+          *reinterpret_cast<f32x4*>(dst + p * CF_LDK) = packed;
+        } else {
+          *reinterpret_cast<f32x4*>(dst + p * CF_LDK) = v[0];
+        }
       }
     }
   };
-  auto store_A = [&](int buf, const f32x4(&ra)[C::APT], int chunk) {
+  auto store_A = [&](int buf, const f32x4(&ra)[C::APT * AV], int chunk) {
     switch (a.prologue) {
       case CF_PRO_AFFINE: store_A_mode(buf, ra, chunk, std::integral_constant<int, CF_PRO_AFFINE>{}); break;
       case CF_PRO_AFFINE_SWISH: store_A_mode(buf, ra, chunk, std::integral_constant<int, CF_PRO_AFFINE_SWISH>{}); break;
@@ -243,7 +280,7 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const ConvArgs a) {
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
   const int nsteps = a.nchunks * TAPS;
-  f32x4 ra[C::APT];
+  f32x4 ra[C::APT * AV];
   f32x4 rb[C::BPT];
 
   if constexpr (TAPS == 9) {
@@ -264,13 +301,23 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const ConvArgs a) {
         bf[ni] = *reinterpret_cast<const f32x4*>(Bs + bslot * (C::BN * CF_LDK) + b_off[ni] + kg * 8);
     };
     auto mma16 = [&](const f32x4(&af)[MI], const f32x4(&bf)[NI]) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
+      if constexpr (BF16) {
+        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[mi]),
+                                                                  __builtin_bit_cast(bf16x8, bf[ni]), acc[mi][ni], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
+      }
     };
     auto tap_off = [](int tap) { return ((tap / 3) * C::HWD + (tap % 3)) * CF_LDK; };
 
@@ -517,7 +564,7 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const ConvArgs a) {
   }
 }
 
-template <int TAPS, int STRIDE, int WM, int WN, int MI, int NI, bool IN_NCHW>
+template <int TAPS, int STRIDE, int WM, int WN, int MI, int NI, bool IN_NCHW, bool BF16 = false>
 int launch(const ConvArgs& a, hipStream_t stream, int* parts_query) {
   using C = Cfg<TAPS, STRIDE, WM, WN, MI, NI>;
   ConvArgs k = a;
@@ -546,7 +593,7 @@ int launch(const ConvArgs& a, hipStream_t stream, int* parts_query) {
     return CF_OK;
   }
   k.ntn = a.cout_pad / C::BN;
-  auto kern = igemm_kernel<TAPS, STRIDE, WM, WN, MI, NI, IN_NCHW>;
+  auto kern = igemm_kernel<TAPS, STRIDE, WM, WN, MI, NI, IN_NCHW, BF16>;
   constexpr size_t lds = C::LDS_FLOATS * sizeof(float);
   static bool attr_set = false;  // benign race: the attribute call is idempotent
   if (!attr_set) {
@@ -579,7 +626,44 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int cout, int ci
   packed[i] = v;
 }
 
+// bf16 variant: [tap][cin_pad/32][cout_pad][32] bf16 (round-to-nearest-even), two values per 32-bit word.
+__global__ void pack_weight_bf16_kernel(const float* __restrict__ w, int cout, int cin, int taps, int cout_pad, int nchunks,
+                                        unsigned* __restrict__ packed, long total_words) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total_words) return;
+  const int k2 = (int)(i % 16);  // word index inside the 32-channel row
+  long r = i / 16;
+  const int n = (int)(r % cout_pad);
+  r /= cout_pad;
+  const int chunk = (int)(r % nchunks);
+  const int tap = (int)(r / nchunks);
+  unsigned out = 0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int c = chunk * 32 + k2 * 2 + h;
+    float v = 0.f;
+    if (n < cout && c < cin) v = w[((long)n * cin + c) * taps + tap];
+    unsigned u = __builtin_bit_cast(unsigned, v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    out |= (u >> 16) << (16 * h);
+  }
+  packed[i] = out;
+}
+
 }  // namespace
+
+extern "C" int cf_pack_conv_weight_bf16(const float* w, int cout, int cin, int taps, int cout_pad, int cin_pad, void* packed,
+                                        cf_stream_t stream) {
+  CF_REQUIRE(w && packed, "cf_pack_conv_weight_bf16: null pointer");
+  CF_REQUIRE(taps == 9, "cf_pack_conv_weight_bf16: the bf16 path covers 3x3 convolutions (taps=9)");
+  CF_REQUIRE(cin_pad % 32 == 0 && cin_pad >= cin && cout_pad >= cout && cout_pad % 64 == 0,
+             "cf_pack_conv_weight_bf16: bad padding cin %d->%d cout %d->%d", cin, cin_pad, cout, cout_pad);
+  const long words = (long)taps * cin_pad * cout_pad / 2;
+  hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, cout,
+                     cin, taps, cout_pad, cin_pad / 32, reinterpret_cast<unsigned*>(packed), words);
+  CF_CHECK_LAUNCH("cf_pack_conv_weight_bf16");
+  return CF_OK;
+}
 
 extern "C" int64_t cf_packed_weight_elems(int cin_pad, int taps, int cout_pad) {
   return (int64_t)taps * cin_pad * cout_pad;
@@ -628,6 +712,11 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
                d->c0, d->c1);
     CF_REQUIRE(d->c1 == 0 || d->in1, "cf_conv2d: c1 > 0 without in1");
   }
+  if (d->bf16_mfma)
+    CF_REQUIRE(d->taps == 9 && d->stride == 1 && !d->in_nchw && !d->out_nchw && d->c0 % 32 == 0 && d->c1 % 32 == 0 &&
+                   d->cout_pad % 64 == 0 && d->cout % 4 == 0,
+               "cf_conv2d: bf16_mfma covers 3x3 stride-1 NHWC convs with channels %% 32 == 0 (c0=%d c1=%d cout_pad=%d)", d->c0,
+               d->c1, d->cout_pad);
   CF_REQUIRE(d->prologue >= 0 && d->prologue <= 3 && d->epilogue >= 0 && d->epilogue <= 3, "cf_conv2d: bad pro/epilogue");
   if (d->prologue == CF_PRO_AFFINE || d->prologue == CF_PRO_AFFINE_SWISH)
     CF_REQUIRE(d->pro_scale && d->pro_shift, "cf_conv2d: affine prologue without scale/shift tables");
@@ -643,7 +732,7 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
   a.c0 = d->c0;
   a.c1 = d->c1;
   a.cin = d->c0 + d->c1;
-  a.nchunks = (a.cin + CF_BK - 1) / CF_BK;
+  a.nchunks = d->bf16_mfma ? a.cin / 32 : (a.cin + CF_BK - 1) / CF_BK;
   a.batch = d->batch;
   a.hin = d->hin;
   a.win = d->win;
@@ -674,6 +763,11 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
   // on the per-image shape ONLY, never on the batch: tiling (and with it the order of the statistics partials) must be
   // the same for a face whether it is restored alone or inside any batch / shard, so results stay bitwise batch-invariant.
   const bool narrow = cp % 128 == 0 && (long)d->hout * d->wout <= 1024;
+  if (d->bf16_mfma) {
+    if (narrow) return launch<9, 1, 2, 2, 2, 1, false, true>(a, stream, pq);
+    if (cp % 128 == 0) return launch<9, 1, 2, 2, 2, 2, false, true>(a, stream, pq);
+    return launch<9, 1, 4, 1, 2, 2, false, true>(a, stream, pq);  // cout_pad == 64
+  }
   if (d->taps == 9 && d->stride == 1) {
     if (d->in_nchw) {
       CF_REQUIRE(cp == 64, "cf_conv2d: in_nchw path is built for cout_pad 64 (got %d)", cp);

@@ -67,64 +67,45 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
 }
 
 // ---- GroupNorm stage 2: fixed-order sum of partials -> per-(b,c) scale/shift --------------------
-// One workgroup per image.  G fine groups (<= 64) x nparts partials; FT = 256/G' threads cooperate on each fine
-// group (strided, then an ordered LDS sum) so long partial lists (conv-epilogue statistics: up to thousands of
-// tiles) do not serialise on one thread.  gmerge adjacent fine groups then form one normalisation group.
-// scale = gamma*rstd, shift = beta - mean*scale: the same affine form ATen's CPU GroupNorm kernel applies.
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ part, int nparts, int C, int cpg,
-                                                          int gmerge, double inv_count, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float eps,
-                                                          float* __restrict__ scale, float* __restrict__ shift, int ld) {
-  __shared__ double red[256][2];
-  __shared__ double fine[64][2];
-  __shared__ float s_mean[64], s_rstd[64];
-  const int b = blockIdx.x;
-  const int tid = threadIdx.x;
-  const int G = C / cpg;                   // fine groups, <= 64
-  int ft = 1;                              // threads per fine group: largest power of two with G*ft <= 256
-  while (G * ft * 2 <= 256) ft *= 2;
-  const int g = tid / ft, sub = tid % ft;
+// One WAVE per (image, normalisation group): the group's gmerge fine groups x nparts partials are contiguous in the
+// table, so the wave streams them with lane-strided 16-byte loads (conv-epilogue statistics can be thousands of
+// partials per group), reduces with a fixed shuffle butterfly (bitwise reproducible), and its first cpg*gmerge lanes
+// write the channel tables.  scale = gamma*rstd, shift = beta - mean*scale: the affine form ATen's CPU kernel applies.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ part, int batch, int nparts, int C,
+                                                          int cpg, int gmerge, double inv_count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                                          int ld) {
+  const int lane = threadIdx.x & 63;
+  const int GM = C / (cpg * gmerge);
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= batch * GM) return;
+  const int b = w / GM, m = w - b * GM;
+  const int G = C / cpg;
+  const double2* p = reinterpret_cast<const double2*>(part) + ((size_t)b * G + (size_t)m * gmerge) * nparts;
+  const int n = gmerge * nparts;
   double s = 0, q = 0;
-  if (g < G) {
-    const double* p = part + ((size_t)b * G + g) * nparts * 2;
-    for (int j = sub; j < nparts; j += ft) {
-      s += p[2 * j];
-      q += p[2 * j + 1];
-    }
+  for (int j = lane; j < n; j += 64) {
+    const double2 v = p[j];
+    s += v.x;
+    q += v.y;
   }
-  red[tid][0] = s;
-  red[tid][1] = q;
-  __syncthreads();
-  if (tid < G) {
-    double fs = 0, fq = 0;
-    for (int j = 0; j < ft; ++j) {
-      fs += red[tid * ft + j][0];
-      fq += red[tid * ft + j][1];
-    }
-    fine[tid][0] = fs;
-    fine[tid][1] = fq;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    q += __shfl_xor(q, o, 64);
   }
-  __syncthreads();
-  const int GM = G / gmerge;
-  if (tid < GM) {
-    double ms = 0, mq = 0;
-    for (int j = 0; j < gmerge; ++j) {
-      ms += fine[tid * gmerge + j][0];
-      mq += fine[tid * gmerge + j][1];
-    }
-    const double mean = ms * inv_count;
-    double var = mq * inv_count - mean * mean;
-    if (var < 0) var = 0;
-    s_mean[tid] = (float)mean;
-    s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
-  }
-  __syncthreads();
+  const double mean = s * inv_count;
+  double var = q * inv_count - mean * mean;
+  if (var < 0) var = 0;
+  const float fmean = (float)mean;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
   const int cpm = cpg * gmerge;
-  for (int c = tid; c < C; c += 256) {
-    const int m = c / cpm;
-    const float sc = s_rstd[m] * gamma[c];
+  for (int i = lane; i < cpm; i += 64) {
+    const int c = m * cpm + i;
+    const float sc = rstd * gamma[c];
     scale[(size_t)b * ld + c] = sc;
-    shift[(size_t)b * ld + c] = -sc * s_mean[m] + beta[c];
+    shift[(size_t)b * ld + c] = -sc * fmean + beta[c];
   }
 }
 
@@ -194,11 +175,12 @@ extern "C" int cf_groupnorm_finalize(const double* partial, int batch, int parts
                                      int64_t count, const float* gamma, const float* beta, float eps, float* scale,
                                      float* shift, int ld, cf_stream_t stream) {
   CF_REQUIRE(partial && gamma && beta && scale && shift, "cf_groupnorm_finalize: null pointer");
-  CF_REQUIRE(cpg >= 1 && c % cpg == 0 && c / cpg <= 64 && gmerge >= 1 && (c / cpg) % gmerge == 0 && count > 0 &&
+  CF_REQUIRE(cpg >= 1 && c % cpg == 0 && gmerge >= 1 && (c / cpg) % gmerge == 0 && count > 0 &&
                  parts >= 1 && ld >= c,
              "cf_groupnorm_finalize: bad dims (c=%d cpg=%d gmerge=%d parts=%d ld=%d)", c, cpg, gmerge, parts, ld);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, partial, parts, c, cpg, gmerge,
-                     1.0 / (double)count, gamma, beta, eps, scale, shift, ld);
+  const int waves = batch * (c / (cpg * gmerge));
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((waves + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, batch, parts, c,
+                     cpg, gmerge, 1.0 / (double)count, gamma, beta, eps, scale, shift, ld);
   CF_CHECK_LAUNCH("cf_groupnorm_finalize");
   return CF_OK;
 }

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('CF_LIB_PATH') or os.path.join(_PKG, 'libcodeformer_hi
 
 c_float_p = ctypes.c_void_p  # device pointers are passed as integers
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 PRO_NONE, PRO_AFFINE, PRO_AFFINE_SWISH, PRO_LEAKY = 0, 1, 2, 3
 EPI_NONE, EPI_RESIDUAL, EPI_SFT, EPI_GELU = 0, 1, 2, 3
 
@@ -35,7 +35,7 @@ class ConvDesc(ctypes.Structure):
         ('res', ctypes.c_void_p), ('sft_scale', ctypes.c_void_p),
         ('sft_w', ctypes.c_float),
         ('out', ctypes.c_void_p),
-        ('stats_out', ctypes.c_void_p), ('stats_cpg', ctypes.c_int32),
+        ('stats_out', ctypes.c_void_p), ('stats_cpg', ctypes.c_int32), ('bf16_mfma', ctypes.c_int32),
     ]
 
 
@@ -49,6 +49,7 @@ SIGNATURES = {
     'cf_conv2d_stats_parts': (_I, [ctypes.POINTER(ConvDesc)]),
     'cf_pack_conv_weight': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     'cf_packed_weight_elems': (_L, [_I, _I, _I]),
+    'cf_pack_conv_weight_bf16': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     'cf_groupnorm_stats': (_I, [_P, _I, _I, _I, _I, _P, _I, _P]),
     'cf_groupnorm_finalize': (_I, [_P, _I, _I, _I, _I, _I, _L, _P, _P, _F, _P, _P, _I, _P]),
     'cf_layernorm': (_I, [_P, _I, _I, _P, _P, _F, _P, _I, _P, _P, _P]),

@@ -39,11 +39,11 @@ class GNStats:
 class PackedWeight:
     """A conv / linear weight in the kernel layout [tap][cin_pad/16][cout_pad][16] (+ bias)."""
 
-    __slots__ = ('w', 'bias', 'cout', 'cin', 'taps', 'cout_pad', 'cin_pad')
+    __slots__ = ('w', 'bias', 'cout', 'cin', 'taps', 'cout_pad', 'cin_pad', 'bf16')
 
-    def __init__(self, w, bias, cout, cin, taps, cout_pad, cin_pad):
+    def __init__(self, w, bias, cout, cin, taps, cout_pad, cin_pad, bf16=False):
         self.w, self.bias, self.cout, self.cin, self.taps = w, bias, cout, cin, taps
-        self.cout_pad, self.cin_pad = cout_pad, cin_pad
+        self.cout_pad, self.cin_pad, self.bf16 = cout_pad, cin_pad, bf16
 
 
 def _cout_pad(cout):
@@ -54,9 +54,21 @@ def _cout_pad(cout):
     return (cout + 127) // 128 * 128
 
 
-def pack_weight(weight, bias=None):
-    """weight: (cout, cin, 3, 3) | (cout, cin, 1, 1) | (cout, cin) CUDA fp32 -> PackedWeight."""
+def pack_weight(weight, bias=None, bf16=False):
+    """weight: (cout, cin, 3, 3) | (cout, cin, 1, 1) | (cout, cin) CUDA fp32 -> PackedWeight.
+    bf16=True (3x3 only, cin % 32 == 0): bf16 operands for the v_mfma_f32_32x32x16_bf16 path of cf_conv2d."""
     lib = L.load()
+    if bf16:
+        w = _f32(weight.detach()).contiguous()
+        cout, cin = w.shape[0], w.shape[1]
+        if w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or cin % 32:
+            raise ValueError('bf16 packing needs a 3x3 weight with cin % 32 == 0')
+        cout_pad = max(64, _cout_pad(cout))
+        packed = torch.empty(9 * cin * cout_pad, dtype=torch.bfloat16, device=w.device)
+        L.check(lib.cf_pack_conv_weight_bf16(L.ptr(w), cout, cin, 9, cout_pad, cin, L.ptr(packed), L.stream_ptr()),
+                'cf_pack_conv_weight_bf16')
+        b = None if bias is None else _f32(bias.detach()).contiguous().clone()
+        return PackedWeight(packed, b, cout, cin, 9, cout_pad, cin, bf16=True)
     w = _f32(weight.detach()).contiguous()
     cout, cin = w.shape[0], w.shape[1]
     taps = 1
@@ -117,7 +129,7 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
         cout_pad=pw.cout_pad, taps=pw.taps, stride=stride, upsample=int(bool(upsample)), in_nchw=int(bool(in_nchw)),
         out_nchw=int(bool(out_nchw)), prologue=prologue, epilogue=epilogue, pro_scale=L.ptr(scale),
         pro_shift=L.ptr(shift), weight=L.ptr(pw.w), bias=L.ptr(pw.bias), res=L.ptr(res), sft_scale=L.ptr(sft_scale),
-        sft_w=float(sft_w), out=L.ptr(out))
+        sft_w=float(sft_w), out=L.ptr(out), bf16_mfma=int(pw.bf16))
     if emit_stats and not out_nchw and pw.cout % GN_GROUPS == 0 and pw.cout // GN_GROUPS >= 2:
         d.stats_cpg = pw.cout // GN_GROUPS
         parts = lib.cf_conv2d_stats_parts(ctypes.byref(d))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 2
+#define CF_ABI_VERSION 3
 
 typedef void* cf_stream_t; /* hipStream_t */
 
@@ -90,6 +90,10 @@ typedef struct cf_conv_desc {
                              tile part), layout [batch][cout/stats_cpg][parts][2], parts = cf_conv2d_stats_parts(d);
                              feeds cf_groupnorm_finalize so the next GroupNorm never re-reads the tensor */
   int32_t stats_cpg;      /* channels per statistics group: power of two in [2,32] dividing cout */
+  int32_t bf16_mfma;      /* 1: `weight` was packed by cf_pack_conv_weight_bf16 and the contraction runs on
+                             v_mfma_f32_32x32x16_bf16 (activations rounded to bf16 after the prologue, fp32 accumulate,
+                             fp32 tensors in HBM); 3x3 stride-1 NHWC only.  Used by the bf16 configurations for the
+                             generator / CFT convolutions -- never for encoder or Transformer (code indices stay exact) */
 } cf_conv_desc;
 
 int cf_conv2d(const cf_conv_desc* d, cf_stream_t stream);
@@ -101,6 +105,10 @@ int cf_conv2d_stats_parts(const cf_conv_desc* d);
 int cf_pack_conv_weight(const float* w, int cout, int cin, int taps, int cout_pad, int cin_pad,
                         float* packed, cf_stream_t stream);
 int64_t cf_packed_weight_elems(int cin_pad, int taps, int cout_pad);
+/* bf16 layout [tap][cin_pad/32][cout_pad][32] (round-to-nearest-even); cin_pad % 32 == 0, cout_pad % 64 == 0; the buffer
+ * holds cf_packed_weight_elems(cin_pad, taps, cout_pad) bf16 values (half the bytes of the fp32 packing). */
+int cf_pack_conv_weight_bf16(const float* w, int cout, int cin, int taps, int cout_pad, int cin_pad, void* packed,
+                             cf_stream_t stream);
 
 /* ---- GroupNorm statistics (vqgan_arch.py:14-15: 32 groups, eps 1e-6, biased variance) --------
  * Partials are fp64 (sum, sumsq) tables [batch][groups][parts][2] over an NHWC tensor with c channels whose (fine)

@@ -9,6 +9,10 @@ The checks themselves live in tools/gpu_check.py (also runnable stand-alone with
           against outputs of the REFERENCE's modules (tests/golden/blocks_seed7.npz), 2e-5
   net     whole CodeFormer.forward against the reference golden: pixels atol 1e-3 (north-star tolerance),
           logits 1e-4, code indices bit-exact; batch-of-4 == batch-of-1 bitwise; run-to-run bitwise
+  bf16    the bf16-MFMA conv instantiations against fp64 convs of the SAME bf16-rounded operands (2e-4: only the
+          accumulation order differs), and the whole net with precision='bf16' (BASELINE configs 3/5: generator + CFT in
+          bf16, encoder/Transformer/argmax fp32): logits bitwise equal to the fp32 mode, code indices exact, pixels within
+          the stated bf16 gate of the fp32 reference (max|d| <= 0.25, mean|d| <= 0.02 on outputs of std 0.5)
 """
 import importlib.util
 import os
@@ -31,7 +35,7 @@ def chk():
     return m
 
 
-@pytest.mark.parametrize('group', ['basic', 'conv', 'attn', 'blocks', 'net'])
+@pytest.mark.parametrize('group', ['basic', 'conv', 'attn', 'blocks', 'net', 'bf16'])
 def test_group(chk, group):
     chk.RESULTS.clear()
     chk.GROUPS[group]()

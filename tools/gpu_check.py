@@ -379,7 +379,91 @@ def g_net():
     run('timing', t_time)
 
 
-GROUPS = {'basic': g_basic, 'conv': g_conv, 'attn': g_attn, 'blocks': g_blocks, 'net': g_net}
+def g_bf16():
+    """bf16-MFMA conv path: (1) kernel vs an fp64 conv of the SAME bf16-rounded operands (isolates layout/indexing
+    errors from rounding: only accumulation order differs), (2) whole net in precision='bf16' vs the fp32 golden."""
+    def bf(x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    def case(name, cin, cout, H, *, B=2, upsample=False, c_split=None, prologue=PRO_NONE, epilogue=EPI_NONE, seed=0):
+        def body():
+            x = rnd((B, cin, H, H), seed + 1)
+            w = rnd((cout, cin, 3, 3), seed + 2, 1.0 / (cin * 9) ** 0.5)
+            bias = rnd((cout,), seed + 3, 0.1)
+            xd = x.clone()
+            sc = sh = None
+            if prologue == PRO_AFFINE_SWISH:
+                sc, sh = rnd((B, cin), seed + 4, 0.5) + 1.0, rnd((B, cin), seed + 5, 0.3)
+                xd = xd * sc.view(B, cin, 1, 1) + sh.view(B, cin, 1, 1)
+                xd = xd * torch.sigmoid(xd)
+            elif prologue == PRO_LEAKY:
+                xd = F.leaky_relu(xd, 0.2)
+            xd = bf(xd).double()
+            if upsample:
+                xd = F.interpolate(xd, scale_factor=2.0, mode='nearest')
+            ref = F.conv2d(xd, bf(w).double(), bias.double(), padding=1)
+            Ho = ref.shape[2]
+            res = sft = None
+            if epilogue == EPI_RESIDUAL:
+                res = rnd((B, cout, Ho, Ho), seed + 6)
+                ref = ref + res.double()
+            elif epilogue == EPI_SFT:
+                res, sft = rnd((B, cout, Ho, Ho), seed + 6), rnd((B, cout, Ho, Ho), seed + 7)
+                ref = res.double() + 0.7 * (res.double() * sft.double() + ref)
+            pw = ops.pack_weight(w.to(DEV), bias.to(DEV), bf16=True)
+            if c_split:
+                xin, x2 = nhwc(x[:, :c_split]).to(DEV), nhwc(x[:, c_split:]).to(DEV)
+            else:
+                xin, x2 = nhwc(x).to(DEV), None
+            got = ops.conv2d(xin, pw, x2=x2, upsample=upsample, prologue=prologue, scale=None if sc is None else sc.to(DEV),
+                             shift=None if sh is None else sh.to(DEV), epilogue=epilogue,
+                             res=None if res is None else nhwc(res).to(DEV), sft_scale=None if sft is None else nhwc(sft).to(DEV),
+                             sft_w=0.7, emit_stats=True)
+            # swish runs on fast exp/rcp in this mode and is then rounded to bf16: allow a few bf16 ulps of the activations
+            tol = 2e-2 if prologue == PRO_AFFINE_SWISH else 2e-4
+            report(name, nchw(got), ref, tol, 1e-4)
+        run(name, body)
+
+    case('bf16 conv 64->128 @32', 64, 128, 32, seed=10)
+    case('bf16 conv 128->64 @32 (BN64)', 128, 64, 32, seed=20)
+    case('bf16 conv 512->512 @16 (narrow)', 512, 512, 16, seed=30, B=1)
+    case('bf16 conv up 128->128 @16', 128, 128, 16, upsample=True, seed=40)
+    case('bf16 conv cat 64+64->64 @32', 128, 64, 32, c_split=64, seed=50)
+    case('bf16 conv leaky+sft 128->128 @32', 128, 128, 32, prologue=PRO_LEAKY, epilogue=EPI_SFT, seed=60)
+    case('bf16 conv swish+res 256->256 @16', 256, 256, 16, prologue=PRO_AFFINE_SWISH, epilogue=EPI_RESIDUAL, seed=70)
+
+    def t_net():
+        net = build_net().to(DEV)
+        gold = np.load(os.path.join(ROOT, 'tests/golden/restoration_seed0_face0.npz'))
+        x = seeded_input(1).to(DEV)
+        o32 = net(x, w=0.5, adain=True)
+        net.precision = 'bf16'
+        out, logits, lq = net(x, w=0.5, adain=True)
+        report('bf16 mode: logits bitwise equal to the fp32 mode', logits, o32[1], 0)
+        neq = int((net.last_indices.cpu().numpy() != gold['idx']).sum())
+        RESULTS.append(('bf16 mode indices exact', neq == 0, neq))
+        d = (out.cpu().double() - torch.from_numpy(gold['out']).double()).abs()
+        ref = torch.from_numpy(gold['out']).double()
+        print(f'   bf16 mode out vs fp32 reference golden: max|d|={float(d.max()):.4f} mean|d|={float(d.mean()):.5f} '
+              f'rms={float((d ** 2).mean().sqrt()):.5f} ref_std={float(ref.std()):.3f} indices_equal={neq == 0}', flush=True)
+        report('bf16 mode out vs fp32 reference golden (bf16 gate)', out, torch.from_numpy(gold['out']), 0.25)
+        RESULTS.append(('bf16 mode mean error gate', float(d.mean()) < 0.02, float(d.mean())))
+        xb = seeded_input(16).to(DEV)
+        for prec in ('fp32', 'bf16'):
+            net.precision = prec
+            for _ in range(2):
+                net(xb, w=0.5, adain=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                net(xb, w=0.5, adain=True)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 3
+            print(f'   precision={prec}: B=16 {dt * 1e3:.1f} ms/forward = {16 / dt:.1f} faces/s', flush=True)
+    run('bf16 net', t_net)
+
+
+GROUPS = {'bf16': g_bf16, 'basic': g_basic, 'conv': g_conv, 'attn': g_attn, 'blocks': g_blocks, 'net': g_net}
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(GROUPS)

@@ -1,0 +1,34 @@
+#!/bin/bash
+# PMC passes over one bench step (each counter set in its own run, --kernel-trace only): per-kernel averages -> JSON.
+tag=${1:-r01}
+mkdir -p gpurun_out; export TMPDIR=/tmp
+i=0
+for set in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1)); rm -rf /tmp/pb$i
+  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pb$i -o p -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/pmcbench_${tag}_run$i.log 2>&1
+  echo "set $i rc=$?"
+done
+python - "$tag" <<'PY'
+import csv, glob, json, sys, collections
+tag = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+dur = collections.defaultdict(list)
+for f in sorted(glob.glob('/tmp/pb*/**/*counter_collection.csv', recursive=True)):
+    seen = set()
+    for r in csv.DictReader(open(f)):
+        name = r['Kernel_Name']
+        if 'igemm' in name or 'gn_' in name or 'attn' in name or 'layernorm' in name or 'argmax' in name or 'gather' in name:
+            key = name.replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0][:64]
+            agg[key][r['Counter_Name']].append(float(r['Counter_Value']))
+            if (f, r['Dispatch_Id']) not in seen and r['Counter_Name'] in ('GRBM_GUI_ACTIVE', 'FETCH_SIZE'):
+                seen.add((f, r['Dispatch_Id']))
+                dur[key].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+out = {}
+for k, d in agg.items():
+    out[k] = {c: {'launches': len(v), 'mean': sum(v) / len(v), 'sum': sum(v)} for c, v in d.items()}
+    if dur[k]:
+        out[k]['mean_duration_ns'] = sum(dur[k]) / len(dur[k])
+json.dump(out, open(f'gpurun_out/pmc_bench_{tag}.json', 'w'), indent=1, sort_keys=True)
+for k, d in out.items():
+    print(k, {c: (round(v['mean'], 1) if isinstance(v, dict) else round(v)) for c, v in d.items()})
+PY

@@ -23,6 +23,19 @@
 #ifndef CF_ABLATE
 #define CF_ABLATE 0
 #endif
+// tuning knobs explored with tools/ab_variants.sh (defaults = the shipped configuration)
+#ifndef CF_LOADA_TAP
+#define CF_LOADA_TAP 0      // tap at which the next halo patch is prefetched into registers (0..8); 0 = a whole slab of cover (+1 % vs 8)
+#endif
+#ifndef CF_WAVES_PER_SIMD
+#define CF_WAVES_PER_SIMD 3  // __launch_bounds__ occupancy target
+#endif
+#ifndef CF_DEEP_B
+#define CF_DEEP_B 0          // 1: weight slabs are fetched TWO steps before their LDS write (second register set)
+#endif
+#ifndef CF_SETPRIO
+#define CF_SETPRIO 0         // 1: raise wave priority around MFMA blocks
+#endif
 
 namespace {
 
@@ -72,7 +85,7 @@ __device__ __forceinline__ float swishf(float y) { return y * (1.0f / (1.0f + ex
 // after the prologue, weights are pre-packed bf16, accumulation stays fp32.  Used for the generator / CFT convs of the
 // bf16 configurations only; the fp32 instantiations are bit-for-bit what they were.
 template <int TAPS, int STRIDE, int WM, int WN, int MI, int NI, bool IN_NCHW, bool BF16 = false>
-__global__ __launch_bounds__(256, 3) void igemm_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const ConvArgs a) {
   using C = Cfg<TAPS, STRIDE, WM, WN, MI, NI>;
   static_assert(!BF16 || (TAPS == 9 && STRIDE == 1 && !IN_NCHW), "bf16 path: 3x3 stride 1 NHWC only");
   constexpr int KC = BF16 ? 32 : CF_BK;  // channels per K slab
@@ -330,6 +343,10 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const ConvArgs a) {
       store_B(0, rb);
       store_B(1, rb1);
     }
+#if CF_DEEP_B
+    f32x4 rb_old[C::BPT];  // slab for step s+2: fetched during step s-1, written to LDS at the end of step s
+    load_B(2 < nsteps ? 2 : nsteps - 1, rb_old);
+#endif
     __syncthreads();
     f32x4 ax[MI], bx[NI], ay[MI], by[NI];
     read_frags(ax, bx, tap_off(0), 0, 0);
@@ -341,13 +358,20 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const ConvArgs a) {
         const int slot1 = slot == 2 ? 0 : slot + 1;
         const int slot2 = slot1 == 2 ? 0 : slot1 + 1;
 #if CF_ABLATE != 4
+#if CF_DEEP_B
+        load_B(step + 3 < nsteps ? step + 3 : nsteps - 1, rb);  // two steps of latency cover before its LDS write
+#else
         load_B(step + 2 < nsteps ? step + 2 : nsteps - 1, rb);  // clamped: the tail prefetches are harmless re-reads
 #endif
-        if (tap == TAPS - 1) load_A(chunk + 1 < a.nchunks ? chunk + 1 : chunk, ra);
+#endif
+        if (tap == CF_LOADA_TAP) load_A(chunk + 1 < a.nchunks ? chunk + 1 : chunk, ra);
 #if CF_ABLATE != 5
         read_frags(ay, by, tap_off(tap), slot, 1);
 #endif
         __builtin_amdgcn_sched_barrier(0);
+#if CF_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
         mma16(ax, bx);
         __builtin_amdgcn_sched_barrier(0);
 #if CF_ABLATE != 5
@@ -355,9 +379,18 @@ __global__ __launch_bounds__(256, 3) void igemm_kernel(const ConvArgs a) {
 #endif
         __builtin_amdgcn_sched_barrier(0);
         mma16(ay, by);
+#if CF_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #if CF_ABLATE != 4
+#if CF_DEEP_B
+        store_B(slot2, rb_old);
+#pragma unroll
+        for (int j = 0; j < C::BPT; ++j) rb_old[j] = rb[j];
+#else
         store_B(slot2, rb);
+#endif
 #endif
 #if CF_ABLATE != 3
         __syncthreads();

@@ -33,6 +33,9 @@
 #ifndef CF_DEEP_B
 #define CF_DEEP_B 0          // 1: weight slabs are fetched TWO steps before their LDS write (second register set)
 #endif
+#ifndef CF_STAGGER
+#define CF_STAGGER 0         // >0: first-round workgroups start 0, 1/3, 2/3 of CF_STAGGER*~3.4us apart (phase de-sync)
+#endif
 #ifndef CF_SETPRIO
 #define CF_SETPRIO 0         // 1: raise wave priority around MFMA blocks
 #endif
@@ -102,6 +105,12 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Con
   const int half = lane >> 5;
   const int l31 = lane & 31;
 
+#if CF_STAGGER
+  if (blockIdx.x < 768) {
+    const int phase = (blockIdx.x / 256) % 3;
+    for (int i = 0; i < phase * CF_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
   const int nt = blockIdx.x % a.ntn;
   const int mt = blockIdx.x / a.ntn;
   const int n0 = nt * C::BN;

@@ -30,14 +30,8 @@
 #ifndef CF_WAVES_PER_SIMD
 #define CF_WAVES_PER_SIMD 3  // __launch_bounds__ occupancy target
 #endif
-#ifndef CF_DEEP_B
-#define CF_DEEP_B 0          // 1: weight slabs are fetched TWO steps before their LDS write (second register set)
-#endif
-#ifndef CF_STAGGER
-#define CF_STAGGER 0         // >0: first-round workgroups start 0, 1/3, 2/3 of CF_STAGGER*~3.4us apart (phase de-sync)
-#endif
-#ifndef CF_SETPRIO
-#define CF_SETPRIO 0         // 1: raise wave priority around MFMA blocks
+#ifndef CF_INTERLEAVE
+#define CF_INTERLEAVE 1      // 1: MFMA-first weave of fetches / LDS traffic into the MFMA stream (sched_group_barrier)
 #endif
 
 namespace {
@@ -105,12 +99,6 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Con
   const int half = lane >> 5;
   const int l31 = lane & 31;
 
-#if CF_STAGGER
-  if (blockIdx.x < 768) {
-    const int phase = (blockIdx.x / 256) % 3;
-    for (int i = 0; i < phase * CF_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-  }
-#endif
   const int nt = blockIdx.x % a.ntn;
   const int mt = blockIdx.x / a.ntn;
   const int n0 = nt * C::BN;
@@ -352,10 +340,6 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Con
       store_B(0, rb);
       store_B(1, rb1);
     }
-#if CF_DEEP_B
-    f32x4 rb_old[C::BPT];  // slab for step s+2: fetched during step s-1, written to LDS at the end of step s
-    load_B(2 < nsteps ? 2 : nsteps - 1, rb_old);
-#endif
     __syncthreads();
     f32x4 ax[MI], bx[NI], ay[MI], by[NI];
     read_frags(ax, bx, tap_off(0), 0, 0);
@@ -366,41 +350,63 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Con
       for (int tap = 0; tap < TAPS; ++tap, ++step) {
         const int slot1 = slot == 2 ? 0 : slot + 1;
         const int slot2 = slot1 == 2 ? 0 : slot1 + 1;
+        constexpr int NM = BF16 ? MI * NI : MI * NI * 4;                    // MFMAs per half step
+        constexpr int NA = (CF_LOADA_TAP >= 0) ? C::APT * AV : 0;           // halo-patch fetches riding in one step
+        constexpr bool WEAVE = CF_INTERLEAVE && !BF16 && NM >= MI + NI + C::BPT + NA;
+        // ---- first half: fetch slab s+2 (and, once per slab, the next halo patch), read frags(s, k 8..15), MFMA on frags(s, k 0..7)
 #if CF_ABLATE != 4
-#if CF_DEEP_B
-        load_B(step + 3 < nsteps ? step + 3 : nsteps - 1, rb);  // two steps of latency cover before its LDS write
-#else
         load_B(step + 2 < nsteps ? step + 2 : nsteps - 1, rb);  // clamped: the tail prefetches are harmless re-reads
-#endif
 #endif
         if (tap == CF_LOADA_TAP) load_A(chunk + 1 < a.nchunks ? chunk + 1 : chunk, ra);
 #if CF_ABLATE != 5
         read_frags(ay, by, tap_off(tap), slot, 1);
 #endif
-        __builtin_amdgcn_sched_barrier(0);
-#if CF_SETPRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
+        if (!WEAVE) __builtin_amdgcn_sched_barrier(0);  // pin the fetches above the MFMA block (hipcc would sink them)
         mma16(ax, bx);
+        if (WEAVE) {
+          // MFMA-first weave: frags(s, k 0..7) are already in registers, so the block opens with an MFMA right behind the
+          // barrier and every fetch / LDS read issues in the shadow of a 64-cycle MFMA instead of in front of the block.
+#pragma unroll
+          for (int i = 0; i < MI + NI; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+          }
+#pragma unroll
+          for (int i = 0; i < C::BPT + (tap == CF_LOADA_TAP ? NA : 0); ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
+          }
+#pragma unroll
+          for (int i = 0; i < NM - (MI + NI) - C::BPT - (tap == CF_LOADA_TAP ? NA : 0); ++i)
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
+        // ---- second half: read frags(s+1, k 0..7), MFMA on frags(s, k 8..15), LDS write of slab s+2
 #if CF_ABLATE != 5
         if (tap != TAPS - 1) read_frags(ax, bx, tap_off(tap + 1), slot1, 0);
 #endif
-        __builtin_amdgcn_sched_barrier(0);
+        if (!WEAVE) __builtin_amdgcn_sched_barrier(0);
         mma16(ay, by);
-#if CF_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
+        if (!WEAVE) __builtin_amdgcn_sched_barrier(0);
 #if CF_ABLATE != 4
-#if CF_DEEP_B
-        store_B(slot2, rb_old);
-#pragma unroll
-        for (int j = 0; j < C::BPT; ++j) rb_old[j] = rb[j];
-#else
         store_B(slot2, rb);
 #endif
-#endif
+        if (WEAVE) {
+#pragma unroll
+          for (int i = 0; i < (tap != TAPS - 1 ? MI + NI : 0); ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+#pragma unroll
+          for (int i = 0; i < NM - (tap != TAPS - 1 ? MI + NI : 0) - C::BPT; ++i)
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+          for (int i = 0; i < C::BPT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write (waits for the slab fetched in the first half)
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #if CF_ABLATE != 3
         __syncthreads();
 #endif

@@ -13,6 +13,10 @@ import torch
 import torch.distributed as dist
 
 
+# 'gather' (one collective to the destination rank) unless the backend lacks it, then one all_gather (set once, by all ranks)
+_GATHER_IMPL = [os.environ.get('CODEFORMER_GATHER', 'gather')]
+
+
 def env_rank_world():
     return int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('LOCAL_RANK', 0))
 
@@ -73,15 +77,27 @@ def gather_faces(local, total, dst=0, group=None):
         send = torch.cat([local, pad], dim=0)
     else:
         send = local.contiguous()
-    if rank == dst:
+    if _GATHER_IMPL[0] == 'gather':
+        try:
+            if rank == dst:
+                slab = torch.empty((world, nmax) + tuple(tail), dtype=local.dtype, device=local.device)
+                dist.gather(send, gather_list=list(slab.unbind(0)), dst=dst, group=group)
+            else:
+                dist.gather(send, gather_list=None, dst=dst, group=group)
+                return None
+        except (NotImplementedError, RuntimeError) as e:  # a backend without gather: every rank takes the same branch
+            if 'gather' not in str(e).lower() and not isinstance(e, NotImplementedError):
+                raise
+            _GATHER_IMPL[0] = 'all_gather'
+    if _GATHER_IMPL[0] == 'all_gather':
         slab = torch.empty((world, nmax) + tuple(tail), dtype=local.dtype, device=local.device)
-        dist.gather(send, gather_list=list(slab.unbind(0)), dst=dst, group=group)
-        parts = [slab[r, :bounds[r + 1] - bounds[r]] for r in range(world)]
-        if all(p.shape[0] == nmax for p in parts):
-            return slab.view((world * nmax,) + tuple(tail))
-        return torch.cat(parts, dim=0)
-    dist.gather(send, gather_list=None, dst=dst, group=group)
-    return None
+        dist.all_gather_into_tensor(slab.view((world * nmax,) + tuple(tail)), send, group=group)
+        if rank != dst:
+            return None
+    parts = [slab[r, :bounds[r + 1] - bounds[r]] for r in range(world)]
+    if all(p.shape[0] == nmax for p in parts):
+        return slab.view((world * nmax,) + tuple(tail))
+    return torch.cat(parts, dim=0)
 
 
 @torch.no_grad()

@@ -95,3 +95,44 @@ def test_inpainting_config(chk):
     assert float((logits.cpu() - torch.from_numpy(g['logits'])).abs().max()) <= 1e-4
     assert np.array_equal(net.last_indices.cpu().numpy(), g['idx'])
     assert float((out.cpu()[:, :, ::4, ::4] - torch.from_numpy(g['out_sub'])).abs().max()) <= 1e-3
+
+
+# ---- size-independent properties at BASELINE config-2 sizes (the CPU oracle is too slow there) -------------------------
+def test_full_size_batch16_is_bitwise_batch_invariant(chk):
+    """Config 2 shape (16 faces): every face of the batch equals the same face restored alone / in a 2-rank shard."""
+    import torch
+    from oracle.synth import seeded_input
+    net = chk.build_net().cuda()
+    x = seeded_input(16).cuda()
+    full = net(x, w=0.5, adain=True)
+    for i in (0, 7, 15):
+        one = net(x[i:i + 1].contiguous(), w=0.5, adain=True)
+        assert torch.equal(full[0][i:i + 1], one[0]) and torch.equal(full[1][i:i + 1], one[1])
+    half = net(x[8:].contiguous(), w=0.5, adain=True)           # what rank 1 of a 2-GPU run computes
+    assert torch.equal(full[0][8:], half[0])
+    assert torch.isfinite(full[0]).all()
+
+
+def test_full_size_conv_linearity_and_layout_round_trip(chk):
+    import torch
+    from codeformer_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x, y = torch.randn(2, 256, 256, 128, generator=g).cuda(), torch.randn(2, 256, 256, 128, generator=g).cuda()
+    pw = ops.pack_weight((torch.randn(128, 128, 3, 3, generator=g) * 0.03).cuda(), None)
+    lhs = ops.conv2d(1.5 * x - 0.5 * y, pw)
+    rhs = 1.5 * ops.conv2d(x, pw) - 0.5 * ops.conv2d(y, pw)
+    assert float((lhs - rhs).abs().max()) < 2e-5 * max(1.0, float(rhs.abs().max()))
+    assert torch.equal(ops.to_nhwc(ops.to_nchw(x)), x)
+
+
+def test_shape_errors_are_raised_not_swallowed(chk):
+    import torch
+    net = chk.build_net().cuda()
+    with pytest.raises(ValueError, match='512x512'):
+        net(torch.zeros(1, 3, 256, 256, device='cuda'), w=0.5)
+    net.precision = 'fp8'
+    with pytest.raises(ValueError, match='precision'):
+        net(torch.zeros(1, 3, 512, 512, device='cuda'), w=0.5)
+    from codeformer_amd import ops
+    with pytest.raises(RuntimeError, match='cf_conv2d'):
+        ops.conv2d(torch.zeros(1, 20, 20, 64, device='cuda'), ops.pack_weight(torch.zeros(64, 64, 3, 3, device='cuda')))

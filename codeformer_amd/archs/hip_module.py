@@ -29,6 +29,14 @@ class HipModule(nn.Module):
         key = (name if isinstance(name, str) else id(conv), bool(bf16))
         return self._packed(key, lambda: ops.pack_weight(conv.weight, conv.bias, bf16=bf16), conv.weight, conv.bias)
 
+    def invalidate_packed_weights(self):
+        """Drop every cached packed weight of this module tree.  The cache already follows load_state_dict / .to() /
+        optimizer steps (parameter version + storage pointer); call this after editing `param.data` in place, which
+        PyTorch does not version."""
+        for m in self.modules():
+            if isinstance(m, HipModule):
+                m.__dict__.pop('_hip_cache', None)
+
     def forward_nhwc(self, x):  # pragma: no cover - abstract
         raise NotImplementedError
 

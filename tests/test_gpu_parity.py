@@ -136,3 +136,27 @@ def test_shape_errors_are_raised_not_swallowed(chk):
     from codeformer_amd import ops
     with pytest.raises(RuntimeError, match='cf_conv2d'):
         ops.conv2d(torch.zeros(1, 20, 20, 64, device='cuda'), ops.pack_weight(torch.zeros(64, 64, 3, 3, device='cuda')))
+
+
+def test_packed_weight_cache_follows_the_parameters(chk):
+    """load_state_dict / in-place parameter updates must reach the kernels (the packed copies are a cache)."""
+    import torch
+    from oracle.synth import seeded_input
+    net = chk.build_net().cuda()
+    x = seeded_input(1).cuda()
+    a = net(x, w=0.5, adain=True)[0].clone()
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    sd2 = dict(sd)
+    sd2['generator.blocks.22.conv2.weight'] = sd['generator.blocks.22.conv2.weight'] * 1.5
+    net.load_state_dict(sd2)
+    b = net(x, w=0.5, adain=True)[0].clone()
+    assert not torch.equal(a, b)
+    net.load_state_dict(sd)
+    assert torch.equal(net(x, w=0.5, adain=True)[0], a)
+    with torch.no_grad():
+        net.generator.blocks[24].bias.add_(0.25)          # versioned in-place op
+    c = net(x, w=0.5, adain=True)[0]
+    assert float((c - a - 0.25).abs().max()) < 1e-5
+    net.generator.blocks[24].bias.data.sub_(0.25)          # un-versioned edit -> explicit invalidation
+    net.invalidate_packed_weights()
+    assert torch.equal(net(x, w=0.5, adain=True)[0], a)

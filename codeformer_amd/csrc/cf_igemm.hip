@@ -30,6 +30,12 @@
 #ifndef CF_WAVES_PER_SIMD
 #define CF_WAVES_PER_SIMD 3  // __launch_bounds__ occupancy target
 #endif
+#ifndef CF_EPI_WAVESYNC
+#define CF_EPI_WAVESYNC 1    // 1: the epilogue transpose is wave-private (no workgroup barriers, operand loads issued first)
+#endif
+#ifndef CF_XCD_SWIZZLE
+#define CF_XCD_SWIZZLE 1     // 1: remap workgroup ids so each XCD (private L2) owns a contiguous run of tiles (shared halos / weights)
+#endif
 #ifndef CF_INTERLEAVE
 #define CF_INTERLEAVE 1      // 1: MFMA-first weave of fetches / LDS traffic into the MFMA stream (sched_group_barrier)
 #endif
@@ -99,8 +105,17 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Con
   const int half = lane >> 5;
   const int l31 = lane & 31;
 
-  const int nt = blockIdx.x % a.ntn;
-  const int mt = blockIdx.x / a.ntn;
+  // Workgroup b runs on XCD b % 8 (observed dispatch order; speed only, never correctness).  Give every XCD a contiguous
+  // run of tile ids so neighbouring tiles -- which share halo rows/columns and the weight slabs -- hit the same L2.
+  int bid = blockIdx.x;
+#if CF_XCD_SWIZZLE
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;  // bijective for any grid size
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+#endif
+  const int nt = bid % a.ntn;
+  const int mt = bid / a.ntn;
   const int n0 = nt * C::BN;
   int b, y0 = 0, x0 = 0, m0 = 0;
   if (TAPS == 9) {
@@ -440,6 +455,7 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Con
       for (int ni = 0; ni < NI; ++ni) bp[ni] = Bs + bbuf * (C::BN * CF_LDK) + b_off[ni];
       cf_mma_slab<MI, NI>(acc, ap, bp);
     }
+    __syncthreads();  // every wave is done reading the last slabs before any wave reuses LDS in its epilogue
   }
 
   // ---- epilogue ------------------------------------------------------------------------------------------
@@ -464,33 +480,66 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Con
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-      __syncthreads();  // main loop (or the previous half) is done with this LDS region
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) stage[cf_acc_row(r, lane) * LDW + ni * 32 + l31] = acc[mi][ni][r];
-      __syncthreads();
+      size_t offs[PASSES];
 #pragma unroll
       for (int p = 0; p < PASSES; ++p) {
-        const int trow = p * RPP + rl;
-        f32x4 v = *reinterpret_cast<const f32x4*>(stage + trow * LDW + cq * 4);
-        const int row = wm * (MI * 32) + mi * 32 + trow;
+        const int row = wm * (MI * 32) + mi * 32 + p * RPP + rl;
         size_t pixel;
         if (TAPS == 9)
           pixel = ((size_t)b * a.hout + (y0 + (row >> 4))) * a.wout + (x0 + (row & 15));
         else
           pixel = (size_t)m0 + row;
-        const size_t o = pixel * a.cout + n;
+        offs[p] = pixel * a.cout + n;
+      }
+#if CF_EPI_WAVESYNC
+      // Residual / SFT operands are requested BEFORE the transpose so their HBM latency overlaps it.  The transpose
+      // buffer is private to the wave (LDS operations of one wave complete in issue order), so no workgroup barrier is
+      // needed: the main loop's closing barrier already retired every read of this LDS region.
+      f32x4 r0[PASSES], r1[PASSES];
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p) {
+        r0[p] = r1[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (nvalid && (EPI == CF_EPI_RESIDUAL || EPI == CF_EPI_SFT)) r0[p] = *reinterpret_cast<const f32x4*>(a.res + offs[p]);
+        if (nvalid && EPI == CF_EPI_SFT) r1[p] = *reinterpret_cast<const f32x4*>(a.sft_scale + offs[p]);
+      }
+      __builtin_amdgcn_wave_barrier();
+#else
+      __syncthreads();  // main loop (or the previous half) is done with this LDS region
+#endif
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stage[cf_acc_row(r, lane) * LDW + ni * 32 + l31] = acc[mi][ni][r];
+#if CF_EPI_WAVESYNC
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
+      __syncthreads();
+#endif
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p) {
+        const int trow = p * RPP + rl;
+        f32x4 v = *reinterpret_cast<const f32x4*>(stage + trow * LDW + cq * 4);
+        const size_t o = offs[p];
         if (nvalid) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += bias4[e];
           if (EPI == CF_EPI_RESIDUAL) {
+#if CF_EPI_WAVESYNC
+            const f32x4 rr = r0[p];
+#else
             const f32x4 rr = *reinterpret_cast<const f32x4*>(a.res + o);
+#endif
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += rr[e];
           } else if (EPI == CF_EPI_SFT) {
+#if CF_EPI_WAVESYNC
+            const f32x4 dec = r0[p], sc = r1[p];
+#else
             const f32x4 dec = *reinterpret_cast<const f32x4*>(a.res + o);
             const f32x4 sc = *reinterpret_cast<const f32x4*>(a.sft_scale + o);
+#endif
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = dec[e] + a.sft_w * (dec[e] * sc[e] + v[e]);
           } else if (EPI == CF_EPI_GELU) {

@@ -153,10 +153,11 @@ def test_packed_weight_cache_follows_the_parameters(chk):
     assert not torch.equal(a, b)
     net.load_state_dict(sd)
     assert torch.equal(net(x, w=0.5, adain=True)[0], a)
+    bias0 = net.generator.blocks[24].bias.detach().clone()
     with torch.no_grad():
         net.generator.blocks[24].bias.add_(0.25)          # versioned in-place op
     c = net(x, w=0.5, adain=True)[0]
     assert float((c - a - 0.25).abs().max()) < 1e-5
-    net.generator.blocks[24].bias.data.sub_(0.25)          # un-versioned edit -> explicit invalidation
+    net.generator.blocks[24].bias.data.copy_(bias0)        # un-versioned edit (.data) -> explicit invalidation
     net.invalidate_packed_weights()
     assert torch.equal(net(x, w=0.5, adain=True)[0], a)

@@ -21,7 +21,7 @@ from torch import nn
 from .. import ops
 from ..ops import EPI_GELU, EPI_RESIDUAL, EPI_SFT, PRO_LEAKY
 from ..utils.registry import ARCH_REGISTRY
-from .hip_module import HipModule
+from .hip_module import PACK_EPOCH, HipModule
 from .vqgan_arch import ResBlock, VQAutoEncoder
 
 
@@ -161,6 +161,11 @@ class CodeFormer(VQAutoEncoder):
         # 'fp32': everything on exact fp32 MFMA.  'bf16' (BASELINE configs 3/5): generator + CFT 3x3 convs on bf16 MFMA
         # operands with fp32 accumulate; encoder, Transformer and the code argmax stay fp32 so the indices stay exact.
         self.precision = os.environ.get('CODEFORMER_HIP_PRECISION', 'fp32')
+        # Optional HIP-graph replay of the whole forward (one graph per input shape / w / flags): takes the ~250 host launches
+        # per call off the critical path.  Measured: no gain at B=1..16 on an otherwise idle host (the kernels, not the launches,
+        # bound even B=1), so it is off by default; useful when the host thread is busy (decode / encode of PNGs).
+        self.use_hip_graphs = os.environ.get('CODEFORMER_HIP_GRAPHS', '0') == '1'
+        self._graphs = {}
         self.connect_list = connect_list
         self.n_layers = n_layers
         self.n_head = n_head
@@ -256,8 +261,44 @@ class CodeFormer(VQAutoEncoder):
                 x = self.fuse_convs_dict[f](enc_feat[f].detach(), x, w)
         return x, logits, lq_feat
 
+    def _forward_graphed(self, x, w, code_only, adain):
+        """Capture-once / replay-many execution of _forward_hip on the current stream.  Outputs are copies, so callers may
+        keep them across calls.  A graph is re-captured when any packed weight was rebuilt since its capture."""
+        key = (tuple(x.shape), float(w), bool(code_only), bool(adain), self.precision, str(x.device))
+        ent = self._graphs.get(key)
+        if ent is None or ent['epoch'] != PACK_EPOCH[0]:
+            static_x = x.float().contiguous().clone()
+            for _ in range(2):                      # warm-up: packs weights, sets kernel attributes, primes the allocator
+                self._forward_hip(static_x, w, code_only, adain)
+            torch.cuda.synchronize(x.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                outs = self._forward_hip(static_x, w, code_only, adain)
+            ent = {'graph': graph, 'x': static_x, 'outs': outs, 'epoch': PACK_EPOCH[0], 'idx': getattr(self, 'last_indices', None)}
+            self._graphs[key] = ent
+        ent['x'].copy_(x)
+        ent['graph'].replay()
+        if ent['idx'] is not None:
+            self.last_indices = ent['idx']
+        return tuple(o.clone() for o in ent['outs'])
+
+    def load_state_dict(self, *args, **kwargs):
+        self._graphs.clear()                       # captured graphs point at the old packed weights
+        return super().load_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):         # .to() / .cuda() / .float(): parameters move, graphs are stale
+        if getattr(self, '_graphs', None):
+            self._graphs.clear()
+        return super()._apply(fn, *args, **kwargs)
+
+    def invalidate_packed_weights(self):
+        self._graphs.clear()
+        super().invalidate_packed_weights()
+
     def forward(self, x, w=0, detach_16=True, code_only=False, adain=False):
         if x.is_cuda:
             with torch.no_grad():
+                if self.use_hip_graphs and ops.PROFILE is None:
+                    return self._forward_graphed(x, w, code_only, adain)
                 return self._forward_hip(x, w, code_only, adain)
         return self._forward_host(x, w, detach_16, code_only, adain)

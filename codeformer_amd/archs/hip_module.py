@@ -12,6 +12,11 @@ from torch import nn
 from .. import ops
 
 
+# Bumped whenever any packed weight is (re)built: captured HIP graphs hold raw pointers to the packed buffers, so a graph
+# recorded under an older epoch must be re-captured.
+PACK_EPOCH = [0]
+
+
 class HipModule(nn.Module):
 
     def _packed(self, key, build, *params):
@@ -22,6 +27,7 @@ class HipModule(nn.Module):
         if ent is None or ent[0] != sig:
             ent = (sig, build())
             cache[key] = ent
+            PACK_EPOCH[0] += 1
         return ent[1]
 
     def _pw_conv(self, name, bf16=False):
@@ -36,6 +42,7 @@ class HipModule(nn.Module):
         for m in self.modules():
             if isinstance(m, HipModule):
                 m.__dict__.pop('_hip_cache', None)
+        PACK_EPOCH[0] += 1
 
     def forward_nhwc(self, x):  # pragma: no cover - abstract
         raise NotImplementedError

@@ -161,3 +161,25 @@ def test_packed_weight_cache_follows_the_parameters(chk):
     net.generator.blocks[24].bias.data.copy_(bias0)        # un-versioned edit (.data) -> explicit invalidation
     net.invalidate_packed_weights()
     assert torch.equal(net(x, w=0.5, adain=True)[0], a)
+
+
+def test_hip_graph_replay_is_bitwise_eager(chk):
+    """use_hip_graphs: capture once, replay; identical bits to the eager path, survives a weight reload."""
+    import torch
+    from oracle.synth import seeded_input
+    net = chk.build_net().cuda()
+    x = seeded_input(2).cuda()
+    eager = [t.clone() for t in net(x, w=0.5, adain=True)]
+    net.use_hip_graphs = True
+    for _ in range(2):                                   # first call captures, second replays
+        got = net(x, w=0.5, adain=True)
+        assert all(torch.equal(a, b) for a, b in zip(got, eager))
+    y = seeded_input(2, seed=99).cuda()
+    net.use_hip_graphs = False
+    eager_y = [t.clone() for t in net(y, w=0.5, adain=True)]
+    net.use_hip_graphs = True
+    assert all(torch.equal(a, b) for a, b in zip(net(y, w=0.5, adain=True), eager_y))   # same graph, new input
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    sd['generator.blocks.24.bias'] = sd['generator.blocks.24.bias'] + 1.0
+    net.load_state_dict(sd)                                                             # repack -> recapture
+    assert float((net(y, w=0.5, adain=True)[0] - eager_y[0] - 1.0).abs().max()) < 1e-5

@@ -378,6 +378,23 @@ def g_net():
             print(f'   B={B}: {dt * 1e3:.1f} ms/forward = {B / dt:.1f} faces/s  ({809.77e9 * B / dt / 1e12:.1f} TFLOP/s fp32)', flush=True)
     run('timing', t_time)
 
+    def t_graph_time():
+        net.use_hip_graphs = True
+        for B in (1, 4, 16):
+            xb = seeded_input(16)[:B].to(DEV).contiguous()
+            for _ in range(2):
+                net(xb, w=0.5, adain=True)
+            torch.cuda.synchronize()
+            n = 5
+            t0 = time.perf_counter()
+            for _ in range(n):
+                net(xb, w=0.5, adain=True)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
+            print(f'   hip-graph replay B={B}: {dt * 1e3:.1f} ms/forward = {B / dt:.1f} faces/s', flush=True)
+        net.use_hip_graphs = False
+    run('graph timing', t_graph_time)
+
 
 def g_bf16():
     """bf16-MFMA conv path: (1) kernel vs an fp64 conv of the SAME bf16-rounded operands (isolates layout/indexing

@@ -661,6 +661,83 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Con
   }
 }
 
+// ---- 3x3 convolution with <= 4 output channels written NCHW (the network's last conv, 64 -> 3 @ 512x512) -----------
+// A 3-wide N would waste 29/32 of every MFMA tile (the MFMA instantiation spends 1.24 ms per 16 faces on padding), and the
+// layer is HBM-bound anyway (reads 64 channels, writes 3): one thread per output pixel on the vector ALU, the same LDS
+// halo patch + prologue as the MFMA kernel, weights fetched through the scalar cache (wave-uniform addresses), coalesced
+// per-plane NCHW stores.  Accumulation order: slab, tap, channel (a plain fp32 FMA chain).
+__global__ __launch_bounds__(256) void conv3x3_few_cout_kernel(const ConvArgs a) {
+  constexpr int TH = 16, TW = 16, HWD = TW + 2, NPIX = (TH + 2) * HWD, APT = (NPIX * 4 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float As[NPIX * CF_LDK];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / a.tiles_per_img;
+  const int r = blockIdx.x - b * a.tiles_per_img;
+  const int ty = r / a.tiles_x;
+  const int y0 = ty * TH, x0 = (r - ty * a.tiles_x) * TW;
+  const int k4 = tid & 3;
+  int pix[APT];
+#pragma unroll
+  for (int j = 0; j < APT; ++j) {
+    const int p = (tid >> 2) + 64 * j;
+    int v = -1;
+    if (p < NPIX) {
+      const int hy = p / HWD, hx = p - hy * HWD;
+      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+      if (iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win) v = (b * a.hin + iy) * a.win + ix;
+    }
+    pix[j] = v;
+  }
+  const int py = tid >> 4, px = tid & 15;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+    const int c = chunk * CF_BK + k4 * 4;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (a.prologue == CF_PRO_AFFINE || a.prologue == CF_PRO_AFFINE_SWISH) {
+      sc = *reinterpret_cast<const f32x4*>(a.pro_scale + (size_t)b * a.cin + c);
+      sh = *reinterpret_cast<const f32x4*>(a.pro_shift + (size_t)b * a.cin + c);
+    }
+#pragma unroll
+    for (int j = 0; j < APT; ++j) {
+      const int p = (tid >> 2) + 64 * j;
+      if (p < NPIX) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (pix[j] >= 0) {
+          v = *reinterpret_cast<const f32x4*>(a.in0 + (size_t)pix[j] * a.c0 + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float y = v[e] * sc[e] + sh[e];
+            if (a.prologue == CF_PRO_AFFINE_SWISH) y = swishf(y);
+            if (a.prologue == CF_PRO_LEAKY) y = v[e] > 0.f ? v[e] : 0.2f * v[e];
+            v[e] = y;
+          }
+        }
+        *reinterpret_cast<f32x4*>(As + p * CF_LDK + k4 * 4) = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll 1  // one tap's 64 weights fit the scalar registers; unrolling all nine spills them
+    for (int tap = 0; tap < 9; ++tap) {
+      const float* ap = As + ((py + tap / 3) * HWD + px + tap % 3) * CF_LDK;
+      const float* wp = a.weight + (size_t)(tap * a.nchunks + chunk) * a.cout_pad * CF_BK;  // [cout_pad][16], wave-uniform
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + q * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int co = 0; co < 4; ++co)  // rows >= cout of the packed weight are zero padding: no branch needed
+            acc[co] = fmaf(av[e], wp[co * CF_BK + q * 4 + e], acc[co]);
+      }
+    }
+    __syncthreads();
+  }
+  const int oy = y0 + py, ox = x0 + px;
+#pragma unroll
+  for (int co = 0; co < 4; ++co)
+    if (co < a.cout)
+      a.out[(((size_t)b * a.cout + co) * a.hout + oy) * a.wout + ox] = acc[co] + (a.bias ? a.bias[co] : 0.f);
+}
+
 template <int TAPS, int STRIDE, int WM, int WN, int MI, int NI, bool IN_NCHW, bool BF16 = false>
 int launch(const ConvArgs& a, hipStream_t stream, int* parts_query) {
   using C = Cfg<TAPS, STRIDE, WM, WN, MI, NI>;
@@ -873,6 +950,13 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
     if (narrow) return launch<9, 1, 2, 2, 2, 1, false>(a, stream, pq);
     if (cp % 128 == 0) return launch<9, 1, 2, 2, 2, 2, false>(a, stream, pq);
     if (cp == 64) return launch<9, 1, 4, 1, 2, 2, false>(a, stream, pq);
+    if (d->out_nchw && d->cout <= 4 && !d->upsample && d->c1 == 0 && d->hout % 16 == 0 && d->wout % 16 == 0 && !pq) {
+      a.tiles_x = d->wout / 16;
+      a.tiles_per_img = a.tiles_x * (d->hout / 16);
+      hipLaunchKernelGGL(conv3x3_few_cout_kernel, dim3(a.tiles_per_img * d->batch), dim3(256), 0, stream, a);
+      CF_CHECK_LAUNCH("cf_conv2d");
+      return CF_OK;
+    }
     if (cp == 32) return launch<9, 1, 4, 1, 2, 1, false>(a, stream, pq);
   } else if (d->taps == 9 && d->stride == 2) {
     if (cp % 128 == 0) return launch<9, 2, 2, 2, 2, 2, false>(a, stream, pq);

@@ -30,10 +30,11 @@ class HipModule(nn.Module):
             PACK_EPOCH[0] += 1
         return ent[1]
 
-    def _pw_conv(self, name, bf16=False):
+    def _pw_conv(self, name, bf16=False, up2x=False):
         conv = getattr(self, name) if isinstance(name, str) else name
-        key = (name if isinstance(name, str) else id(conv), bool(bf16))
-        return self._packed(key, lambda: ops.pack_weight(conv.weight, conv.bias, bf16=bf16), conv.weight, conv.bias)
+        key = (name if isinstance(name, str) else id(conv), bool(bf16), bool(up2x))
+        return self._packed(key, lambda: ops.pack_weight(conv.weight, conv.bias, bf16=bf16, up2x=up2x), conv.weight,
+                            conv.bias)
 
     def invalidate_packed_weights(self):
         """Drop every cached packed weight of this module tree.  The cache already follows load_state_dict / .to() /

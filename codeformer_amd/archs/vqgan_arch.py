@@ -116,14 +116,15 @@ class Downsample(HipModule):
 
 
 class Upsample(HipModule):
-    """nearest x2 + 3x3 conv (basicsr/archs/vqgan_arch.py:129-138); the upsample is `src = dst >> 1` in the gather."""
+    """nearest x2 + 3x3 conv (basicsr/archs/vqgan_arch.py:129-138).  GPU: the upsampled tensor never exists -- every output
+    parity class (oy&1, ox&1) is a 2x2 convolution of the SOURCE with taps pre-summed at pack time (2.25x fewer MACs)."""
 
     def __init__(self, in_channels):
         super().__init__()
         self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
 
     def forward_nhwc(self, x, bf16=False):
-        return ops.conv2d(x, self._pw_conv('conv', bf16), upsample=True, emit_stats=True)
+        return ops.conv2d(x, self._pw_conv('conv', bf16, up2x=True), upsample=True, emit_stats=True)
 
     def forward_host(self, x):
         return self.conv(F.interpolate(x, scale_factor=2.0, mode='nearest'))

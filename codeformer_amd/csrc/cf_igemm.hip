@@ -68,13 +68,15 @@ struct Cfg {
   static constexpr int BN = WN * NI * 32;
   static constexpr int TW = 16;
   static constexpr int TH = BM / 16;
-  static constexpr int HH = (TAPS == 9) ? (TH - 1) * STRIDE + 3 : TH;   // halo patch rows
-  static constexpr int HWD = (TAPS == 9) ? (TW - 1) * STRIDE + 3 : TW;  // halo patch cols
-  static constexpr int NPIX = (TAPS == 9) ? HH * HWD : BM;
+  // TAPS: 9 = 3x3 ; 4 = nearest-x2 + 3x3 folded into four 2x2 sub-pixel convolutions (one output parity class per
+  // workgroup, taps pre-summed at pack time: 4 instead of 9 MACs per weight) ; 1 = 1x1 / Linear
+  static constexpr int HH = (TAPS == 9) ? (TH - 1) * STRIDE + 3 : (TAPS == 4 ? TH + 1 : TH);   // halo patch rows
+  static constexpr int HWD = (TAPS == 9) ? (TW - 1) * STRIDE + 3 : (TAPS == 4 ? TW + 1 : TW);  // halo patch cols
+  static constexpr int NPIX = (TAPS > 1) ? HH * HWD : BM;
   static constexpr int ABUF = (TAPS == 1) ? 2 : 1;
   static constexpr int APT = (NPIX * 4 + 255) / 256;  // float4 gather items per thread
   static constexpr int BPT = (BN * 4 + 255) / 256;    // float4 weight items per thread
-  static constexpr int BBUF = (TAPS == 9) ? 3 : 2;    // weight-slab ring depth in LDS
+  static constexpr int BBUF = (TAPS > 1) ? 3 : 2;    // weight-slab ring depth in LDS
   static constexpr int LDS_MAIN = ABUF * NPIX * CF_LDK + BBUF * BN * CF_LDK;
   static constexpr int LDS_EPI = 4 * 32 * (NI * 32 + 4);  // per-wave 32-row transpose buffers of the epilogue
   static constexpr int LDS_FLOATS = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
@@ -90,7 +92,7 @@ __device__ __forceinline__ float swishf(float y) { return y * (1.0f / (1.0f + ex
 template <int TAPS, int STRIDE, int WM, int WN, int MI, int NI, bool IN_NCHW, bool BF16 = false>
 __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const ConvArgs a) {
   using C = Cfg<TAPS, STRIDE, WM, WN, MI, NI>;
-  static_assert(!BF16 || (TAPS == 9 && STRIDE == 1 && !IN_NCHW), "bf16 path: 3x3 stride 1 NHWC only");
+  static_assert(!BF16 || (TAPS > 1 && STRIDE == 1 && !IN_NCHW), "bf16 path: 3x3 stride 1 NHWC only");
   constexpr int KC = BF16 ? 32 : CF_BK;  // channels per K slab
   constexpr int AV = BF16 ? 2 : 1;       // float4 fetched per gather item (8 / 4 channels)
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -118,9 +120,17 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Con
   const int mt = bid / a.ntn;
   const int n0 = nt * C::BN;
   int b, y0 = 0, x0 = 0, m0 = 0;
-  if (TAPS == 9) {
+  int sub_y = 0, sub_x = 0;  // TAPS == 4: output parity class (oy & 1, ox & 1) of this workgroup; y0/x0 are SOURCE coords
+  if (TAPS > 1) {
     b = mt / a.tiles_per_img;
-    const int r = mt - b * a.tiles_per_img;
+    int r = mt - b * a.tiles_per_img;
+    if (TAPS == 4) {
+      const int src_tiles = a.tiles_per_img >> 2;
+      const int cls = r / src_tiles;
+      r -= cls * src_tiles;
+      sub_y = cls >> 1;
+      sub_x = cls & 1;
+    }
     const int ty = r / a.tiles_x;
     y0 = ty * C::TH;
     x0 = (r - ty * a.tiles_x) * C::TW;
@@ -137,17 +147,20 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Con
     const int p = (tid >> 2) + 64 * j;
     int v = -1;
     if (p < C::NPIX) {
-      if (TAPS == 9) {
+      if (TAPS == 4) {
+        // parity 0 reads source rows (y-1, y), parity 1 reads (y, y+1): the 2x2 footprint of the folded taps
+        const int hy = p / C::HWD;
+        const int hx = p - hy * C::HWD;
+        const int iy = y0 - 1 + sub_y + hy;
+        const int ix = x0 - 1 + sub_x + hx;
+        if (iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win) v = (b * a.hin + iy) * a.win + ix;
+      } else if (TAPS == 9) {
         const int hy = p / C::HWD;
         const int hx = p - hy * C::HWD;
         const int pad = (STRIDE == 1) ? 1 : 0;
         const int iy = y0 * STRIDE - pad + hy;
         const int ix = x0 * STRIDE - pad + hx;
-        const int hv = a.hin << a.upsample, wv = a.win << a.upsample;
-        if (iy >= 0 && iy < hv && ix >= 0 && ix < wv) {
-          const int sy = iy >> a.upsample, sx = ix >> a.upsample;
-          v = IN_NCHW ? (sy * a.win + sx) : ((b * a.hin + sy) * a.win + sx);
-        }
+        if (iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win) v = IN_NCHW ? (iy * a.win + ix) : ((b * a.hin + iy) * a.win + ix);
       } else {
         v = m0 + p;
       }
@@ -264,7 +277,8 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Con
   auto load_B = [&](int step, f32x4(&rb)[C::BPT]) {
     const int chunk = step / TAPS;
     const int tap = step - chunk * TAPS;
-    const float* src = a.weight + ((size_t)(tap * a.nchunks + chunk) * a.cout_pad + n0) * CF_BK;
+    const int cls_tap = (TAPS == 4) ? (sub_y * 2 + sub_x) * 4 + tap : tap;  // sub-pixel: [class][tap] slabs
+    const float* src = a.weight + ((size_t)(cls_tap * a.nchunks + chunk) * a.cout_pad + n0) * CF_BK;
 #pragma unroll
     for (int j = 0; j < C::BPT; ++j) {
       int f = tid + 256 * j;
@@ -286,7 +300,7 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Con
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int row = wm * (MI * 32) + mi * 32 + l31;
-    if (TAPS == 9) {
+    if (TAPS > 1) {
       const int py = row >> 4, px = row & 15;
       a_off[mi] = ((py * STRIDE) * C::HWD + px * STRIDE) * CF_LDK + half * 4;
     } else {
@@ -308,8 +322,8 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Con
   f32x4 ra[C::APT * AV];
   f32x4 rb[C::BPT];
 
-  if constexpr (TAPS == 9) {
-    // ---- software-pipelined schedule (3x3) -----------------------------------------------------------------
+  if constexpr (TAPS > 1) {
+    // ---- software-pipelined schedule (3x3 / folded 2x2) -----------------------------------------------------------------
     // Weight slabs live in a 3-deep LDS ring: slab t is fetched from HBM/L2 at the start of step t-2, written to
     // LDS at the end of step t-2, made visible by the barrier that opens step t-1, and its first fragments are read
     // in the MIDDLE of step t-1 -- so no wave ever waits on an LDS round trip between two MFMA blocks:
@@ -344,7 +358,7 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Con
               acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
       }
     };
-    auto tap_off = [](int tap) { return ((tap / 3) * C::HWD + (tap % 3)) * CF_LDK; };
+    auto tap_off = [](int tap) { return (TAPS == 4 ? (tap >> 1) * C::HWD + (tap & 1) : (tap / 3) * C::HWD + (tap % 3)) * CF_LDK; };
 
     {
       f32x4 rb1[C::BPT];  // all three prologue fetches in flight together: one exposed HBM/L2 latency, not two
@@ -485,7 +499,9 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Con
       for (int p = 0; p < PASSES; ++p) {
         const int row = wm * (MI * 32) + mi * 32 + p * RPP + rl;
         size_t pixel;
-        if (TAPS == 9)
+        if (TAPS == 4)
+          pixel = ((size_t)b * a.hout + (2 * (y0 + (row >> 4)) + sub_y)) * a.wout + (2 * (x0 + (row & 15)) + sub_x);
+        else if (TAPS == 9)
           pixel = ((size_t)b * a.hout + (y0 + (row >> 4))) * a.wout + (x0 + (row & 15));
         else
           pixel = (size_t)m0 + row;
@@ -580,7 +596,7 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Con
         q0 += __shfl_xor(q0, o, 64);
       }
       if (rl == 0 && nvalid && (n % cpg) == 0) {
-        const int tile_in_img = (TAPS == 9) ? (mt - b * a.tiles_per_img) : (m0 - b * (a.hout * a.wout)) / C::BM;
+        const int tile_in_img = (TAPS > 1) ? (mt - b * a.tiles_per_img) : (m0 - b * (a.hout * a.wout)) / C::BM;
         const size_t pidx = (size_t)tile_in_img * WM + wm;
         const int ng = a.cout / cpg;
         double* o = a.stats_out + (((size_t)b * ng + n / cpg) * a.nparts + pidx) * 2;
@@ -743,7 +759,15 @@ int launch(const ConvArgs& a, hipStream_t stream, int* parts_query) {
   using C = Cfg<TAPS, STRIDE, WM, WN, MI, NI>;
   ConvArgs k = a;
   int mtiles;
-  if (TAPS == 9) {
+  if (TAPS == 4) {  // tiles live on the SOURCE grid; each is computed once per output parity class
+    if (a.hin % C::TH != 0 || a.win % C::TW != 0) {
+      cf_set_error("cf_conv2d: %dx%d upsample source not divisible by the %dx%d tile", a.hin, a.win, C::TH, C::TW);
+      return CF_ERR_ARG;
+    }
+    k.tiles_x = a.win / C::TW;
+    k.tiles_per_img = 4 * k.tiles_x * (a.hin / C::TH);
+    mtiles = k.tiles_per_img * a.batch;
+  } else if (TAPS == 9) {
     if (a.hout % C::TH != 0 || a.wout % C::TW != 0) {
       cf_set_error("cf_conv2d: %dx%d output not divisible by the %dx%d tile", a.hout, a.wout, C::TH, C::TW);
       return CF_ERR_ARG;
@@ -784,7 +808,26 @@ int launch(const ConvArgs& a, hipStream_t stream, int* parts_query) {
   return CF_OK;
 }
 
-__global__ void pack_weight_kernel(const float* __restrict__ w, int cout, int cin, int taps, int cout_pad,
+// Value of packed slab entry (slab, n, c).  slab < 9 (or 1): the plain tap.  Folded nearest-x2 + 3x3 (fold != 0): slab =
+// class*4 + tap2 with class = (oy&1)*2 + (ox&1), tap2 = ty*2 + tx over the 2x2 source footprint; the entry is the SUM of the
+// 3x3 taps that land on that source pixel: parity 0 -> {k=0} , {k=1,2} ; parity 1 -> {k=0,1} , {k=2} (per axis), summed
+// ky-major in fp32 (one rounding per add, fixed order).
+__device__ __forceinline__ float packed_weight_value(const float* __restrict__ w, int cout, int cin, int taps, int fold,
+                                                     int slab, int n, int c) {
+  if (n >= cout || c >= cin) return 0.f;
+  const float* wk = w + ((long)n * cin + c) * taps;
+  if (!fold) return wk[slab];
+  const int cls = slab >> 2, t2 = slab & 3;
+  const int sy = cls >> 1, sx = cls & 1, ty = t2 >> 1, tx = t2 & 1;
+  const int ky0 = sy == 0 ? (ty == 0 ? 0 : 1) : (ty == 0 ? 0 : 2), ky1 = sy == 0 ? (ty == 0 ? 0 : 2) : (ty == 0 ? 1 : 2);
+  const int kx0 = sx == 0 ? (tx == 0 ? 0 : 1) : (tx == 0 ? 0 : 2), kx1 = sx == 0 ? (tx == 0 ? 0 : 2) : (tx == 0 ? 1 : 2);
+  float v = 0.f;
+  for (int ky = ky0; ky <= ky1; ++ky)
+    for (int kx = kx0; kx <= kx1; ++kx) v += wk[ky * 3 + kx];
+  return v;
+}
+
+__global__ void pack_weight_kernel(const float* __restrict__ w, int cout, int cin, int taps, int fold, int cout_pad,
                                    int nchunks, float* __restrict__ packed, long total) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -793,16 +836,13 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int cout, int ci
   const int n = (int)(r % cout_pad);
   r /= cout_pad;
   const int chunk = (int)(r % nchunks);
-  const int tap = (int)(r / nchunks);
-  const int c = chunk * CF_BK + k;
-  float v = 0.f;
-  if (n < cout && c < cin) v = w[((long)n * cin + c) * taps + tap];
-  packed[i] = v;
+  const int slab = (int)(r / nchunks);
+  packed[i] = packed_weight_value(w, cout, cin, taps, fold, slab, n, chunk * CF_BK + k);
 }
 
 // bf16 variant: [tap][cin_pad/32][cout_pad][32] bf16 (round-to-nearest-even), two values per 32-bit word.
-__global__ void pack_weight_bf16_kernel(const float* __restrict__ w, int cout, int cin, int taps, int cout_pad, int nchunks,
-                                        unsigned* __restrict__ packed, long total_words) {
+__global__ void pack_weight_bf16_kernel(const float* __restrict__ w, int cout, int cin, int taps, int fold, int cout_pad,
+                                        int nchunks, unsigned* __restrict__ packed, long total_words) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total_words) return;
   const int k2 = (int)(i % 16);  // word index inside the 32-channel row
@@ -810,13 +850,11 @@ __global__ void pack_weight_bf16_kernel(const float* __restrict__ w, int cout, i
   const int n = (int)(r % cout_pad);
   r /= cout_pad;
   const int chunk = (int)(r % nchunks);
-  const int tap = (int)(r / nchunks);
+  const int slab = (int)(r / nchunks);
   unsigned out = 0;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    const int c = chunk * 32 + k2 * 2 + h;
-    float v = 0.f;
-    if (n < cout && c < cin) v = w[((long)n * cin + c) * taps + tap];
+    const float v = packed_weight_value(w, cout, cin, taps, fold, slab, n, chunk * 32 + k2 * 2 + h);
     unsigned u = __builtin_bit_cast(unsigned, v);
     u += 0x7fffu + ((u >> 16) & 1u);
     out |= (u >> 16) << (16 * h);
@@ -826,16 +864,38 @@ __global__ void pack_weight_bf16_kernel(const float* __restrict__ w, int cout, i
 
 }  // namespace
 
-extern "C" int cf_pack_conv_weight_bf16(const float* w, int cout, int cin, int taps, int cout_pad, int cin_pad, void* packed,
-                                        cf_stream_t stream) {
+static int pack_bf16(const float* w, int cout, int cin, int fold, int cout_pad, int cin_pad, void* packed, cf_stream_t stream) {
   CF_REQUIRE(w && packed, "cf_pack_conv_weight_bf16: null pointer");
-  CF_REQUIRE(taps == 9, "cf_pack_conv_weight_bf16: the bf16 path covers 3x3 convolutions (taps=9)");
   CF_REQUIRE(cin_pad % 32 == 0 && cin_pad >= cin && cout_pad >= cout && cout_pad % 64 == 0,
              "cf_pack_conv_weight_bf16: bad padding cin %d->%d cout %d->%d", cin, cin_pad, cout, cout_pad);
-  const long words = (long)taps * cin_pad * cout_pad / 2;
+  const int slabs = fold ? 16 : 9;
+  const long words = (long)slabs * cin_pad * cout_pad / 2;
   hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, cout,
-                     cin, taps, cout_pad, cin_pad / 32, reinterpret_cast<unsigned*>(packed), words);
+                     cin, 9, fold, cout_pad, cin_pad / 32, reinterpret_cast<unsigned*>(packed), words);
   CF_CHECK_LAUNCH("cf_pack_conv_weight_bf16");
+  return CF_OK;
+}
+
+extern "C" int cf_pack_conv_weight_bf16(const float* w, int cout, int cin, int taps, int cout_pad, int cin_pad, void* packed,
+                                        cf_stream_t stream) {
+  CF_REQUIRE(taps == 9, "cf_pack_conv_weight_bf16: the bf16 path covers 3x3 convolutions (taps=9)");
+  return pack_bf16(w, cout, cin, 0, cout_pad, cin_pad, packed, stream);
+}
+
+extern "C" int cf_pack_conv_weight_up2x_bf16(const float* w, int cout, int cin, int cout_pad, int cin_pad, void* packed,
+                                             cf_stream_t stream) {
+  return pack_bf16(w, cout, cin, 1, cout_pad, cin_pad, packed, stream);
+}
+
+extern "C" int cf_pack_conv_weight_up2x(const float* w, int cout, int cin, int cout_pad, int cin_pad, float* packed,
+                                        cf_stream_t stream) {
+  CF_REQUIRE(w && packed, "cf_pack_conv_weight_up2x: null pointer");
+  CF_REQUIRE(cin_pad % CF_BK == 0 && cin_pad >= cin && cout_pad >= cout && cout_pad % 32 == 0,
+             "cf_pack_conv_weight_up2x: bad padding cin %d->%d cout %d->%d", cin, cin_pad, cout, cout_pad);
+  const long total = 16L * cin_pad * cout_pad;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, cout, cin,
+                     9, 1, cout_pad, cin_pad / CF_BK, packed, total);
+  CF_CHECK_LAUNCH("cf_pack_conv_weight_up2x");
   return CF_OK;
 }
 
@@ -851,7 +911,7 @@ extern "C" int cf_pack_conv_weight(const float* w, int cout, int cin, int taps, 
              "cf_pack_conv_weight: bad padding cin %d->%d cout %d->%d", cin, cin_pad, cout, cout_pad);
   const long total = (long)taps * cin_pad * cout_pad;
   const int blocks = (int)((total + 255) / 256);
-  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, cout, cin, taps,
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, cout, cin, taps, 0,
                      cout_pad, cin_pad / CF_BK, packed, total);
   CF_CHECK_LAUNCH("cf_pack_conv_weight");
   return CF_OK;
@@ -863,7 +923,8 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
   CF_REQUIRE(d->taps == 1 || d->taps == 9, "cf_conv2d: taps must be 1 or 9 (got %d)", d->taps);
   CF_REQUIRE(d->stride == 1 || (d->stride == 2 && d->taps == 9), "cf_conv2d: unsupported stride %d", d->stride);
   CF_REQUIRE(d->batch > 0 && d->hin > 0 && d->win > 0 && d->cout > 0, "cf_conv2d: bad dims");
-  CF_REQUIRE(!(d->upsample && (d->stride != 1 || d->taps != 9)), "cf_conv2d: upsample needs 3x3 stride 1");
+  CF_REQUIRE(!(d->upsample && (d->stride != 1 || d->taps != 9 || d->in_nchw || d->out_nchw)),
+             "cf_conv2d: upsample needs a 3x3 stride-1 NHWC conv");
   const int exp_h = d->stride == 2 ? d->hin / 2 : (d->hin << (d->upsample ? 1 : 0));
   const int exp_w = d->stride == 2 ? d->win / 2 : (d->win << (d->upsample ? 1 : 0));
   CF_REQUIRE(d->hout == exp_h && d->wout == exp_w, "cf_conv2d: hout/wout %dx%d, expected %dx%d", d->hout, d->wout,
@@ -937,6 +998,18 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
   // on the per-image shape ONLY, never on the batch: tiling (and with it the order of the statistics partials) must be
   // the same for a face whether it is restored alone or inside any batch / shard, so results stay bitwise batch-invariant.
   const bool narrow = cp % 128 == 0 && (long)d->hout * d->wout <= 1024;
+  if (d->upsample) {  // nearest x2 + 3x3 as four 2x2 sub-pixel convolutions; weight packed by cf_pack_conv_weight_up2x[_bf16]
+    if (d->bf16_mfma) {
+      if (narrow) return launch<4, 1, 2, 2, 2, 1, false, true>(a, stream, pq);
+      if (cp % 128 == 0) return launch<4, 1, 2, 2, 2, 2, false, true>(a, stream, pq);
+      return launch<4, 1, 4, 1, 2, 2, false, true>(a, stream, pq);
+    }
+    if (narrow) return launch<4, 1, 2, 2, 2, 1, false>(a, stream, pq);
+    if (cp % 128 == 0) return launch<4, 1, 2, 2, 2, 2, false>(a, stream, pq);
+    if (cp == 64) return launch<4, 1, 4, 1, 2, 2, false>(a, stream, pq);
+    cf_set_error("cf_conv2d: upsample path needs cout_pad 64 or a multiple of 128 (got %d)", cp);
+    return CF_ERR_ARG;
+  }
   if (d->bf16_mfma) {
     if (narrow) return launch<9, 1, 2, 2, 2, 1, false, true>(a, stream, pq);
     if (cp % 128 == 0) return launch<9, 1, 2, 2, 2, 2, false, true>(a, stream, pq);

@@ -39,11 +39,11 @@ class GNStats:
 class PackedWeight:
     """A conv / linear weight in the kernel layout [tap][cin_pad/16][cout_pad][16] (+ bias)."""
 
-    __slots__ = ('w', 'bias', 'cout', 'cin', 'taps', 'cout_pad', 'cin_pad', 'bf16')
+    __slots__ = ('w', 'bias', 'cout', 'cin', 'taps', 'cout_pad', 'cin_pad', 'bf16', 'up2x')
 
-    def __init__(self, w, bias, cout, cin, taps, cout_pad, cin_pad, bf16=False):
+    def __init__(self, w, bias, cout, cin, taps, cout_pad, cin_pad, bf16=False, up2x=False):
         self.w, self.bias, self.cout, self.cin, self.taps = w, bias, cout, cin, taps
-        self.cout_pad, self.cin_pad, self.bf16 = cout_pad, cin_pad, bf16
+        self.cout_pad, self.cin_pad, self.bf16, self.up2x = cout_pad, cin_pad, bf16, up2x
 
 
 def _cout_pad(cout):
@@ -54,10 +54,27 @@ def _cout_pad(cout):
     return (cout + 127) // 128 * 128
 
 
-def pack_weight(weight, bias=None, bf16=False):
+def pack_weight(weight, bias=None, bf16=False, up2x=False):
     """weight: (cout, cin, 3, 3) | (cout, cin, 1, 1) | (cout, cin) CUDA fp32 -> PackedWeight.
-    bf16=True (3x3 only, cin % 32 == 0): bf16 operands for the v_mfma_f32_32x32x16_bf16 path of cf_conv2d."""
+    bf16=True (3x3 only, cin % 32 == 0): bf16 operands for the v_mfma_f32_32x32x16_bf16 path of cf_conv2d.
+    up2x=True (3x3 only): taps folded for conv2d(upsample=True) -- nearest x2 + 3x3 as four 2x2 sub-pixel convolutions."""
     lib = L.load()
+    if up2x:
+        w = _f32(weight.detach()).contiguous()
+        cout, cin = w.shape[0], w.shape[1]
+        if w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or cin % (32 if bf16 else 16):
+            raise ValueError('up2x packing needs a 3x3 weight with cin % 16 == 0 (32 for bf16)')
+        cout_pad = max(64, _cout_pad(cout))
+        b = None if bias is None else _f32(bias.detach()).contiguous().clone()
+        if bf16:
+            packed = torch.empty(16 * cin * cout_pad, dtype=torch.bfloat16, device=w.device)
+            L.check(lib.cf_pack_conv_weight_up2x_bf16(L.ptr(w), cout, cin, cout_pad, cin, L.ptr(packed), L.stream_ptr()),
+                    'cf_pack_conv_weight_up2x_bf16')
+        else:
+            packed = torch.empty(16 * cin * cout_pad, dtype=torch.float32, device=w.device)
+            L.check(lib.cf_pack_conv_weight_up2x(L.ptr(w), cout, cin, cout_pad, cin, L.ptr(packed), L.stream_ptr()),
+                    'cf_pack_conv_weight_up2x')
+        return PackedWeight(packed, b, cout, cin, 9, cout_pad, cin, bf16=bf16, up2x=True)
     if bf16:
         w = _f32(weight.detach()).contiguous()
         cout, cin = w.shape[0], w.shape[1]
@@ -112,6 +129,8 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
         c1 = x2.shape[3]
     if c0 + c1 != pw.cin:
         raise ValueError(f'input channels {c0}+{c1} != weight cin {pw.cin}')
+    if bool(upsample) != bool(pw.up2x):
+        raise ValueError('conv2d(upsample=True) needs a weight packed with up2x=True (and vice versa)')
     if stride == 2:
         Ho, Wo = H // 2, W // 2
     else:
@@ -146,10 +165,10 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
     L.check(lib.cf_conv2d(ctypes.byref(d), L.stream_ptr()), 'cf_conv2d')
     e1.record()
     cin = c0 + c1
-    flops = 2.0 * B * Ho * Wo * pw.cout * cin * pw.taps
+    flops = 2.0 * B * Ho * Wo * pw.cout * cin * (4 if upsample else pw.taps)   # executed MACs (folded taps for up2x)
     nbytes = 4.0 * (x.numel() + (0 if x2 is None else x2.numel()) + pw.cout * cin * pw.taps + out.numel()
                     + (0 if res is None else res.numel()) + (0 if sft_scale is None else sft_scale.numel()))
-    kind = ('conv3x3_s2' if stride == 2 else 'conv3x3') if pw.taps == 9 else 'gemm1x1'
+    kind = ('conv3x3_s2' if stride == 2 else ('conv_up2x' if upsample else 'conv3x3')) if pw.taps == 9 else 'gemm1x1'
     PROFILE.append((kind, flops, nbytes, e0, e1, (B, H, W, cin, pw.cout)))
     return out
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 3
+#define CF_ABI_VERSION 4
 
 typedef void* cf_stream_t; /* hipStream_t */
 
@@ -73,7 +73,9 @@ typedef struct cf_conv_desc {
   int32_t cout_pad;       /* packed weight rows (multiple of the N tile: 32/64/128) */
   int32_t taps;           /* 1 or 9 */
   int32_t stride;         /* 1 or 2 (2: pad right/bottom only, vqgan_arch.py:123) */
-  int32_t upsample;       /* 1: nearest x2 of the input fused into the gather */
+  int32_t upsample;       /* 1: nearest x2 + 3x3 (vqgan_arch.py:134-138) computed as four 2x2 sub-pixel convolutions of the
+                             SOURCE tensor (taps folded at pack time: 4 instead of 9 MACs per weight, mathematically
+                             identical); `weight` must come from cf_pack_conv_weight_up2x[_bf16] */
   int32_t in_nchw;        /* 1: in0 is NCHW with c0 <= 4 channels (network input) */
   int32_t out_nchw;       /* 1: write out as NCHW (network output) */
   int32_t prologue;       /* enum cf_prologue */
@@ -109,6 +111,12 @@ int64_t cf_packed_weight_elems(int cin_pad, int taps, int cout_pad);
  * holds cf_packed_weight_elems(cin_pad, taps, cout_pad) bf16 values (half the bytes of the fp32 packing). */
 int cf_pack_conv_weight_bf16(const float* w, int cout, int cin, int taps, int cout_pad, int cin_pad, void* packed,
                              cf_stream_t stream);
+/* Folded weights for cf_conv_desc.upsample: [class 4][tap 4][cin_pad/16][cout_pad][16] fp32 (16*cin_pad*cout_pad values), or the
+ * bf16 analogue with 32-channel slabs.  class = (oy&1)*2 + (ox&1); each entry is the fp32 sum of the 3x3 taps that read the same
+ * source pixel for that output parity. */
+int cf_pack_conv_weight_up2x(const float* w, int cout, int cin, int cout_pad, int cin_pad, float* packed, cf_stream_t stream);
+int cf_pack_conv_weight_up2x_bf16(const float* w, int cout, int cin, int cout_pad, int cin_pad, void* packed,
+                                  cf_stream_t stream);
 
 /* ---- GroupNorm statistics (vqgan_arch.py:14-15: 32 groups, eps 1e-6, biased variance) --------
  * Partials are fp64 (sum, sumsq) tables [batch][groups][parts][2] over an NHWC tensor with c channels whose (fine)

@@ -16,7 +16,7 @@ dev = 'cuda'
 def bench(name, cin, cout, H, k=3, prologue=PRO_NONE, epilogue=EPI_NONE, upsample=False, stride=1, reps=5):
     x = torch.randn(B, H, H, cin, device=dev)
     w = torch.randn(cout, cin, k, k, device=dev) * 0.05
-    pw = ops.pack_weight(w, torch.randn(cout, device=dev))
+    pw = ops.pack_weight(w, torch.randn(cout, device=dev), up2x=upsample)
     sc = sh = res = None
     if prologue in (PRO_AFFINE, PRO_AFFINE_SWISH):
         sc, sh = torch.rand(B, cin, device=dev) + 0.5, torch.randn(B, cin, device=dev) * 0.1
@@ -33,7 +33,7 @@ def bench(name, cin, cout, H, k=3, prologue=PRO_NONE, epilogue=EPI_NONE, upsampl
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    fl = 2.0 * B * Ho * Ho * cout * cin * k * k
+    fl = 2.0 * B * Ho * Ho * cout * cin * (4 if upsample else k * k)
     print(f'{name:52s} {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s', flush=True)
 
 

@@ -145,7 +145,7 @@ def g_basic():
             w = rnd((cout, cin, k, k), 320 + i, 1.0 / (cin * k * k) ** 0.5)
             bias = rnd((cout,), 340 + i, 0.3) + 0.5
             g, b = rnd((cout,), 360 + i), rnd((cout,), 380 + i)
-            pw = ops.pack_weight(w.to(DEV), bias.to(DEV))
+            pw = ops.pack_weight(w.to(DEV), bias.to(DEV), up2x=up)
             y = ops.conv2d(nhwc(x).to(DEV), pw, stride=stride, upsample=up, emit_stats=True)
             assert getattr(y, '_cf_stats', None) is not None, 'conv2d did not attach statistics'
             sc, sh = ops.groupnorm_tables([y], g.to(DEV), b.to(DEV))
@@ -200,7 +200,7 @@ def conv_case(name, cin, cout, H, *, B=2, k=3, stride=1, upsample=False, c_split
             ref = res.double() + 0.7 * (res.double() * sft.double() + ref)
         elif epilogue == EPI_GELU:
             ref = F.gelu(ref)
-        pw = ops.pack_weight(w.to(DEV), bias.to(DEV))
+        pw = ops.pack_weight(w.to(DEV), bias.to(DEV), up2x=upsample)
         if in_nchw:
             xin, x2 = x.to(DEV), None
         elif c_split:
@@ -226,6 +226,8 @@ def g_conv():
     conv_case('conv3x3 s2 64->64 @64', 64, 64, 64, stride=2, seed=70)
     conv_case('conv3x3 up 64->64 @16', 64, 64, 16, upsample=True, seed=80)
     conv_case('conv3x3 up 128->128 @16', 128, 128, 16, upsample=True, seed=90)
+    conv_case('conv3x3 up 256->256 @32 B=3 (narrow off, 2 N tiles)', 256, 256, 32, upsample=True, B=3, seed=95)
+    conv_case('conv3x3 up swish 64->128 @16 (prologue on the source)', 64, 128, 16, upsample=True, prologue=PRO_AFFINE_SWISH, seed=97)
     conv_case('conv3x3 cat 64+64->64 @32', 128, 64, 32, c_split=64, seed=100)
     conv_case('conv3x3 cat 128+128->128 @16', 256, 128, 16, c_split=128, seed=110)
     conv_case('conv3x3 affine+swish 64->128 @32', 64, 128, 32, prologue=PRO_AFFINE_SWISH, seed=120)
@@ -427,7 +429,7 @@ def g_bf16():
             elif epilogue == EPI_SFT:
                 res, sft = rnd((B, cout, Ho, Ho), seed + 6), rnd((B, cout, Ho, Ho), seed + 7)
                 ref = res.double() + 0.7 * (res.double() * sft.double() + ref)
-            pw = ops.pack_weight(w.to(DEV), bias.to(DEV), bf16=True)
+            pw = ops.pack_weight(w.to(DEV), bias.to(DEV), bf16=True, up2x=upsample)
             if c_split:
                 xin, x2 = nhwc(x[:, :c_split]).to(DEV), nhwc(x[:, c_split:]).to(DEV)
             else:
@@ -437,7 +439,8 @@ def g_bf16():
                              res=None if res is None else nhwc(res).to(DEV), sft_scale=None if sft is None else nhwc(sft).to(DEV),
                              sft_w=0.7, emit_stats=True)
             # swish runs on fast exp/rcp in this mode and is then rounded to bf16: allow a few bf16 ulps of the activations
-            tol = 2e-2 if prologue == PRO_AFFINE_SWISH else 2e-4
+            # folded up2x taps are summed in fp32 and THEN rounded to bf16 (the reference here rounds each tap): bf16-ulp level
+            tol = 2e-2 if (prologue == PRO_AFFINE_SWISH or upsample) else 2e-4
             report(name, nchw(got), ref, tol, 1e-4)
         run(name, body)
 

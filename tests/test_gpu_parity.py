@@ -183,3 +183,31 @@ def test_hip_graph_replay_is_bitwise_eager(chk):
     sd['generator.blocks.24.bias'] = sd['generator.blocks.24.bias'] + 1.0
     net.load_state_dict(sd)                                                             # repack -> recapture
     assert float((net(y, w=0.5, adain=True)[0] - eager_y[0] - 1.0).abs().max()) < 1e-5
+
+
+def test_code_only_and_vqautoencoder_module_api(chk):
+    """Other callers of the boundary: code_only=True (training stage II) and VQAutoEncoder.forward (scripts/inference_vqgan.py)."""
+    import torch
+    from oracle.synth import seeded_input
+    net = chk.build_net().cuda()
+    x = seeded_input(1).cuda()
+    full = net(x, w=0.5, adain=True)
+    logits, lq = net(x, w=0.5, code_only=True)
+    assert torch.equal(logits, full[1]) and torch.equal(lq, full[2])
+    # VQAutoEncoder path: encoder -> L2 nearest code -> generator (no fusion); self-consistency + host generator on the same codes
+    import codeformer_amd.archs  # noqa: F401
+    from codeformer_amd.utils.registry import ARCH_REGISTRY
+    torch.manual_seed(3)
+    vq = ARCH_REGISTRY.get('VQAutoEncoder')(512, 64, [1, 2, 2, 4, 4, 8], 'nearest', 2, [16], 1024).eval()
+    vq_gpu = ARCH_REGISTRY.get('VQAutoEncoder')(512, 64, [1, 2, 2, 4, 4, 8], 'nearest', 2, [16], 1024).eval()
+    vq_gpu.load_state_dict(vq.state_dict())
+    vq_gpu = vq_gpu.cuda()
+    out, loss, stats = vq_gpu(x)
+    assert out.shape == (1, 3, 512, 512) and torch.isfinite(out).all() and torch.isfinite(loss)
+    idx = stats['min_encoding_indices'].view(-1)
+    assert idx.shape == (256,) and int(idx.min()) >= 0 and int(idx.max()) < 1024
+    zq = vq_gpu.quantize.get_codebook_feat(idx, [1, 16, 16, 256])
+    assert torch.equal(zq, vq.quantize.embedding.weight[idx.cpu()].view(1, 16, 16, 256).permute(0, 3, 1, 2).cuda())
+    with torch.no_grad():
+        ref = vq.generator(zq.cpu())                        # host (stock torch) generator on the same quantised latent
+    assert float((vq_gpu.generator(zq).cpu() - ref).abs().max()) < 1e-3

@@ -73,10 +73,10 @@ struct Cfg {
   static constexpr int HH = (TAPS == 9) ? (TH - 1) * STRIDE + 3 : (TAPS == 4 ? TH + 1 : TH);   // halo patch rows
   static constexpr int HWD = (TAPS == 9) ? (TW - 1) * STRIDE + 3 : (TAPS == 4 ? TW + 1 : TW);  // halo patch cols
   static constexpr int NPIX = (TAPS > 1) ? HH * HWD : BM;
-  static constexpr int ABUF = (TAPS == 1) ? 2 : 1;
+  static constexpr int ABUF = (TAPS == 1) ? 3 : 1;    // 1x1: the A rows ride in a ring like the weights
   static constexpr int APT = (NPIX * 4 + 255) / 256;  // float4 gather items per thread
   static constexpr int BPT = (BN * 4 + 255) / 256;    // float4 weight items per thread
-  static constexpr int BBUF = (TAPS > 1) ? 3 : 2;    // weight-slab ring depth in LDS
+  static constexpr int BBUF = 3;                      // weight-slab ring depth in LDS
   static constexpr int LDS_MAIN = ABUF * NPIX * CF_LDK + BBUF * BN * CF_LDK;
   static constexpr int LDS_EPI = 4 * 32 * (NI * 32 + 4);  // per-wave 32-row transpose buffers of the epilogue
   static constexpr int LDS_FLOATS = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
@@ -448,28 +448,89 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Con
       }
     }
   } else {
-    load_B(0, rb);
-    load_A(0, ra);
-    int step = 0;
-    for (int chunk = 0; chunk < a.nchunks; ++chunk, ++step) {
-      const int abuf = chunk & 1;
-      const int bbuf = step & 1;
-      store_A(abuf, ra, chunk);
-      store_B(bbuf, rb);
-      __syncthreads();
-      load_B(step + 1 < nsteps ? step + 1 : step, rb);  // clamped: the last prefetch is a harmless re-read
-      load_A(chunk + 1 < a.nchunks ? chunk + 1 : chunk, ra);
-      // pin the prefetch loads ABOVE the MFMA block (hipcc otherwise sinks them next to their first use)
-      __builtin_amdgcn_sched_barrier(0);
-      const float* ap[MI];
-      const float* bp[NI];
+    // ---- 1x1 / Linear: the same ring + weave schedule with BOTH operands in 3-deep LDS rings -----------------------------
+    // Slab t (A rows and weight rows) is fetched at the start of step t-2, written to LDS at the end of step t-2 (the
+    // GroupNorm-apply prologue of the AttnBlock q|k|v GEMM runs in that write), made visible by the barrier opening step
+    // t-1 and first read in the middle of step t-1; ring slot (t+3)%3 is rewritten only after the barrier that follows
+    // every wave's last read of slab t.
+    auto read_frags1 = [&](f32x4(&af)[MI], f32x4(&bf)[NI], int slot_, int kg) {
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) ap[mi] = As + abuf * (C::NPIX * CF_LDK) + a_off[mi];
+      for (int mi = 0; mi < MI; ++mi)
+        af[mi] = *reinterpret_cast<const f32x4*>(As + slot_ * (C::NPIX * CF_LDK) + a_off[mi] + kg * 8);
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) bp[ni] = Bs + bbuf * (C::BN * CF_LDK) + b_off[ni];
-      cf_mma_slab<MI, NI>(acc, ap, bp);
+      for (int ni = 0; ni < NI; ++ni)
+        bf[ni] = *reinterpret_cast<const f32x4*>(Bs + slot_ * (C::BN * CF_LDK) + b_off[ni] + kg * 8);
+    };
+    auto mma16 = [&](const f32x4(&af)[MI], const f32x4(&bf)[NI]) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
+    };
+    const int n = a.nchunks;
+    {
+      f32x4 ra1[C::APT * AV];
+      f32x4 rb1[C::BPT];
+      load_A(0, ra);
+      load_B(0, rb);
+      load_A(1 < n ? 1 : 0, ra1);
+      load_B(1 < n ? 1 : 0, rb1);
+      store_A(0, ra, 0);
+      store_B(0, rb);
+      store_A(1, ra1, 1 < n ? 1 : 0);
+      store_B(1, rb1);
     }
-    __syncthreads();  // every wave is done reading the last slabs before any wave reuses LDS in its epilogue
+    __syncthreads();
+    f32x4 ax[MI], bx[NI], ay[MI], by[NI];
+    read_frags1(ax, bx, 0, 0);
+    int slot = 0;
+    for (int chunk = 0; chunk < n; ++chunk) {
+      const int slot1 = slot == 2 ? 0 : slot + 1;
+      const int slot2 = slot1 == 2 ? 0 : slot1 + 1;
+      const int nxt = chunk + 2 < n ? chunk + 2 : n - 1;  // clamped: the tail prefetches are harmless re-reads
+      constexpr int NM = MI * NI * 4;
+      constexpr bool WEAVE = CF_INTERLEAVE && NM >= MI + NI + C::BPT + C::APT * AV;
+      load_B(nxt, rb);
+      load_A(nxt, ra);
+      read_frags1(ay, by, slot, 1);
+      if (!WEAVE) __builtin_amdgcn_sched_barrier(0);
+      mma16(ax, bx);
+      if (WEAVE) {
+#pragma unroll
+        for (int i = 0; i < MI + NI; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < C::BPT + C::APT * AV; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NM - (MI + NI) - C::BPT - C::APT * AV; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags1(ax, bx, slot1, 0);  // slab chunk+1 (on the last step: a harmless read of the clamped duplicate)
+      mma16(ay, by);
+      if (WEAVE) {
+#pragma unroll
+        for (int i = 0; i < MI + NI; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NM - (MI + NI); ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      store_A(slot2, ra, nxt);
+      store_B(slot2, rb);
+      __syncthreads();
+      slot = slot1;
+    }
+    // (the loop's closing barrier retired every LDS read before any wave reuses LDS in its epilogue)
   }
 
   // ---- epilogue ------------------------------------------------------------------------------------------

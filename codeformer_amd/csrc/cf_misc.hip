@@ -226,17 +226,22 @@ __global__ void upfirdn2d_kernel(const float* __restrict__ x, int in_h, int in_w
   const long plane = i / ((long)out_w * out_h);
   const float* xp = x + plane * in_h * in_w;
   float acc = 0.f;
-  for (int ky = 0; ky < kh; ++ky) {
-    const int uy = oy * down_y + ky - pad_y0;  // coordinate in the zero-stuffed image
-    if (uy < 0 || uy % up_y != 0) continue;
+  // polyphase walk: only taps that land on a real (non zero-stuffed) sample, i.e. (o*down + k - pad) % up == 0
+  const int by = oy * down_y - pad_y0, bx = ox * down_x - pad_x0;
+  const int ky0 = ((-by) % up_y + up_y) % up_y, kx0 = ((-bx) % up_x + up_x) % up_x;
+  for (int ky = ky0; ky < kh; ky += up_y) {
+    const int uy = by + ky;
+    if (uy < 0) continue;
     const int iy = uy / up_y;
-    if (iy >= in_h) continue;
-    for (int kx = 0; kx < kw; ++kx) {
-      const int ux = ox * down_x + kx - pad_x0;
-      if (ux < 0 || ux % up_x != 0) continue;
+    if (iy >= in_h) break;
+    const float* xr = xp + (size_t)iy * in_w;
+    const float* kr = k + (kh - 1 - ky) * kw + (kw - 1);  // flipped FIR kernel
+    for (int kx = kx0; kx < kw; kx += up_x) {
+      const int ux = bx + kx;
+      if (ux < 0) continue;
       const int ix = ux / up_x;
-      if (ix >= in_w) continue;
-      acc += xp[(size_t)iy * in_w + ix] * k[(kh - 1 - ky) * kw + (kw - 1 - kx)];  // flipped FIR kernel
+      if (ix >= in_w) break;
+      acc += xr[ix] * kr[-kx];
     }
   }
   y[i] = acc;

@@ -95,3 +95,25 @@ def test_face_misc_helpers():
     assert h.restored_faces[0].shape == (16, 16, 3)
     h.clean_all()
     assert h.restored_faces == [] and h.cropped_faces == []
+
+
+def test_bundled_ops_shim_cpu():
+    """`basicsr.ops` names of the reference import here; CPU upfirdn2d follows the oracle, grads are refused."""
+    import pytest
+    import torch
+    from basicsr.ops.fused_act import FusedLeakyReLU, fused_leaky_relu  # noqa: F401
+    from basicsr.ops.upfirdn2d import upfirdn2d
+    from oracle import codeformer_oracle as O
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 3, 9, 11, generator=g)
+    k = torch.randn(4, 4, generator=g)
+    for up, down, pad in [(1, 1, (0, 0)), (2, 1, (2, 1)), (1, 2, (1, 1)), (2, 3, (3, 2)), (1, 1, (-1, 2))]:
+        got = upfirdn2d(x, k, up=up, down=down, pad=pad)
+        ref = O.upfirdn2d(x, k, up=up, down=down, pad=pad)
+        assert got.shape == ref.shape and torch.allclose(got, ref, atol=1e-5), (up, down, pad)
+    m = FusedLeakyReLU(3)
+    assert list(m.state_dict()) == ['bias'] and m.negative_slope == 0.2 and abs(m.scale - 2 ** 0.5) < 1e-12
+    with pytest.raises(RuntimeError):
+        upfirdn2d(x.requires_grad_(True), k)
+    with pytest.raises(RuntimeError):
+        fused_leaky_relu(x.detach(), m.bias.detach())   # no CPU implementation, as in the reference

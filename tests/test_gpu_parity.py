@@ -82,6 +82,15 @@ def test_bundled_ops(chk):
         got = ops.upfirdn2d(x.cuda(), k.cuda(), up=up, down=down, pad=pad).cpu()
         ref = O.upfirdn2d(x, k, up=up, down=down, pad=pad)
         assert got.shape == ref.shape and torch.allclose(got, ref, atol=2e-6), (up, down, pad)
+    # the reference's import surface (basicsr/ops/{fused_act,upfirdn2d}/__init__.py) on the same kernels
+    from basicsr.ops.fused_act import FusedLeakyReLU
+    from basicsr.ops.upfirdn2d import upfirdn2d
+    m = FusedLeakyReLU(5).cuda()
+    m.load_state_dict({'bias': b})
+    assert torch.allclose(m(x.cuda()).cpu(), O.fused_bias_act(x, b), atol=1e-6)
+    k3 = seeded_randn((3, 3), 4)
+    assert torch.allclose(upfirdn2d(x.cuda(), k3.cuda(), up=3, down=2, pad=(2, 2)).cpu(),
+                          O.upfirdn2d(x, k3, up=3, down=2, pad=(2, 2)), atol=2e-6)
 
 
 def test_inpainting_config(chk):

@@ -61,6 +61,18 @@ struct ConvArgs {
   int stats_cpg, nparts;
   int tiles_x, tiles_per_img, ntn;
 };
+// The general (EXT) instantiations take a longer argument block; the CodeFormer kernels keep the exact ConvArgs layout
+// (the kernarg size feeds register allocation: growing it perturbed every instantiation's code).
+struct ConvArgsExt : ConvArgs {
+  int ld0, ld1, ldo;  // channel strides of in0 / in1 / out (and res, res2)
+};
+template <bool EXT>
+using ArgsOf = std::conditional_t<EXT, ConvArgsExt, ConvArgs>;
+template <bool EXT>
+__device__ __forceinline__ int ext_ld(const ArgsOf<EXT>& a, int which, int dense) {
+  if constexpr (EXT) return which == 0 ? a.ld0 : (which == 1 ? a.ld1 : a.ldo);
+  return dense;
+}
 
 template <int TAPS, int STRIDE, int WM, int WN, int MI, int NI>
 struct Cfg {
@@ -89,10 +101,16 @@ __device__ __forceinline__ float swishf(float y) { return y * (1.0f / (1.0f + ex
 // still 64 B + 16 B pad, so every LDS address below is unchanged), activations are rounded to bf16 (RNE) in the gather
 // after the prologue, weights are pre-packed bf16, accumulation stays fp32.  Used for the generator / CFT convs of the
 // bf16 configurations only; the fp32 instantiations are bit-for-bit what they were.
-template <int TAPS, int STRIDE, int WM, int WN, int MI, int NI, bool IN_NCHW, bool BF16 = false>
-__global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const ConvArgs a) {
+//
+// EXT = true: the general variant used by dense-block networks (Real-ESRGAN RRDBNet): inputs / outputs are channel slices
+// of wider NHWC buffers (ld0 / ld1 / ldo), image sizes need not be tile multiples (edge tiles are masked in the epilogue;
+// the gather already zero-fills outside the image), and the epilogue set is {none, residual, leaky, axpy, axpy2}.  Kept
+// behind a template flag so the CodeFormer instantiations stay instruction-for-instruction what they were.
+template <int TAPS, int STRIDE, int WM, int WN, int MI, int NI, bool IN_NCHW, bool BF16 = false, bool EXT = false>
+__global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const ArgsOf<EXT> a) {
   using C = Cfg<TAPS, STRIDE, WM, WN, MI, NI>;
   static_assert(!BF16 || (TAPS > 1 && STRIDE == 1 && !IN_NCHW), "bf16 path: 3x3 stride 1 NHWC only");
+  static_assert(!EXT || (TAPS > 1 && STRIDE == 1 && !IN_NCHW && !BF16 && CF_EPI_WAVESYNC), "EXT: 3x3 / folded 2x2, stride 1, NHWC, fp32");
   constexpr int KC = BF16 ? 32 : CF_BK;  // channels per K slab
   constexpr int AV = BF16 ? 2 : 1;       // float4 fetched per gather item (8 / 4 channels)
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -194,7 +212,8 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Con
     } else {
       const bool first = c < a.c0;
       const float* src = first ? a.in0 : a.in1;
-      const int cs = first ? a.c0 : a.c1;
+      int cs = first ? a.c0 : a.c1;
+      if constexpr (EXT) cs = first ? a.ld0 : a.ld1;
       const int cc = first ? c : c - a.c0;
 #pragma unroll
       for (int j = 0; j < C::APT; ++j) {
@@ -556,6 +575,7 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Con
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       size_t offs[PASSES];
+      [[maybe_unused]] unsigned inside = 0;  // EXT: bit p = pass p's pixel lies inside the image (edge tiles)
 #pragma unroll
       for (int p = 0; p < PASSES; ++p) {
         const int row = wm * (MI * 32) + mi * 32 + p * RPP + rl;
@@ -566,8 +586,14 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Con
           pixel = ((size_t)b * a.hout + (y0 + (row >> 4))) * a.wout + (x0 + (row & 15));
         else
           pixel = (size_t)m0 + row;
-        offs[p] = pixel * a.cout + n;
+        offs[p] = pixel * ext_ld<EXT>(a, 2, a.cout) + n;
+        if constexpr (EXT) {
+          const int oy = TAPS == 4 ? 2 * (y0 + (row >> 4)) + sub_y : y0 + (row >> 4);
+          const int ox = TAPS == 4 ? 2 * (x0 + (row & 15)) + sub_x : x0 + (row & 15);
+          if (oy < a.hout && ox < a.wout) inside |= 1u << p;
+        }
       }
+#define CF_LIVE(p) (nvalid && (!EXT || ((inside >> (p)) & 1u)))
 #if CF_EPI_WAVESYNC
       // Residual / SFT operands are requested BEFORE the transpose so their HBM latency overlaps it.  The transpose
       // buffer is private to the wave (LDS operations of one wave complete in issue order), so no workgroup barrier is
@@ -576,8 +602,9 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Con
 #pragma unroll
       for (int p = 0; p < PASSES; ++p) {
         r0[p] = r1[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (nvalid && (EPI == CF_EPI_RESIDUAL || EPI == CF_EPI_SFT)) r0[p] = *reinterpret_cast<const f32x4*>(a.res + offs[p]);
-        if (nvalid && EPI == CF_EPI_SFT) r1[p] = *reinterpret_cast<const f32x4*>(a.sft_scale + offs[p]);
+        if (CF_LIVE(p) && (EPI == CF_EPI_RESIDUAL || EPI == CF_EPI_SFT || EPI == CF_EPI_AXPY || EPI == CF_EPI_AXPY2))
+          r0[p] = *reinterpret_cast<const f32x4*>(a.res + offs[p]);
+        if (CF_LIVE(p) && (EPI == CF_EPI_SFT || EPI == CF_EPI_AXPY2)) r1[p] = *reinterpret_cast<const f32x4*>(a.sft_scale + offs[p]);
       }
       __builtin_amdgcn_wave_barrier();
 #else
@@ -599,7 +626,7 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Con
         const int trow = p * RPP + rl;
         f32x4 v = *reinterpret_cast<const f32x4*>(stage + trow * LDW + cq * 4);
         const size_t o = offs[p];
-        if (nvalid) {
+        if (CF_LIVE(p)) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += bias4[e];
           if (EPI == CF_EPI_RESIDUAL) {
@@ -622,6 +649,19 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Con
           } else if (EPI == CF_EPI_GELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+          } else if (EPI == CF_EPI_LEAKY) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+          } else if (EPI == CF_EPI_AXPY || EPI == CF_EPI_AXPY2) {
+            // separately rounded multiply and add, the two ATen ops of `x5 * 0.2 + x` (rrdbnet_arch.py:39,62) -- no FMA contraction
+#if CF_EPI_WAVESYNC
+            const f32x4 x = r0[p], xx = r1[p];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] = __fadd_rn(__fmul_rn(v[e], a.sft_w), x[e]);
+              if (EPI == CF_EPI_AXPY2) v[e] = __fadd_rn(__fmul_rn(v[e], a.sft_w), xx[e]);
+            }
+#endif
           }
           *reinterpret_cast<f32x4*>(a.out + o) = v;
 #pragma unroll
@@ -632,7 +672,7 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Con
         }
       }
     }
-    if (a.stats_out) {
+    if (!EXT && a.stats_out) {
       // GroupNorm statistics of the values just written, for the NEXT norm: one fp64 partial per (image, group,
       // tile, wave row), combined in a fixed shuffle order -> the later finalize is a deterministic sum.
       const int cpg = a.stats_cpg;
@@ -671,6 +711,7 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Con
     }
   };
 
+#undef CF_LIVE
   // scalar path: NCHW scatter of the 3-channel image (and any cout that is not a multiple of 4)
   auto epilogue_scalar = [&](auto mode) {
     constexpr int EPI = decltype(mode)::value;
@@ -726,7 +767,15 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Con
     return;
   }
 #endif
-  if (vec_ok) {
+  if constexpr (EXT) {  // host guarantees NHWC output with cout % 4 == 0
+    switch (a.epilogue) {
+      case CF_EPI_RESIDUAL: epilogue_vec(std::integral_constant<int, CF_EPI_RESIDUAL>{}); break;
+      case CF_EPI_LEAKY: epilogue_vec(std::integral_constant<int, CF_EPI_LEAKY>{}); break;
+      case CF_EPI_AXPY: epilogue_vec(std::integral_constant<int, CF_EPI_AXPY>{}); break;
+      case CF_EPI_AXPY2: epilogue_vec(std::integral_constant<int, CF_EPI_AXPY2>{}); break;
+      default: epilogue_vec(std::integral_constant<int, CF_EPI_NONE>{}); break;
+    }
+  } else if (vec_ok) {
     switch (a.epilogue) {
       case CF_EPI_RESIDUAL: epilogue_vec(std::integral_constant<int, CF_EPI_RESIDUAL>{}); break;
       case CF_EPI_SFT: epilogue_vec(std::integral_constant<int, CF_EPI_SFT>{}); break;
@@ -811,16 +860,21 @@ __global__ __launch_bounds__(256) void conv3x3_few_cout_kernel(const ConvArgs a)
   const int oy = y0 + py, ox = x0 + px;
 #pragma unroll
   for (int co = 0; co < 4; ++co)
-    if (co < a.cout)
+    if (co < a.cout && oy < a.hout && ox < a.wout)
       a.out[(((size_t)b * a.cout + co) * a.hout + oy) * a.wout + ox] = acc[co] + (a.bias ? a.bias[co] : 0.f);
 }
 
-template <int TAPS, int STRIDE, int WM, int WN, int MI, int NI, bool IN_NCHW, bool BF16 = false>
-int launch(const ConvArgs& a, hipStream_t stream, int* parts_query) {
+template <int TAPS, int STRIDE, int WM, int WN, int MI, int NI, bool IN_NCHW, bool BF16 = false, bool EXT = false>
+int launch(const ConvArgsExt& a, hipStream_t stream, int* parts_query) {
   using C = Cfg<TAPS, STRIDE, WM, WN, MI, NI>;
-  ConvArgs k = a;
+  ArgsOf<EXT> k = a;  // (slices the stride fields off for the CodeFormer instantiations)
   int mtiles;
-  if (TAPS == 4) {  // tiles live on the SOURCE grid; each is computed once per output parity class
+  if (EXT) {  // any image size: ceil-divided tile grid (on the SOURCE grid for the folded upsample), edge tiles masked
+    const int gh = TAPS == 4 ? a.hin : a.hout, gw = TAPS == 4 ? a.win : a.wout;
+    k.tiles_x = (gw + C::TW - 1) / C::TW;
+    k.tiles_per_img = (TAPS == 4 ? 4 : 1) * k.tiles_x * ((gh + C::TH - 1) / C::TH);
+    mtiles = k.tiles_per_img * a.batch;
+  } else if (TAPS == 4) {  // tiles live on the SOURCE grid; each is computed once per output parity class
     if (a.hin % C::TH != 0 || a.win % C::TW != 0) {
       cf_set_error("cf_conv2d: %dx%d upsample source not divisible by the %dx%d tile", a.hin, a.win, C::TH, C::TW);
       return CF_ERR_ARG;
@@ -852,7 +906,7 @@ int launch(const ConvArgs& a, hipStream_t stream, int* parts_query) {
     return CF_OK;
   }
   k.ntn = a.cout_pad / C::BN;
-  auto kern = igemm_kernel<TAPS, STRIDE, WM, WN, MI, NI, IN_NCHW, BF16>;
+  auto kern = igemm_kernel<TAPS, STRIDE, WM, WN, MI, NI, IN_NCHW, BF16, EXT>;
   constexpr size_t lds = C::LDS_FLOATS * sizeof(float);
   static bool attr_set = false;  // benign race: the attribute call is idempotent
   if (!attr_set) {
@@ -1013,16 +1067,36 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
                    d->cout_pad % 64 == 0 && d->cout % 4 == 0,
                "cf_conv2d: bf16_mfma covers 3x3 stride-1 NHWC convs with channels %% 32 == 0 (c0=%d c1=%d cout_pad=%d)", d->c0,
                d->c1, d->cout_pad);
-  CF_REQUIRE(d->prologue >= 0 && d->prologue <= 3 && d->epilogue >= 0 && d->epilogue <= 3, "cf_conv2d: bad pro/epilogue");
+  CF_REQUIRE(d->prologue >= 0 && d->prologue <= 3 && d->epilogue >= 0 && d->epilogue <= CF_EPI_AXPY2, "cf_conv2d: bad pro/epilogue");
   if (d->prologue == CF_PRO_AFFINE || d->prologue == CF_PRO_AFFINE_SWISH)
     CF_REQUIRE(d->pro_scale && d->pro_shift, "cf_conv2d: affine prologue without scale/shift tables");
-  if (d->epilogue == CF_EPI_RESIDUAL || d->epilogue == CF_EPI_SFT) CF_REQUIRE(d->res, "cf_conv2d: epilogue needs res");
+  if (d->epilogue == CF_EPI_RESIDUAL || d->epilogue == CF_EPI_SFT || d->epilogue == CF_EPI_AXPY || d->epilogue == CF_EPI_AXPY2)
+    CF_REQUIRE(d->res, "cf_conv2d: epilogue needs res");
   if (d->epilogue == CF_EPI_SFT) CF_REQUIRE(d->sft_scale, "cf_conv2d: SFT epilogue needs sft_scale");
+  if (d->epilogue == CF_EPI_AXPY2) CF_REQUIRE(d->sft_scale, "cf_conv2d: AXPY2 epilogue needs res2 (sft_scale)");
+  // general (EXT) instantiations: strided channel slices, dense-block epilogues, image sizes off the tile grid
+  const int ld0 = d->ld_in0 > 0 ? d->ld_in0 : d->c0, ld1 = d->ld_in1 > 0 ? d->ld_in1 : d->c1,
+            ldo = d->ld_out > 0 ? d->ld_out : d->cout;
+  CF_REQUIRE(d->ld_in0 >= 0 && d->ld_in1 >= 0 && d->ld_out >= 0 && ld0 >= d->c0 && ld1 >= d->c1 && ldo >= d->cout,
+             "cf_conv2d: channel strides (%d,%d,%d) smaller than the channel counts (%d,%d,%d)", ld0, ld1, ldo, d->c0, d->c1,
+             d->cout);
+  const bool few_cout = d->taps == 9 && d->stride == 1 && d->out_nchw && d->cout <= 4 && !d->upsample && d->c1 == 0 && !d->in_nchw;
+  const bool ext = ld0 != d->c0 || ld1 != d->c1 || ldo != d->cout || d->epilogue >= CF_EPI_LEAKY ||
+                   (d->taps == 9 && d->stride == 1 && !d->in_nchw && !few_cout && (d->hout % 16 != 0 || d->wout % 16 != 0));
+  if (ext) {
+    CF_REQUIRE(d->taps == 9 && d->stride == 1 && !d->in_nchw && !d->out_nchw && !d->bf16_mfma && !d->stats_out &&
+                   !(pq && d->stats_cpg) && d->cout % 4 == 0 && d->epilogue != CF_EPI_SFT && d->epilogue != CF_EPI_GELU,
+               "cf_conv2d: strided slices / leaky|axpy epilogues / off-grid sizes (%dx%d) need a 3x3 stride-1 fp32 NHWC conv with "
+               "cout %% 4 == 0, no statistics, epilogue in {none, residual, leaky, axpy, axpy2}", d->hout, d->wout);
+    CF_REQUIRE(ld0 % 4 == 0 && ld1 % 4 == 0 && ldo % 4 == 0, "cf_conv2d: channel strides must be multiples of 4 floats");
+  } else {
+    CF_REQUIRE(!few_cout || ld0 == d->c0, "cf_conv2d: the NCHW <=4-channel output conv reads a dense input");
+  }
   CF_REQUIRE(!(d->out_nchw && (d->taps != 9 || d->epilogue != CF_EPI_NONE)), "cf_conv2d: out_nchw needs 3x3, no epilogue");
   CF_REQUIRE(d->cout_pad >= d->cout && d->cout_pad % 32 == 0, "cf_conv2d: cout_pad %d invalid for cout %d", d->cout_pad,
              d->cout);
 
-  ConvArgs a;
+  ConvArgsExt a;
   a.in0 = d->in0;
   a.in1 = d->in1;
   a.c0 = d->c0;
@@ -1052,6 +1126,9 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
   a.stats_cpg = d->stats_cpg > 0 ? d->stats_cpg : 1;
   a.nparts = 0;
   a.tiles_x = a.tiles_per_img = a.ntn = 0;
+  a.ld0 = ld0;
+  a.ld1 = ld1;
+  a.ldo = ldo;
 
   const int cp = d->cout_pad;
   // Small-M layers (16x16 / 32x32 latents): at batch 16 a 128x128 tiling yields only 128-256 workgroups for 256 CUs;
@@ -1059,6 +1136,14 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
   // on the per-image shape ONLY, never on the batch: tiling (and with it the order of the statistics partials) must be
   // the same for a face whether it is restored alone or inside any batch / shard, so results stay bitwise batch-invariant.
   const bool narrow = cp % 128 == 0 && (long)d->hout * d->wout <= 1024;
+  if (ext) {
+    if (d->upsample) {
+      CF_REQUIRE(cp % 64 == 0, "cf_conv2d: general upsample path needs cout_pad %% 64 == 0 (got %d)", cp);
+      return launch<4, 1, 4, 1, 2, 2, false, false, true>(a, stream, pq);
+    }
+    if (cp % 64 == 0) return launch<9, 1, 4, 1, 2, 2, false, false, true>(a, stream, pq);
+    return launch<9, 1, 4, 1, 2, 1, false, false, true>(a, stream, pq);  // cout_pad % 32 == 0 (checked above)
+  }
   if (d->upsample) {  // nearest x2 + 3x3 as four 2x2 sub-pixel convolutions; weight packed by cf_pack_conv_weight_up2x[_bf16]
     if (d->bf16_mfma) {
       if (narrow) return launch<4, 1, 2, 2, 2, 1, false, true>(a, stream, pq);
@@ -1084,10 +1169,10 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
     if (narrow) return launch<9, 1, 2, 2, 2, 1, false>(a, stream, pq);
     if (cp % 128 == 0) return launch<9, 1, 2, 2, 2, 2, false>(a, stream, pq);
     if (cp == 64) return launch<9, 1, 4, 1, 2, 2, false>(a, stream, pq);
-    if (d->out_nchw && d->cout <= 4 && !d->upsample && d->c1 == 0 && d->hout % 16 == 0 && d->wout % 16 == 0 && !pq) {
-      a.tiles_x = d->wout / 16;
-      a.tiles_per_img = a.tiles_x * (d->hout / 16);
-      hipLaunchKernelGGL(conv3x3_few_cout_kernel, dim3(a.tiles_per_img * d->batch), dim3(256), 0, stream, a);
+    if (few_cout && !pq) {  // any image size: edge tiles are masked
+      a.tiles_x = (d->wout + 15) / 16;
+      a.tiles_per_img = a.tiles_x * ((d->hout + 15) / 16);
+      hipLaunchKernelGGL(conv3x3_few_cout_kernel, dim3(a.tiles_per_img * d->batch), dim3(256), 0, stream, static_cast<const ConvArgs&>(a));
       CF_CHECK_LAUNCH("cf_conv2d");
       return CF_OK;
     }

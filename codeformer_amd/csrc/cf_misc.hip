@@ -247,7 +247,36 @@ __global__ void upfirdn2d_kernel(const float* __restrict__ x, int in_h, int in_w
   y[i] = acc;
 }
 
+// pixel-unshuffle NCHW -> zero-padded NHWC (arch_util.py:190-206); one thread per output float, channel fastest
+__global__ void pixel_unshuffle_nhwc_kernel(const float* __restrict__ x, int c, int h, int w, int s, int c_pad,
+                                            float* __restrict__ out, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int k = (int)(i % c_pad);
+  const long pix = i / c_pad;
+  const int ox = (int)(pix % w);
+  const int oy = (int)((pix / w) % h);
+  const long b = pix / ((long)w * h);
+  float v = 0.f;
+  if (k < c * s * s) {
+    const int dx = k % s, dy = (k / s) % s, ci = k / (s * s);
+    v = x[((b * c + ci) * (long)(h * s) + (oy * s + dy)) * (long)(w * s) + (ox * s + dx)];
+  }
+  out[i] = v;
+}
+
 }  // namespace
+
+extern "C" int cf_pixel_unshuffle_nhwc(const float* x, int batch, int c, int h, int w, int s, int c_pad, float* out,
+                                       cf_stream_t stream) {
+  CF_REQUIRE(x && out && batch > 0 && c > 0 && h > 0 && w > 0 && s >= 1 && c_pad >= c * s * s && c_pad % 16 == 0,
+             "cf_pixel_unshuffle_nhwc: bad args (c=%d s=%d c_pad=%d)", c, s, c_pad);
+  const long total = (long)batch * h * w * c_pad;
+  hipLaunchKernelGGL(pixel_unshuffle_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     c, h, w, s, c_pad, out, total);
+  CF_CHECK_LAUNCH("cf_pixel_unshuffle_nhwc");
+  return CF_OK;
+}
 
 extern "C" int cf_argmax_rows(const float* logits, int rows, int n, int64_t* idx, cf_stream_t stream) {
   CF_REQUIRE(logits && idx && rows > 0 && n > 0 && n % 4 == 0, "cf_argmax_rows: bad args (n=%d must be a multiple of 4)", n);

@@ -14,9 +14,9 @@ LIB_PATH = os.environ.get('CF_LIB_PATH') or os.path.join(_PKG, 'libcodeformer_hi
 
 c_float_p = ctypes.c_void_p  # device pointers are passed as integers
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 PRO_NONE, PRO_AFFINE, PRO_AFFINE_SWISH, PRO_LEAKY = 0, 1, 2, 3
-EPI_NONE, EPI_RESIDUAL, EPI_SFT, EPI_GELU = 0, 1, 2, 3
+EPI_NONE, EPI_RESIDUAL, EPI_SFT, EPI_GELU, EPI_LEAKY, EPI_AXPY, EPI_AXPY2 = 0, 1, 2, 3, 4, 5, 6
 
 
 class ConvDesc(ctypes.Structure):
@@ -36,6 +36,7 @@ class ConvDesc(ctypes.Structure):
         ('sft_w', ctypes.c_float),
         ('out', ctypes.c_void_p),
         ('stats_out', ctypes.c_void_p), ('stats_cpg', ctypes.c_int32), ('bf16_mfma', ctypes.c_int32),
+        ('ld_in0', ctypes.c_int32), ('ld_in1', ctypes.c_int32), ('ld_out', ctypes.c_int32),
     ]
 
 
@@ -61,6 +62,7 @@ SIGNATURES = {
     'cf_row_sqnorm': (_I, [_P, _I, _I, _P, _P]),
     'cf_vq_argmin': (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
     'cf_nchw_to_nhwc': (_I, [_P, _I, _I, _I, _P, _P]),
+    'cf_pixel_unshuffle_nhwc': (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     'cf_nhwc_to_nchw': (_I, [_P, _I, _I, _I, _P, _P]),
     'cf_img_u8_to_tensor': (_I, [_P, _I, _I, _I, _P, _P]),
     'cf_tensor_to_img_u8': (_I, [_P, _I, _I, _I, _P, _P]),
@@ -116,12 +118,13 @@ def stream_ptr():
     return torch.cuda.current_stream().cuda_stream
 
 
-def ptr(t):
-    """Device pointer of a tensor (None -> NULL).  Tensors must be fp32/int64/uint8/float64 CUDA + contiguous."""
+def ptr(t, strided=False):
+    """Device pointer of a tensor (None -> NULL).  Tensors must be fp32/int64/uint8/float64 CUDA + contiguous
+    (strided=True: the caller validated the layout itself, e.g. a channel slice of an NHWC buffer)."""
     if t is None:
         return None
     if not t.is_cuda:
         raise ValueError('codeformer_amd ops need CUDA (ROCm) tensors')
-    if not t.is_contiguous():
+    if not strided and not t.is_contiguous():
         raise ValueError('codeformer_amd ops need contiguous tensors')
     return t.data_ptr()

@@ -10,7 +10,8 @@ import math
 import torch
 
 from . import lib as L
-from .lib import (EPI_GELU, EPI_NONE, EPI_RESIDUAL, EPI_SFT, PRO_AFFINE, PRO_AFFINE_SWISH, PRO_LEAKY, PRO_NONE)
+from .lib import (EPI_AXPY, EPI_AXPY2, EPI_GELU, EPI_LEAKY, EPI_NONE, EPI_RESIDUAL, EPI_SFT, PRO_AFFINE, PRO_AFFINE_SWISH,
+                  PRO_LEAKY, PRO_NONE)
 
 GN_GROUPS = 32
 GN_EPS = 1e-6
@@ -110,24 +111,45 @@ def pack_weight_cat(weights, biases):
     return pack_weight(w, b)
 
 
+def _nhwc_ld(t, what):
+    """Channel stride (floats per pixel) of an NHWC tensor that is dense or a channel slice `buf[..., a:b]` of a dense one."""
+    B, H, W, C = t.shape
+    ld = t.stride(2) if W > 1 else (t.stride(1) if H > 1 else max(C, t.stride(0) // max(H * W, 1)))
+    ok = t.stride(3) == 1 and ld >= C and (W == 1 or t.stride(2) == ld) and (H == 1 or t.stride(1) == W * ld) and \
+        (B == 1 or t.stride(0) == H * W * ld)
+    if not ok:
+        raise ValueError(f'{what}: expected a dense NHWC tensor or a channel slice of one, got shape {tuple(t.shape)} '
+                         f'strides {t.stride()}')
+    return ld
+
+
 def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale=None, shift=None,
-           epilogue=EPI_NONE, res=None, sft_scale=None, sft_w=0.0, in_nchw=False, out_nchw=False, emit_stats=False):
+           epilogue=EPI_NONE, res=None, sft_scale=None, sft_w=0.0, in_nchw=False, out_nchw=False, emit_stats=False,
+           out=None):
     """Implicit-GEMM conv (3x3 / 1x1).  x: (B,H,W,C0) [x2: (B,H,W,C1) concatenated after x]; returns (B,Ho,Wo,cout)
     (or (B,cout,Ho,Wo) when out_nchw).  With in_nchw, x is (B,C<=4,H,W).
     emit_stats: also write the GroupNorm(32) partial statistics of the output in the epilogue and attach them to the
-    returned tensor (`._cf_stats`), so a following groupnorm_tables() does not re-read the tensor."""
+    returned tensor (`._cf_stats`), so a following groupnorm_tables() does not re-read the tensor.
+    x, x2 and `out` (optional destination) may be channel slices `buf[..., a:b]` of wider NHWC buffers -- the dense-block
+    pattern of RRDBNet, where torch.cat never materialises; res / sft_scale (= res2 of EPI_AXPY2) then share out's stride.
+    EPI_LEAKY / EPI_AXPY / EPI_AXPY2 use sft_w as alpha (see cf_epilogue in the header)."""
     lib = L.load()
     _f32(x)
     if in_nchw:
         B, c0, H, W = x.shape
+        ld0 = 0
+        if not x.is_contiguous():
+            raise ValueError('in_nchw input must be contiguous')
     else:
         B, H, W, c0 = x.shape
-    c1 = 0
+        ld0 = _nhwc_ld(x, 'x')
+    c1 = ld1 = 0
     if x2 is not None:
         if x2.shape[:3] != x.shape[:3]:
             raise ValueError('x2 spatial shape mismatch')
         c1 = x2.shape[3]
-    if c0 + c1 != pw.cin:
+        ld1 = _nhwc_ld(_f32(x2), 'x2')
+    if c0 + c1 != pw.cin and not (c1 == 0 and c0 == pw.cin_pad):
         raise ValueError(f'input channels {c0}+{c1} != weight cin {pw.cin}')
     if bool(upsample) != bool(pw.up2x):
         raise ValueError('conv2d(upsample=True) needs a weight packed with up2x=True (and vice versa)')
@@ -136,19 +158,32 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
     else:
         Ho, Wo = (H * 2, W * 2) if upsample else (H, W)
     shape = (B, pw.cout, Ho, Wo) if out_nchw else (B, Ho, Wo, pw.cout)
-    out = torch.empty(shape, dtype=torch.float32, device=x.device)
+    ldo = 0
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=x.device)
+    else:
+        if tuple(out.shape) != shape or out.dtype != torch.float32 or out.device != x.device:
+            raise ValueError(f'out: expected float32 {shape} on {x.device}')
+        if out_nchw:
+            if not out.is_contiguous():
+                raise ValueError('out_nchw destination must be contiguous')
+        else:
+            ldo = _nhwc_ld(out, 'out')
     for t in (res, sft_scale):
         if t is not None and tuple(t.shape) != (B, Ho, Wo, pw.cout):
             raise ValueError(f'epilogue operand shape {tuple(t.shape)} != {(B, Ho, Wo, pw.cout)}')
+        if t is not None and _nhwc_ld(_f32(t), 'epilogue operand') != (ldo or pw.cout):
+            raise ValueError('epilogue operands must have the channel stride of the output')
     for t in (scale, shift):
         if t is not None and tuple(t.shape) != (B, c0 + c1):
             raise ValueError(f'prologue table shape {tuple(t.shape)} != {(B, c0 + c1)}')
     d = L.ConvDesc(
-        in0=L.ptr(x), in1=L.ptr(x2), c0=c0, c1=c1, batch=B, hin=H, win=W, hout=Ho, wout=Wo, cout=pw.cout,
+        in0=L.ptr(x, not in_nchw), in1=L.ptr(x2, True), c0=c0, c1=c1, batch=B, hin=H, win=W, hout=Ho, wout=Wo, cout=pw.cout,
         cout_pad=pw.cout_pad, taps=pw.taps, stride=stride, upsample=int(bool(upsample)), in_nchw=int(bool(in_nchw)),
         out_nchw=int(bool(out_nchw)), prologue=prologue, epilogue=epilogue, pro_scale=L.ptr(scale),
-        pro_shift=L.ptr(shift), weight=L.ptr(pw.w), bias=L.ptr(pw.bias), res=L.ptr(res), sft_scale=L.ptr(sft_scale),
-        sft_w=float(sft_w), out=L.ptr(out), bf16_mfma=int(pw.bf16))
+        pro_shift=L.ptr(shift), weight=L.ptr(pw.w), bias=L.ptr(pw.bias), res=L.ptr(res, True),
+        sft_scale=L.ptr(sft_scale, True), sft_w=float(sft_w), out=L.ptr(out, not out_nchw), bf16_mfma=int(pw.bf16),
+        ld_in0=ld0, ld_in1=ld1, ld_out=ldo)
     if emit_stats and not out_nchw and pw.cout % GN_GROUPS == 0 and pw.cout // GN_GROUPS >= 2:
         d.stats_cpg = pw.cout // GN_GROUPS
         parts = lib.cf_conv2d_stats_parts(ctypes.byref(d))
@@ -292,6 +327,22 @@ def to_nhwc(x):
     x = _f32(x).contiguous()
     y = torch.empty(B, H, W, C, dtype=torch.float32, device=x.device)
     L.check(lib.cf_nchw_to_nhwc(L.ptr(x), B, C, H * W, L.ptr(y), L.stream_ptr()), 'cf_nchw_to_nhwc')
+    return y
+
+
+def pixel_unshuffle_nhwc(x, scale, c_pad=None):
+    """(B,C,H*s,W*s) NCHW -> (B,H,W,c_pad) channels-last pixel-unshuffle (arch_util.py:190-206), channels zero-padded to a
+    multiple of 16 so the result feeds conv2d directly.  scale=1 is a padded layout change."""
+    lib = L.load()
+    B, C, Hs, Ws = x.shape
+    if Hs % scale or Ws % scale:
+        raise ValueError(f'pixel_unshuffle: {Hs}x{Ws} not divisible by {scale}')
+    cu = C * scale * scale
+    c_pad = (cu + 15) // 16 * 16 if c_pad is None else c_pad
+    x = _f32(x).contiguous()
+    y = torch.empty(B, Hs // scale, Ws // scale, c_pad, dtype=torch.float32, device=x.device)
+    L.check(lib.cf_pixel_unshuffle_nhwc(L.ptr(x), B, C, Hs // scale, Ws // scale, scale, c_pad, L.ptr(y), L.stream_ptr()),
+            'cf_pixel_unshuffle_nhwc')
     return y
 
 

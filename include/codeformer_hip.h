@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 4
+#define CF_ABI_VERSION 5
 
 typedef void* cf_stream_t; /* hipStream_t */
 
@@ -61,6 +61,11 @@ enum cf_epilogue {
   CF_EPI_RESIDUAL = 1,  /* acc + bias + res                                */
   CF_EPI_SFT = 2,       /* res + sft_w*(res*sft_scale + (acc + bias))      */
   CF_EPI_GELU = 3,      /* gelu_erf(acc + bias)                            */
+  /* dense-block family (Real-ESRGAN RRDBNet, basicsr/archs/rrdbnet_arch.py:32-62,111-119); alpha = sft_w */
+  CF_EPI_LEAKY = 4,     /* leaky_relu_0.2(acc + bias)                      */
+  CF_EPI_AXPY = 5,      /* (acc + bias) * alpha + res        (x5 * 0.2 + x, rrdbnet_arch.py:39)          */
+  CF_EPI_AXPY2 = 6,     /* ((acc + bias) * alpha + res) * alpha + res2 ; res2 = sft_scale
+                           (last conv of an RRDB: both residuals of rrdbnet_arch.py:39 and :62 in one pass) */
 };
 
 typedef struct cf_conv_desc {
@@ -96,6 +101,13 @@ typedef struct cf_conv_desc {
                              v_mfma_f32_32x32x16_bf16 (activations rounded to bf16 after the prologue, fp32 accumulate,
                              fp32 tensors in HBM); 3x3 stride-1 NHWC only.  Used by the bf16 configurations for the
                              generator / CFT convolutions -- never for encoder or Transformer (code indices stay exact) */
+  /* Channel strides (floats per pixel) of in0 / in1 / out when they are channel SLICES of wider NHWC buffers; 0 = dense
+   * (c0 / c1 / cout).  res and res2 share ld_out.  A dense block (rrdbnet_arch.py:32-39) keeps x1..x4 in one 128-channel
+   * buffer: conv_k reads cat(x, growth[:, :32(k-1)]) through (in0, in1, ld_in1 = 128) and writes its 32 channels in place
+   * at out = growth + 32(k-1), ld_out = 128 -- torch.cat never materialises.  Any stride other than dense, the epilogues
+   * >= CF_EPI_LEAKY, and output sizes that are not a multiple of the 16x16 pixel tile (edge tiles are masked) select the
+   * general instantiations: 3x3 stride-1 NHWC, cout_pad 32 or 64, no statistics, no bf16. */
+  int32_t ld_in0, ld_in1, ld_out;
 } cf_conv_desc;
 
 int cf_conv2d(const cf_conv_desc* d, cf_stream_t stream);
@@ -167,6 +179,11 @@ int cf_vq_argmin(const float* scores, const float* zz, const float* ee, int rows
 /* ---- layout converters at the NCHW module boundary ---------------------------------------------- */
 int cf_nchw_to_nhwc(const float* x, int batch, int c, int hw, float* y, cf_stream_t stream);
 int cf_nhwc_to_nchw(const float* x, int batch, int c, int hw, float* y, cf_stream_t stream);
+
+/* pixel-unshuffle into channels-last (basicsr/archs/arch_util.py:190-206 + the NCHW->NHWC change): x [batch][c][h*s][w*s]
+ * -> out [batch][h][w][c_pad], channel (ci*s + dy)*s + dx = x[ci][y*s+dy][x*s+dx], channels >= c*s*s zero (c_pad % 16 == 0).
+ * s = 1 is a plain NCHW -> zero-padded NHWC conversion. */
+int cf_pixel_unshuffle_nhwc(const float* x, int batch, int c, int h, int w, int s, int c_pad, float* out, cf_stream_t stream);
 
 /* ---- tensor boundary (basicsr/utils/img_util.py:9-35 img2tensor + normalize, :38-94 tensor2img) ---
  * u8 HWC BGR [batch][h][w][3] -> fp32 NCHW RGB in [-1,1] ((x/255 - 0.5)/0.5), and back

@@ -52,3 +52,39 @@ def load_reference():
     ref_mods = {k: sys.modules.pop(k) for k in list(sys.modules) if k == 'basicsr' or k.startswith('basicsr.')}
     sys.modules.update(saved)
     return reg, vq, cf, ref_mods
+
+
+def load_reference_rrdbnet():
+    """Returns (rrdbnet_arch_module, realesrgan_utils_module) of the reference.
+
+    arch_util.py imports torchvision and the compiled DCN op at module level, realesrgan_utils.py imports cv2; none of
+    them is touched by RRDBNet.forward or by RealESRGANer's tensor stages (pre_process / tile_process / post_process),
+    so empty stand-ins are enough to import the files.  `RealESRGANer.enhance` (cv2 colour conversion) is NOT usable.
+    """
+    if not available():
+        raise RuntimeError(f'reference not found under {REF}')
+    saved = {k: v for k, v in sys.modules.items()
+             if k == 'basicsr' or k.startswith('basicsr.') or k in ('torchvision', 'cv2')}
+    for k in saved:
+        del sys.modules[k]
+    for pkg in ('basicsr', 'basicsr.utils', 'basicsr.archs', 'basicsr.ops', 'basicsr.ops.dcn', 'basicsr.utils.download_util',
+                'basicsr.utils.misc', 'torchvision', 'cv2'):
+        m = types.ModuleType(pkg)
+        m.__path__ = []
+        sys.modules[pkg] = m
+    sys.modules['torchvision'].__version__ = '0.0.0'
+    sys.modules['basicsr.utils'].get_root_logger = lambda *a, **k: logging.getLogger('basicsr_ref')
+    sys.modules['basicsr.ops.dcn'].ModulatedDeformConvPack = type('ModulatedDeformConvPack', (), {})
+    sys.modules['basicsr.ops.dcn'].modulated_deform_conv = None
+    sys.modules['basicsr.utils.download_util'].load_file_from_url = None
+    sys.modules['basicsr.utils.misc'].get_device = lambda gpu_id=None: 'cpu'
+    try:
+        _load('basicsr.utils.registry', f'{REF}/basicsr/utils/registry.py')
+        _load('basicsr.archs.arch_util', f'{REF}/basicsr/archs/arch_util.py')
+        arch = _load('basicsr.archs.rrdbnet_arch', f'{REF}/basicsr/archs/rrdbnet_arch.py')
+        esr = _load('basicsr.utils.realesrgan_utils', f'{REF}/basicsr/utils/realesrgan_utils.py')
+    finally:
+        for k in [k for k in sys.modules if k == 'basicsr' or k.startswith('basicsr.') or k in ('torchvision', 'cv2')]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+    return arch, esr

@@ -143,8 +143,12 @@ def test_shape_errors_are_raised_not_swallowed(chk):
     with pytest.raises(ValueError, match='precision'):
         net(torch.zeros(1, 3, 512, 512, device='cuda'), w=0.5)
     from codeformer_amd import ops
-    with pytest.raises(RuntimeError, match='cf_conv2d'):
-        ops.conv2d(torch.zeros(1, 20, 20, 64, device='cuda'), ops.pack_weight(torch.zeros(64, 64, 3, 3, device='cuda')))
+    pw = ops.pack_weight(torch.zeros(64, 64, 3, 3, device='cuda'))
+    with pytest.raises(RuntimeError, match='cf_conv2d'):      # stride-2 output 10x10 is off the tile grid: refused, not garbage
+        ops.conv2d(torch.zeros(1, 20, 20, 64, device='cuda'), pw, stride=2)
+    with pytest.raises(RuntimeError, match='cf_conv2d'):      # off-grid size + GroupNorm statistics: refused
+        ops.conv2d(torch.zeros(1, 20, 20, 64, device='cuda'), pw, emit_stats=True)
+    assert ops.conv2d(torch.ones(1, 20, 20, 64, device='cuda'), pw).abs().max().item() == 0.0   # stride 1: masked edge tiles
 
 
 def test_packed_weight_cache_follows_the_parameters(chk):

@@ -39,6 +39,9 @@
 #ifndef CF_INTERLEAVE
 #define CF_INTERLEAVE 1      // 1: MFMA-first weave of fetches / LDS traffic into the MFMA stream (sched_group_barrier)
 #endif
+#ifndef CF_FAST_SWISH
+#define CF_FAST_SWISH 1      // 1: fp32 prologue swish on v_exp_f32 / v_rcp_f32 (~3 ulp of x*sigmoid(x)) instead of expf + IEEE divide: +1.2..2.5 % on the GN-swish convs
+#endif
 
 namespace {
 
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Arg
             if (PRO == CF_PRO_AFFINE) y = y * sc[u][e] + sh[u][e];
             if (PRO == CF_PRO_AFFINE_SWISH) {
               y = y * sc[u][e] + sh[u][e];
-              y = BF16 ? y * __frcp_rn(1.0f + __expf(-y)) : swishf(y);  // bf16 operands: fast exp/rcp are far below the rounding
+              y = (BF16 || CF_FAST_SWISH) ? y * __frcp_rn(1.0f + __expf(-y)) : swishf(y);  // bf16 operands: fast exp/rcp are far below the rounding
             }
             if (PRO == CF_PRO_LEAKY) y = y > 0.f ? y : 0.2f * y;
             v[u][e] = valid ? y : 0.f;

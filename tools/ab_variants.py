@@ -12,14 +12,17 @@ for f in sorted(glob.glob(os.path.join(ROOT, 'gpurun_ablate', 'lib_*.so'))):
     l.cf_conv2d.argtypes = [ctypes.POINTER(L.ConvDesc), ctypes.c_void_p]
     libs[os.path.basename(f)[4:-3]] = l
 B = 16
-shapes = [(128, 128, 256, True), (64, 64, 512, True), (256, 256, 64, True), (128, 128, 256, False)]
-for cin, cout, H, swish in shapes:
+shapes = [(128, 128, 256, True, 9), (64, 64, 512, True, 9), (256, 256, 64, True, 9), (128, 128, 256, False, 9)]
+if os.environ.get('AB_SHAPES'):   # "cin,cout,H,swish,taps;..."
+    shapes = [tuple(int(v) for v in item.split(',')) for item in os.environ['AB_SHAPES'].split(';')]
+for cin, cout, H, swish, taps in shapes:
+    k = 3 if taps == 9 else 1
     x = torch.randn(B, H, H, cin, device='cuda')
-    pw = ops.pack_weight(torch.randn(cout, cin, 3, 3, device='cuda') * 0.05, torch.randn(cout, device='cuda'))
+    pw = ops.pack_weight(torch.randn(cout, cin, k, k, device='cuda') * 0.05, torch.randn(cout, device='cuda'))
     sc, sh = torch.rand(B, cin, device='cuda') + 0.5, torch.randn(B, cin, device='cuda') * 0.1
     res = torch.randn(B, H, H, cout, device='cuda')
     out = torch.empty(B, H, H, cout, device='cuda')
-    d = L.ConvDesc(in0=x.data_ptr(), c0=cin, batch=B, hin=H, win=H, hout=H, wout=H, cout=cout, cout_pad=pw.cout_pad, taps=9,
+    d = L.ConvDesc(in0=x.data_ptr(), c0=cin, batch=B, hin=H, win=H, hout=H, wout=H, cout=cout, cout_pad=pw.cout_pad, taps=taps,
                    stride=1, prologue=2 if swish else 0, epilogue=1 if swish else 0, pro_scale=sc.data_ptr(), pro_shift=sh.data_ptr(),
                    weight=pw.w.data_ptr(), bias=pw.bias.data_ptr(), res=res.data_ptr(), out=out.data_ptr())
     st = torch.cuda.current_stream().cuda_stream
@@ -37,8 +40,8 @@ for cin, cout, H, swish in shapes:
             e1.record()
             torch.cuda.synchronize()
             times[k].append(e0.elapsed_time(e1) / 10)
-    fl = 2.0 * B * H * H * cout * cin * 9
-    print(f'--- 3x3 {cin}->{cout} @{H} {"swish+res" if swish else "plain"}')
+    fl = 2.0 * B * H * H * cout * cin * taps
+    print(f'--- taps {taps} {cin}->{cout} @{H} {"swish+res" if swish else "plain"}')
     for k, v in times.items():
         v = sorted(v)
         print(f'   {k:14s} median {v[len(v)//2]:.3f} ms  min {v[0]:.3f} ms   {fl / v[len(v)//2] / 1e9:6.1f} TFLOP/s (median)  {fl / v[0] / 1e9:6.1f} (best)')

@@ -30,10 +30,10 @@ class HipModule(nn.Module):
             PACK_EPOCH[0] += 1
         return ent[1]
 
-    def _pw_conv(self, name, bf16=False, up2x=False):
+    def _pw_conv(self, name, bf16=False, up2x=False, f16=False):
         conv = getattr(self, name) if isinstance(name, str) else name
-        key = (name if isinstance(name, str) else id(conv), bool(bf16), bool(up2x))
-        return self._packed(key, lambda: ops.pack_weight(conv.weight, conv.bias, bf16=bf16, up2x=up2x), conv.weight,
+        key = (name if isinstance(name, str) else id(conv), bool(bf16), bool(up2x), bool(f16))
+        return self._packed(key, lambda: ops.pack_weight(conv.weight, conv.bias, bf16=bf16, up2x=up2x, f16=f16), conv.weight,
                             conv.bias)
 
     def invalidate_packed_weights(self):

@@ -14,6 +14,8 @@ How the dense block maps onto cf_conv2d (no torch.cat, no stand-alone activation
   * `feat + conv_body(...)` is a residual epilogue; conv_last writes NCHW directly.
 Image sizes are arbitrary (edge tiles are masked); there is no tiling requirement on a 288 GB device.
 """
+import os
+
 import torch
 from torch import nn
 from torch.nn import functional as F
@@ -51,17 +53,18 @@ class ResidualDenseBlock(HipModule):
             conv.weight.data *= 0.1
             conv.bias.data.fill_(0)
 
-    def run_hip(self, x, growth, out, outer=None):
+    def run_hip(self, x, growth, out, outer=None, f16=False):
         """x: (B,H,W,num_feat) dense; growth: (B,H,W,4*grow) scratch; out: destination (B,H,W,num_feat).
-        outer: the enclosing RRDB's input when this is its last block (second residual fused)."""
+        outer: the enclosing RRDB's input when this is its last block (second residual fused).
+        f16: IEEE-half MFMA operands (fp32 accumulate, fp32 tensors)."""
         g = self.num_grow_ch
         for k in range(1, 5):
-            ops.conv2d(x, self._pw_conv(f'conv{k}'), x2=growth[..., :g * (k - 1)] if k > 1 else None,
+            ops.conv2d(x, self._pw_conv(f'conv{k}', f16=f16), x2=growth[..., :g * (k - 1)] if k > 1 else None,
                        epilogue=ops.EPI_LEAKY, out=growth[..., g * (k - 1):g * k])
+        pw5 = self._pw_conv('conv5', f16=f16)
         if outer is None:
-            return ops.conv2d(x, self._pw_conv('conv5'), x2=growth, epilogue=ops.EPI_AXPY, res=x, sft_w=_RES_SCALE, out=out)
-        return ops.conv2d(x, self._pw_conv('conv5'), x2=growth, epilogue=ops.EPI_AXPY2, res=x, sft_scale=outer,
-                          sft_w=_RES_SCALE, out=out)
+            return ops.conv2d(x, pw5, x2=growth, epilogue=ops.EPI_AXPY, res=x, sft_w=_RES_SCALE, out=out)
+        return ops.conv2d(x, pw5, x2=growth, epilogue=ops.EPI_AXPY2, res=x, sft_scale=outer, sft_w=_RES_SCALE, out=out)
 
     def forward_host(self, x):
         feats = [x]
@@ -87,11 +90,11 @@ class RRDB(HipModule):
         self.rdb2 = ResidualDenseBlock(num_feat, num_grow_ch)
         self.rdb3 = ResidualDenseBlock(num_feat, num_grow_ch)
 
-    def run_hip(self, x, growth, bufs):
+    def run_hip(self, x, growth, bufs, f16=False):
         """bufs: three (B,H,W,num_feat) buffers, none of them x; returns bufs[2]."""
-        a = self.rdb1.run_hip(x, growth, bufs[0])
-        b = self.rdb2.run_hip(a, growth, bufs[1])
-        return self.rdb3.run_hip(b, growth, bufs[2], outer=x)
+        a = self.rdb1.run_hip(x, growth, bufs[0], f16=f16)
+        b = self.rdb2.run_hip(a, growth, bufs[1], f16=f16)
+        return self.rdb3.run_hip(b, growth, bufs[2], outer=x, f16=f16)
 
     def forward_host(self, x):
         return self.rdb3(self.rdb2(self.rdb1(x))) * _RES_SCALE + x
@@ -126,6 +129,20 @@ class RRDBNet(HipModule):
         self.conv_hr = nn.Conv2d(num_feat, num_feat, 3, 1, 1)
         self.conv_last = nn.Conv2d(num_feat, num_out_ch, 3, 1, 1)
         self.lrelu = nn.LeakyReLU(negative_slope=_SLOPE, inplace=True)
+        # 'fp32' (default): exact fp32 MFMA.  'fp16': IEEE-half MFMA operands with fp32 accumulation and fp32 tensors for every
+        # 64/32-wide 3x3 conv (conv_first and conv_last stay fp32) -- what `.half()` asks for (the reference's RealESRGANer
+        # default on GPUs, inference_codeformer.py:23-27), at higher accuracy than fp16 storage.
+        self.precision = os.environ.get('CODEFORMER_HIP_RRDB_PRECISION', 'fp32')
+
+    def half(self):
+        """Module.half() of the reference switches to fp16 storage; here it selects the f16-operand kernels and keeps fp32
+        parameters and I/O (inputs of any float dtype are accepted, outputs follow the input dtype)."""
+        self.precision = 'fp16'
+        return self
+
+    def float(self):
+        self.precision = 'fp32'
+        return super().float()
 
     def _unshuffle_factor(self):
         return {2: 2, 1: 4}.get(self.scale, 1)
@@ -135,18 +152,23 @@ class RRDBNet(HipModule):
             raise ValueError('RRDBNet on HIP needs num_feat and num_grow_ch to be multiples of 16')
         if self.num_out_ch > 4:
             raise NotImplementedError('RRDBNet on HIP writes at most 4 output channels (num_out_ch <= 4)')
+        if self.precision not in ('fp32', 'fp16'):
+            raise ValueError(f"RRDBNet.precision must be 'fp32' or 'fp16', got {self.precision!r}")
+        f16 = self.precision == 'fp16'
+        if f16 and (self.num_feat % 32 or self.num_grow_ch % 32):
+            raise ValueError('fp16 operands need num_feat and num_grow_ch to be multiples of 32')
         t = ops.pixel_unshuffle_nhwc(x.float(), self._unshuffle_factor())
         feat = ops.conv2d(t, self._pw_conv('conv_first'))
         growth = feat.new_empty(feat.shape[:3] + (4 * self.num_grow_ch,))
         pool = [torch.empty_like(feat) for _ in range(4)]
         cur = feat
         for block in self.body:
-            cur = block.run_hip(cur, growth, [b for b in pool if b is not cur][:3])
-        feat = ops.conv2d(cur, self._pw_conv('conv_body'), epilogue=ops.EPI_RESIDUAL, res=feat)
+            cur = block.run_hip(cur, growth, [b for b in pool if b is not cur][:3], f16=f16)
+        feat = ops.conv2d(cur, self._pw_conv('conv_body', f16=f16), epilogue=ops.EPI_RESIDUAL, res=feat)
         del growth, pool, cur
-        feat = ops.conv2d(feat, self._pw_conv('conv_up1', up2x=True), upsample=True, epilogue=ops.EPI_LEAKY)
-        feat = ops.conv2d(feat, self._pw_conv('conv_up2', up2x=True), upsample=True, epilogue=ops.EPI_LEAKY)
-        feat = ops.conv2d(feat, self._pw_conv('conv_hr'), epilogue=ops.EPI_LEAKY)
+        feat = ops.conv2d(feat, self._pw_conv('conv_up1', up2x=True, f16=f16), upsample=True, epilogue=ops.EPI_LEAKY)
+        feat = ops.conv2d(feat, self._pw_conv('conv_up2', up2x=True, f16=f16), upsample=True, epilogue=ops.EPI_LEAKY)
+        feat = ops.conv2d(feat, self._pw_conv('conv_hr', f16=f16), epilogue=ops.EPI_LEAKY)
         return ops.conv2d(feat, self._pw_conv('conv_last'), out_nchw=True)
 
     def forward_host(self, x):
@@ -160,5 +182,5 @@ class RRDBNet(HipModule):
     def forward(self, x):
         if x.is_cuda:
             with torch.no_grad():
-                return self.forward_hip(x)
-        return self.forward_host(x)
+                return self.forward_hip(x).to(x.dtype)
+        return self.forward_host(x.float()).to(x.dtype)

@@ -109,13 +109,17 @@ __device__ __forceinline__ float swishf(float y) { return y * (1.0f / (1.0f + ex
 // of wider NHWC buffers (ld0 / ld1 / ldo), image sizes need not be tile multiples (edge tiles are masked in the epilogue;
 // the gather already zero-fills outside the image), and the epilogue set is {none, residual, leaky, axpy, axpy2}.  Kept
 // behind a template flag so the CodeFormer instantiations stay instruction-for-instruction what they were.
-template <int TAPS, int STRIDE, int WM, int WN, int MI, int NI, bool IN_NCHW, bool BF16 = false, bool EXT = false>
+// F16 = true (EXT only): as BF16 but IEEE half operands on v_mfma_f32_32x32x16_f16 -- the operand format of the reference's
+// `half=True` Real-ESRGAN (inference_codeformer.py:23-27,44), with fp32 accumulation and fp32 tensors in HBM.
+template <int TAPS, int STRIDE, int WM, int WN, int MI, int NI, bool IN_NCHW, bool BF16 = false, bool EXT = false, bool F16 = false>
 __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const ArgsOf<EXT> a) {
   using C = Cfg<TAPS, STRIDE, WM, WN, MI, NI>;
-  static_assert(!BF16 || (TAPS > 1 && STRIDE == 1 && !IN_NCHW), "bf16 path: 3x3 stride 1 NHWC only");
-  static_assert(!EXT || (TAPS > 1 && STRIDE == 1 && !IN_NCHW && !BF16 && CF_EPI_WAVESYNC), "EXT: 3x3 / folded 2x2, stride 1, NHWC, fp32");
-  constexpr int KC = BF16 ? 32 : CF_BK;  // channels per K slab
-  constexpr int AV = BF16 ? 2 : 1;       // float4 fetched per gather item (8 / 4 channels)
+  constexpr bool LP = BF16 || F16;  // 16-bit MFMA operands
+  static_assert(!LP || (TAPS > 1 && STRIDE == 1 && !IN_NCHW), "16-bit operand path: 3x3 stride 1 NHWC only");
+  static_assert(!(BF16 && F16) && (!F16 || EXT), "one operand format; f16 exists for the EXT instantiations only");
+  static_assert(!EXT || (TAPS > 1 && STRIDE == 1 && !IN_NCHW && !BF16 && CF_EPI_WAVESYNC), "EXT: 3x3 / folded 2x2, stride 1, NHWC, fp32 or f16");
+  constexpr int KC = LP ? 32 : CF_BK;  // channels per K slab
+  constexpr int AV = LP ? 2 : 1;       // float4 fetched per gather item (8 / 4 channels)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const As = smem;
   float* const Bs = smem + C::ABUF * C::NPIX * CF_LDK;
@@ -261,13 +265,23 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Arg
             if (PRO == CF_PRO_AFFINE) y = y * sc[u][e] + sh[u][e];
             if (PRO == CF_PRO_AFFINE_SWISH) {
               y = y * sc[u][e] + sh[u][e];
-              y = (BF16 || CF_FAST_SWISH) ? y * __frcp_rn(1.0f + __expf(-y)) : swishf(y);  // bf16 operands: fast exp/rcp are far below the rounding
+              y = (LP || CF_FAST_SWISH) ? y * __frcp_rn(1.0f + __expf(-y)) : swishf(y);  // bf16 operands: fast exp/rcp are far below the rounding
             }
             if (PRO == CF_PRO_LEAKY) y = y > 0.f ? y : 0.2f * y;
             v[u][e] = valid ? y : 0.f;
           }
         }
-        if constexpr (BF16) {
+        if constexpr (F16) {
+          typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+          f32x4 packed;  // 8 channels -> 8 IEEE halves (v_cvt_f16_f32, round-to-nearest-even) in 16 bytes
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            const float flo = v[h >> 1][(h & 1) * 2], fhi = v[h >> 1][(h & 1) * 2 + 1];
+            const f16x2 pr = {(_Float16)flo, (_Float16)fhi};
+            packed[h] = __builtin_bit_cast(float, pr);
+          }
+          *reinterpret_cast<f32x4*>(dst + p * CF_LDK) = packed;
+        } else if constexpr (BF16) {
           f32x4 packed;  // 8 channels -> 8 bf16 (round-to-nearest-even) in 16 bytes, channel order preserved
 #pragma unroll
           for (int h = 0; h < 4; ++h) {
@@ -362,7 +376,15 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Arg
         bf[ni] = *reinterpret_cast<const f32x4*>(Bs + bslot * (C::BN * CF_LDK) + b_off[ni] + kg * 8);
     };
     auto mma16 = [&](const f32x4(&af)[MI], const f32x4(&bf)[NI]) {
-      if constexpr (BF16) {
+      if constexpr (F16) {
+        typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[mi]),
+                                                                 __builtin_bit_cast(f16x8, bf[ni]), acc[mi][ni], 0, 0, 0);
+      } else if constexpr (BF16) {
         typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -401,9 +423,9 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Arg
       for (int tap = 0; tap < TAPS; ++tap, ++step) {
         const int slot1 = slot == 2 ? 0 : slot + 1;
         const int slot2 = slot1 == 2 ? 0 : slot1 + 1;
-        constexpr int NM = BF16 ? MI * NI : MI * NI * 4;                    // MFMAs per half step
+        constexpr int NM = LP ? MI * NI : MI * NI * 4;                      // MFMAs per half step
         constexpr int NA = (CF_LOADA_TAP >= 0) ? C::APT * AV : 0;           // halo-patch fetches riding in one step
-        constexpr bool WEAVE = CF_INTERLEAVE && !BF16 && NM >= MI + NI + C::BPT + NA;
+        constexpr bool WEAVE = CF_INTERLEAVE && !LP && NM >= MI + NI + C::BPT + NA;
         // ---- first half: fetch slab s+2 (and, once per slab, the next halo patch), read frags(s, k 8..15), MFMA on frags(s, k 0..7)
 #if CF_ABLATE != 4
         load_B(step + 2 < nsteps ? step + 2 : nsteps - 1, rb);  // clamped: the tail prefetches are harmless re-reads
@@ -867,7 +889,7 @@ __global__ __launch_bounds__(256) void conv3x3_few_cout_kernel(const ConvArgs a)
       a.out[(((size_t)b * a.cout + co) * a.hout + oy) * a.wout + ox] = acc[co] + (a.bias ? a.bias[co] : 0.f);
 }
 
-template <int TAPS, int STRIDE, int WM, int WN, int MI, int NI, bool IN_NCHW, bool BF16 = false, bool EXT = false>
+template <int TAPS, int STRIDE, int WM, int WN, int MI, int NI, bool IN_NCHW, bool BF16 = false, bool EXT = false, bool F16 = false>
 int launch(const ConvArgsExt& a, hipStream_t stream, int* parts_query) {
   using C = Cfg<TAPS, STRIDE, WM, WN, MI, NI>;
   ArgsOf<EXT> k = a;  // (slices the stride fields off for the CodeFormer instantiations)
@@ -909,7 +931,7 @@ int launch(const ConvArgsExt& a, hipStream_t stream, int* parts_query) {
     return CF_OK;
   }
   k.ntn = a.cout_pad / C::BN;
-  auto kern = igemm_kernel<TAPS, STRIDE, WM, WN, MI, NI, IN_NCHW, BF16, EXT>;
+  auto kern = igemm_kernel<TAPS, STRIDE, WM, WN, MI, NI, IN_NCHW, BF16, EXT, F16>;
   constexpr size_t lds = C::LDS_FLOATS * sizeof(float);
   static bool attr_set = false;  // benign race: the attribute call is idempotent
   if (!attr_set) {
@@ -958,9 +980,9 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int cout, int ci
   packed[i] = packed_weight_value(w, cout, cin, taps, fold, slab, n, chunk * CF_BK + k);
 }
 
-// bf16 variant: [tap][cin_pad/32][cout_pad][32] bf16 (round-to-nearest-even), two values per 32-bit word.
+// 16-bit variants: [tap][cin_pad/32][cout_pad][32] bf16 or IEEE half (round-to-nearest-even), two values per 32-bit word.
 __global__ void pack_weight_bf16_kernel(const float* __restrict__ w, int cout, int cin, int taps, int fold, int cout_pad,
-                                        int nchunks, unsigned* __restrict__ packed, long total_words) {
+                                        int nchunks, unsigned* __restrict__ packed, long total_words, int f16) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total_words) return;
   const int k2 = (int)(i % 16);  // word index inside the 32-channel row
@@ -973,6 +995,11 @@ __global__ void pack_weight_bf16_kernel(const float* __restrict__ w, int cout, i
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const float v = packed_weight_value(w, cout, cin, taps, fold, slab, n, chunk * 32 + k2 * 2 + h);
+    if (f16) {
+      const _Float16 hv = (_Float16)v;
+      out |= (unsigned)__builtin_bit_cast(unsigned short, hv) << (16 * h);
+      continue;
+    }
     unsigned u = __builtin_bit_cast(unsigned, v);
     u += 0x7fffu + ((u >> 16) & 1u);
     out |= (u >> 16) << (16 * h);
@@ -982,14 +1009,15 @@ __global__ void pack_weight_bf16_kernel(const float* __restrict__ w, int cout, i
 
 }  // namespace
 
-static int pack_bf16(const float* w, int cout, int cin, int fold, int cout_pad, int cin_pad, void* packed, cf_stream_t stream) {
-  CF_REQUIRE(w && packed, "cf_pack_conv_weight_bf16: null pointer");
-  CF_REQUIRE(cin_pad % 32 == 0 && cin_pad >= cin && cout_pad >= cout && cout_pad % 64 == 0,
-             "cf_pack_conv_weight_bf16: bad padding cin %d->%d cout %d->%d", cin, cin_pad, cout, cout_pad);
+static int pack_bf16(const float* w, int cout, int cin, int fold, int cout_pad, int cin_pad, void* packed, cf_stream_t stream,
+                     int f16 = 0) {
+  CF_REQUIRE(w && packed, "cf_pack_conv_weight_bf16/f16: null pointer");
+  CF_REQUIRE(cin_pad % 32 == 0 && cin_pad >= cin && cout_pad >= cout && cout_pad % (f16 ? 32 : 64) == 0,
+             "cf_pack_conv_weight_bf16/f16: bad padding cin %d->%d cout %d->%d", cin, cin_pad, cout, cout_pad);
   const int slabs = fold ? 16 : 9;
   const long words = (long)slabs * cin_pad * cout_pad / 2;
   hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, cout,
-                     cin, 9, fold, cout_pad, cin_pad / 32, reinterpret_cast<unsigned*>(packed), words);
+                     cin, 9, fold, cout_pad, cin_pad / 32, reinterpret_cast<unsigned*>(packed), words, f16);
   CF_CHECK_LAUNCH("cf_pack_conv_weight_bf16");
   return CF_OK;
 }
@@ -1003,6 +1031,17 @@ extern "C" int cf_pack_conv_weight_bf16(const float* w, int cout, int cin, int t
 extern "C" int cf_pack_conv_weight_up2x_bf16(const float* w, int cout, int cin, int cout_pad, int cin_pad, void* packed,
                                              cf_stream_t stream) {
   return pack_bf16(w, cout, cin, 1, cout_pad, cin_pad, packed, stream);
+}
+
+extern "C" int cf_pack_conv_weight_f16(const float* w, int cout, int cin, int taps, int cout_pad, int cin_pad, void* packed,
+                                       cf_stream_t stream) {
+  CF_REQUIRE(taps == 9, "cf_pack_conv_weight_f16: 3x3 weights only (taps=%d)", taps);
+  return pack_bf16(w, cout, cin, 0, cout_pad, cin_pad, packed, stream, 1);
+}
+
+extern "C" int cf_pack_conv_weight_up2x_f16(const float* w, int cout, int cin, int cout_pad, int cin_pad, void* packed,
+                                            cf_stream_t stream) {
+  return pack_bf16(w, cout, cin, 1, cout_pad, cin_pad, packed, stream, 1);
 }
 
 extern "C" int cf_pack_conv_weight_up2x(const float* w, int cout, int cin, int cout_pad, int cin_pad, float* packed,
@@ -1065,9 +1104,10 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
                d->c0, d->c1);
     CF_REQUIRE(d->c1 == 0 || d->in1, "cf_conv2d: c1 > 0 without in1");
   }
+  CF_REQUIRE(d->bf16_mfma >= CF_OPERAND_F32 && d->bf16_mfma <= CF_OPERAND_F16, "cf_conv2d: bad operand format %d", d->bf16_mfma);
   if (d->bf16_mfma)
     CF_REQUIRE(d->taps == 9 && d->stride == 1 && !d->in_nchw && !d->out_nchw && d->c0 % 32 == 0 && d->c1 % 32 == 0 &&
-                   d->cout_pad % 64 == 0 && d->cout % 4 == 0,
+                   d->cout_pad % (d->bf16_mfma == CF_OPERAND_F16 ? 32 : 64) == 0 && d->cout % 4 == 0,
                "cf_conv2d: bf16_mfma covers 3x3 stride-1 NHWC convs with channels %% 32 == 0 (c0=%d c1=%d cout_pad=%d)", d->c0,
                d->c1, d->cout_pad);
   CF_REQUIRE(d->prologue >= 0 && d->prologue <= 3 && d->epilogue >= 0 && d->epilogue <= CF_EPI_AXPY2, "cf_conv2d: bad pro/epilogue");
@@ -1084,12 +1124,12 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
              "cf_conv2d: channel strides (%d,%d,%d) smaller than the channel counts (%d,%d,%d)", ld0, ld1, ldo, d->c0, d->c1,
              d->cout);
   const bool few_cout = d->taps == 9 && d->stride == 1 && d->out_nchw && d->cout <= 4 && !d->upsample && d->c1 == 0 && !d->in_nchw;
-  const bool ext = ld0 != d->c0 || ld1 != d->c1 || ldo != d->cout || d->epilogue >= CF_EPI_LEAKY ||
+  const bool ext = ld0 != d->c0 || ld1 != d->c1 || ldo != d->cout || d->epilogue >= CF_EPI_LEAKY || d->bf16_mfma == CF_OPERAND_F16 ||
                    (d->taps == 9 && d->stride == 1 && !d->in_nchw && !few_cout && (d->hout % 16 != 0 || d->wout % 16 != 0));
   if (ext) {
-    CF_REQUIRE(d->taps == 9 && d->stride == 1 && !d->in_nchw && !d->out_nchw && !d->bf16_mfma && !d->stats_out &&
+    CF_REQUIRE(d->taps == 9 && d->stride == 1 && !d->in_nchw && !d->out_nchw && d->bf16_mfma != CF_OPERAND_BF16 && !d->stats_out &&
                    !(pq && d->stats_cpg) && d->cout % 4 == 0 && d->epilogue != CF_EPI_SFT && d->epilogue != CF_EPI_GELU,
-               "cf_conv2d: strided slices / leaky|axpy epilogues / off-grid sizes (%dx%d) need a 3x3 stride-1 fp32 NHWC conv with "
+               "cf_conv2d: strided slices / leaky|axpy epilogues / off-grid sizes (%dx%d) need a 3x3 stride-1 fp32 / f16-operand NHWC conv with "
                "cout %% 4 == 0, no statistics, epilogue in {none, residual, leaky, axpy, axpy2}", d->hout, d->wout);
     CF_REQUIRE(ld0 % 4 == 0 && ld1 % 4 == 0 && ldo % 4 == 0, "cf_conv2d: channel strides must be multiples of 4 floats");
   } else {
@@ -1140,9 +1180,15 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
   // the same for a face whether it is restored alone or inside any batch / shard, so results stay bitwise batch-invariant.
   const bool narrow = cp % 128 == 0 && (long)d->hout * d->wout <= 1024;
   if (ext) {
+    const bool f16 = d->bf16_mfma == CF_OPERAND_F16;
     if (d->upsample) {
       CF_REQUIRE(cp % 64 == 0, "cf_conv2d: general upsample path needs cout_pad %% 64 == 0 (got %d)", cp);
+      if (f16) return launch<4, 1, 4, 1, 2, 2, false, false, true, true>(a, stream, pq);
       return launch<4, 1, 4, 1, 2, 2, false, false, true>(a, stream, pq);
+    }
+    if (f16) {
+      if (cp % 64 == 0) return launch<9, 1, 4, 1, 2, 2, false, false, true, true>(a, stream, pq);
+      return launch<9, 1, 4, 1, 2, 1, false, false, true, true>(a, stream, pq);
     }
     if (cp % 64 == 0) return launch<9, 1, 4, 1, 2, 2, false, false, true>(a, stream, pq);
     return launch<9, 1, 4, 1, 2, 1, false, false, true>(a, stream, pq);  // cout_pad % 32 == 0 (checked above)

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('CF_LIB_PATH') or os.path.join(_PKG, 'libcodeformer_hi
 
 c_float_p = ctypes.c_void_p  # device pointers are passed as integers
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 PRO_NONE, PRO_AFFINE, PRO_AFFINE_SWISH, PRO_LEAKY = 0, 1, 2, 3
 EPI_NONE, EPI_RESIDUAL, EPI_SFT, EPI_GELU, EPI_LEAKY, EPI_AXPY, EPI_AXPY2 = 0, 1, 2, 3, 4, 5, 6
 
@@ -51,8 +51,10 @@ SIGNATURES = {
     'cf_pack_conv_weight': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     'cf_packed_weight_elems': (_L, [_I, _I, _I]),
     'cf_pack_conv_weight_bf16': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    'cf_pack_conv_weight_f16': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     'cf_pack_conv_weight_up2x': (_I, [_P, _I, _I, _I, _I, _P, _P]),
     'cf_pack_conv_weight_up2x_bf16': (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    'cf_pack_conv_weight_up2x_f16': (_I, [_P, _I, _I, _I, _I, _P, _P]),
     'cf_groupnorm_stats': (_I, [_P, _I, _I, _I, _I, _P, _I, _P]),
     'cf_groupnorm_finalize': (_I, [_P, _I, _I, _I, _I, _I, _L, _P, _P, _F, _P, _P, _I, _P]),
     'cf_layernorm': (_I, [_P, _I, _I, _P, _P, _F, _P, _I, _P, _P, _P]),

@@ -38,7 +38,8 @@ class GNStats:
 
 
 class PackedWeight:
-    """A conv / linear weight in the kernel layout [tap][cin_pad/16][cout_pad][16] (+ bias)."""
+    """A conv / linear weight in the kernel layout [tap][cin_pad/16][cout_pad][16] (+ bias).
+    `bf16` is the operand code of cf_conv_desc.bf16_mfma: 0 / False fp32, 1 / True bf16, 2 IEEE half."""
 
     __slots__ = ('w', 'bias', 'cout', 'cin', 'taps', 'cout_pad', 'cin_pad', 'bf16', 'up2x')
 
@@ -55,11 +56,27 @@ def _cout_pad(cout):
     return (cout + 127) // 128 * 128
 
 
-def pack_weight(weight, bias=None, bf16=False, up2x=False):
+def pack_weight(weight, bias=None, bf16=False, up2x=False, f16=False):
     """weight: (cout, cin, 3, 3) | (cout, cin, 1, 1) | (cout, cin) CUDA fp32 -> PackedWeight.
     bf16=True (3x3 only, cin % 32 == 0): bf16 operands for the v_mfma_f32_32x32x16_bf16 path of cf_conv2d.
+    f16=True (3x3 only, cin % 32 == 0): IEEE-half operands (general instantiations; RRDBNet's half mode).
     up2x=True (3x3 only): taps folded for conv2d(upsample=True) -- nearest x2 + 3x3 as four 2x2 sub-pixel convolutions."""
     lib = L.load()
+    if f16:
+        w = _f32(weight.detach()).contiguous()
+        cout, cin = w.shape[0], w.shape[1]
+        if bf16 or w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or cin % 32:
+            raise ValueError('f16 packing needs a 3x3 weight with cin % 32 == 0 (and not bf16)')
+        cout_pad = max(64, _cout_pad(cout)) if up2x else _cout_pad(cout)
+        b = None if bias is None else _f32(bias.detach()).contiguous().clone()
+        packed = torch.empty((16 if up2x else 9) * cin * cout_pad, dtype=torch.float16, device=w.device)
+        if up2x:
+            L.check(lib.cf_pack_conv_weight_up2x_f16(L.ptr(w), cout, cin, cout_pad, cin, L.ptr(packed), L.stream_ptr()),
+                    'cf_pack_conv_weight_up2x_f16')
+        else:
+            L.check(lib.cf_pack_conv_weight_f16(L.ptr(w), cout, cin, 9, cout_pad, cin, L.ptr(packed), L.stream_ptr()),
+                    'cf_pack_conv_weight_f16')
+        return PackedWeight(packed, b, cout, cin, 9, cout_pad, cin, bf16=2, up2x=bool(up2x))
     if up2x:
         w = _f32(weight.detach()).contiguous()
         cout, cin = w.shape[0], w.shape[1]

@@ -3,8 +3,8 @@
 
 Same constructor arguments and `enhance(img, outscale, alpha_upsampler) -> (output, img_mode)` contract: `img` is an
 HxWx{1,3,4} BGR(A) uint8 / uint16 array as cv2.imread returns it, the result is BGR(A) in the same integer range.
-The network runs in fp32 on the HIP kernels (`half` is accepted for signature compatibility and ignored -- the
-reference's fp16 is an NVIDIA memory workaround); colour handling is plain numpy (cv2 is not a dependency).
+The network runs on the HIP kernels in fp32, or -- `half=True`, the reference's GPU default -- with IEEE-half MFMA operands
+(fp32 accumulation, fp32 tensors: `RRDBNet.half()`); colour handling is plain numpy (cv2 is not a dependency).
 Tiling is kept for API parity (`tile` > 0) but a 288 GB device does not need it: `tile=0` runs the whole image at once.
 """
 import os
@@ -31,7 +31,7 @@ class RealESRGANer:
     def __init__(self, scale, model_path, model=None, tile=0, tile_pad=10, pre_pad=10, half=False, device=None, gpu_id=None):
         self.scale, self.tile_size, self.tile_pad, self.pre_pad = scale, tile, tile_pad, pre_pad
         self.mod_scale = {2: 2, 1: 4}.get(scale)   # the pixel-unshuffle factor the input size must be divisible by
-        self.half = False
+        self.half = bool(half)   # -> RRDBNet.precision 'fp16' (f16 MFMA operands); tensors handed to / from the model stay fp32
         self.device = get_device(gpu_id) if device is None else torch.device(device)
         if model_path is not None:
             if model_path.startswith('https://'):
@@ -40,6 +40,8 @@ class RealESRGANer:
             ckpt = torch.load(model_path, map_location='cpu')
             model.load_state_dict(ckpt['params_ema' if 'params_ema' in ckpt else 'params'], strict=True)
         self.model = model.eval().to(self.device)
+        if self.half and self.device.type == 'cuda':
+            self.model = self.model.half()
 
     # -- tensor stages ---------------------------------------------------------------------------------------------------
     def pre_process(self, img):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 5
+#define CF_ABI_VERSION 6
 
 typedef void* cf_stream_t; /* hipStream_t */
 
@@ -68,6 +68,14 @@ enum cf_epilogue {
                            (last conv of an RRDB: both residuals of rrdbnet_arch.py:39 and :62 in one pass) */
 };
 
+/* MFMA operand format (cf_conv_desc.bf16_mfma; the field keeps its ABI-v3 name) */
+enum cf_operand {
+  CF_OPERAND_F32 = 0,   /* v_mfma_f32_32x32x2_f32, exact fp32 */
+  CF_OPERAND_BF16 = 1,  /* v_mfma_f32_32x32x16_bf16; weight from cf_pack_conv_weight[_up2x]_bf16 */
+  CF_OPERAND_F16 = 2,   /* v_mfma_f32_32x32x16_f16 (general instantiations only); weight from cf_pack_conv_weight[_up2x]_f16.
+                           The operand format of the reference's half-precision Real-ESRGAN (inference_codeformer.py:23-27,44) */
+};
+
 typedef struct cf_conv_desc {
   const float* in0;       /* first input  [batch][hin][win][c0]  (or NCHW when in_nchw) */
   const float* in1;       /* optional second input, channel-concatenated after in0      */
@@ -97,7 +105,7 @@ typedef struct cf_conv_desc {
                              tile part), layout [batch][cout/stats_cpg][parts][2], parts = cf_conv2d_stats_parts(d);
                              feeds cf_groupnorm_finalize so the next GroupNorm never re-reads the tensor */
   int32_t stats_cpg;      /* channels per statistics group: power of two in [2,32] dividing cout */
-  int32_t bf16_mfma;      /* 1: `weight` was packed by cf_pack_conv_weight_bf16 and the contraction runs on
+  int32_t bf16_mfma;      /* enum cf_operand.  1: `weight` was packed by cf_pack_conv_weight_bf16 and the contraction runs on
                              v_mfma_f32_32x32x16_bf16 (activations rounded to bf16 after the prologue, fp32 accumulate,
                              fp32 tensors in HBM); 3x3 stride-1 NHWC only.  Used by the bf16 configurations for the
                              generator / CFT convolutions -- never for encoder or Transformer (code indices stay exact) */
@@ -105,8 +113,8 @@ typedef struct cf_conv_desc {
    * (c0 / c1 / cout).  res and res2 share ld_out.  A dense block (rrdbnet_arch.py:32-39) keeps x1..x4 in one 128-channel
    * buffer: conv_k reads cat(x, growth[:, :32(k-1)]) through (in0, in1, ld_in1 = 128) and writes its 32 channels in place
    * at out = growth + 32(k-1), ld_out = 128 -- torch.cat never materialises.  Any stride other than dense, the epilogues
-   * >= CF_EPI_LEAKY, and output sizes that are not a multiple of the 16x16 pixel tile (edge tiles are masked) select the
-   * general instantiations: 3x3 stride-1 NHWC, cout_pad 32 or 64, no statistics, no bf16. */
+   * >= CF_EPI_LEAKY, CF_OPERAND_F16, and output sizes that are not a multiple of the 16x16 pixel tile (edge tiles are masked)
+   * select the general instantiations: 3x3 stride-1 NHWC, cout_pad 32 or 64, no statistics, fp32 or f16 operands. */
   int32_t ld_in0, ld_in1, ld_out;
 } cf_conv_desc;
 
@@ -129,6 +137,11 @@ int cf_pack_conv_weight_bf16(const float* w, int cout, int cin, int taps, int co
 int cf_pack_conv_weight_up2x(const float* w, int cout, int cin, int cout_pad, int cin_pad, float* packed, cf_stream_t stream);
 int cf_pack_conv_weight_up2x_bf16(const float* w, int cout, int cin, int cout_pad, int cin_pad, void* packed,
                                   cf_stream_t stream);
+/* IEEE-half analogues of the two bf16 packers (same layouts; cout_pad % 32 == 0), for CF_OPERAND_F16 */
+int cf_pack_conv_weight_f16(const float* w, int cout, int cin, int taps, int cout_pad, int cin_pad, void* packed,
+                            cf_stream_t stream);
+int cf_pack_conv_weight_up2x_f16(const float* w, int cout, int cin, int cout_pad, int cin_pad, void* packed,
+                                 cf_stream_t stream);
 
 /* ---- GroupNorm statistics (vqgan_arch.py:14-15: 32 groups, eps 1e-6, biased variance) --------
  * Partials are fp64 (sum, sumsq) tables [batch][groups][parts][2] over an NHWC tensor with c channels whose (fine)

@@ -231,3 +231,55 @@ def test_realesrganer_hip_tiled_equals_reference():
     assert float((tiled - torch.from_numpy(gold['tiled'])).abs().max()) <= 2e-5
     out, mode = up.enhance((img * 255).round().astype(np.uint8)[:, :, ::-1])
     assert mode == 'RGB' and out.shape == (74, 90, 3)
+
+
+@pytest.mark.gpu
+def test_rrdbnet_hip_fp16_operands():
+    """`RRDBNet.half()` = IEEE-half MFMA operands, fp32 accumulate / tensors (the reference's GPU default is fp16 storage).
+    Kernel level: against fp64 convolutions of the SAME half-rounded operands (2e-4 + 1e-4*|ref|: only the accumulation order
+    differs).  Network level: against the fp32 reference goldens -- gate max|d| <= 2e-4 and mean|d| <= 3e-5 on the 2-block
+    nets (outputs up to 0.09; measured 6e-5 / 1e-5), max|d| <= 1e-2 / mean|d| <= 1e-3 on the 23-block net (outputs up to 1.3;
+    measured 2.0e-3 / 3.2e-4)."""
+    from codeformer_amd import lib, ops
+    import torch.nn.functional as F
+    lib.load()
+    g = torch.Generator().manual_seed(33)
+    B, H, W = 2, 21, 40
+    xin = torch.randn(B, H, W, 64, generator=g)
+    buf = torch.randn(B, H, W, 128, generator=g)
+    res = torch.randn(B, H, W, 64, generator=g)
+    h = lambda t: t.half().double()   # noqa: E731
+
+    def ref_conv(inp, w, b, up=False):
+        x = h(inp).permute(0, 3, 1, 2)
+        if up:
+            x = x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+        return F.conv2d(x, h(w), b.double(), padding=1).permute(0, 2, 3, 1)
+
+    def close(a, r):
+        return bool(((a.double() - r).abs() <= 2e-4 + 1e-4 * r.abs()).all())
+
+    w32, b32 = torch.randn(32, 128, 3, 3, generator=g) * 0.05, torch.randn(32, generator=g)
+    dbuf = buf.cuda()
+    ops.conv2d(xin.cuda(), ops.pack_weight(w32.cuda(), b32.cuda(), f16=True), x2=dbuf[..., :64], epilogue=ops.EPI_LEAKY,
+               out=dbuf[..., 64:96])
+    assert close(dbuf[..., 64:96].cpu(), F.leaky_relu(ref_conv(torch.cat([xin, buf[..., :64]], 3), w32, b32), 0.2))
+    w64, b64 = torch.randn(64, 192, 3, 3, generator=g) * 0.05, torch.randn(64, generator=g)
+    y = ops.conv2d(xin.cuda(), ops.pack_weight(w64.cuda(), b64.cuda(), f16=True), x2=buf.cuda(), epilogue=ops.EPI_AXPY,
+                   res=res.cuda(), sft_w=0.2)
+    assert close(y.cpu(), ref_conv(torch.cat([xin, buf], 3), w64, b64) * 0.2 + res.double())
+    wu, bu = torch.randn(64, 64, 3, 3, generator=g) * 0.05, torch.randn(64, generator=g)
+    y = ops.conv2d(xin.cuda(), ops.pack_weight(wu.cuda(), bu.cuda(), f16=True, up2x=True), upsample=True, epilogue=ops.EPI_LEAKY)
+    r = F.leaky_relu(ref_conv(xin, wu, bu, up=True), 0.2)
+    # folded taps are summed in fp32 and THEN rounded to half (as for bf16): compare at the half-rounding level of the sum
+    assert bool(((y.cpu().double() - r).abs() <= 2e-2 + 1e-2 * r.abs()).all())
+    d = _digests()
+    for name, (tmax, tmean) in (('x2_small', (2e-4, 3e-5)), ('x4_small', (2e-4, 3e-5)), ('x2_full', (1e-2, 1e-3))):
+        case = d[name]
+        net = _build(case).cuda().half()
+        gold = torch.from_numpy(np.load(os.path.join(GOLD, f'rrdbnet_{name}.npz'))['out'])
+        y = net(_input(case['shape'], case['in_seed']).cuda()).cpu()
+        err = (y - gold).abs()
+        print(f'rrdbnet fp16 {name}: max|d| {float(err.max()):.3e} mean|d| {float(err.mean()):.3e} (out max {float(gold.abs().max()):.3f})')
+        assert y.dtype == torch.float32 and float(err.max()) <= tmax and float(err.mean()) <= tmean
+        assert net.float().precision == 'fp32'

@@ -11,7 +11,7 @@ for f in sorted(glob.glob(os.path.join(ROOT, 'gpurun_ablate', 'lib_*.so'))):
     l.cf_conv2d.restype = ctypes.c_int
     l.cf_conv2d.argtypes = [ctypes.POINTER(L.ConvDesc), ctypes.c_void_p]
     libs[os.path.basename(f)[4:-3]] = l
-B = 16
+B = int(os.environ.get('AB_BATCH', 16))
 shapes = [(128, 128, 256, True, 9), (64, 64, 512, True, 9), (256, 256, 64, True, 9), (128, 128, 256, False, 9)]
 if os.environ.get('AB_SHAPES'):   # "cin,cout,H,swish,taps;..."
     shapes = [tuple(int(v) for v in item.split(',')) for item in os.environ['AB_SHAPES'].split(';')]

@@ -1,5 +1,5 @@
 """Time RRDBNet (RealESRGAN_x2plus shape: scale 2, 23 blocks) on the HIP path.  GPU box only.
-    python tools/rrdb_bench.py [H W [batch]]      # input image size, default 1080 1920 1
+    python tools/rrdb_bench.py [H W [batch [fp32|fp16]]]      # input image size, default 1080 1920 1 fp32
 Prints ms per image, nominal TFLOP/s (2*MAC of every conv as the reference executes it, 9 taps for the upsample convs)
 and the per-kernel-kind split from ops.PROFILE events."""
 import os
@@ -23,8 +23,10 @@ def nominal_flops(h, w, scale=2, nf=64, gc=32, nb=23, cin=3, cout=3):
 def main():
     h, w = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1080, 1920)
     b = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    prec = sys.argv[4] if len(sys.argv) > 4 else 'fp32'
     torch.manual_seed(0)
     net = RRDBNet(3, 3, scale=2, num_feat=64, num_block=23, num_grow_ch=32).eval().cuda()
+    net.precision = prec
     x = torch.rand(b, 3, h, w, device='cuda')
     for _ in range(2):
         y = net(x)
@@ -38,7 +40,7 @@ def main():
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     fl = nominal_flops(h, w) * b
-    print(f'RRDBNet x2 23 blocks, input {b}x3x{h}x{w} -> {tuple(y.shape)}: {ms:.2f} ms/call, {ms / b:.2f} ms/image, '
+    print(f'RRDBNet x2 23 blocks ({prec}), input {b}x3x{h}x{w} -> {tuple(y.shape)}: {ms:.2f} ms/call, {ms / b:.2f} ms/image, '
           f'{fl / ms / 1e9:.1f} nominal TFLOP/s, peak mem {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB')
     ops.PROFILE = []
     net(x)

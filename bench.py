@@ -141,7 +141,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch-per-gpu', type=int, default=16)
     ap.add_argument('--w', type=float, default=0.5)
-    ap.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32',
+    ap.add_argument('--precision', choices=['fp32', 'bf16', 'fp16'], default='fp32',
                     help="fp32 = BASELINE config 2 (the headline); bf16 = generator + CFT on bf16 MFMA operands (configs 3/5), "
                          "encoder / Transformer / argmax stay fp32")
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -192,7 +192,7 @@ def main():
             'metric': 'aligned 512x512 faces/sec (whole node) at w=0.5', 'value': round(faces_per_s, 2), 'unit': 'faces/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if args.precision == 'fp32' else 'bf16 operands / f32 accumulate (generator+CFT); f32 (encoder, Transformer)',
+            'dtype': 'f32' if args.precision == 'fp32' else f'{args.precision} operands / f32 accumulate (generator+CFT); f32 (encoder, Transformer)',
             'data': 'synthetic',
             'config': {'workload': f'BASELINE config 2: batch={B} aligned 512x512 faces per GPU, w={args.w}, adain=True, fp32, '
                                    f'CodeFormer(codebook 1024, 4 fuse levels), {weights} weights', 'global_batch': total,

@@ -160,6 +160,7 @@ class CodeFormer(VQAutoEncoder):
 
         # 'fp32': everything on exact fp32 MFMA.  'bf16' (BASELINE configs 3/5): generator + CFT 3x3 convs on bf16 MFMA
         # operands with fp32 accumulate; encoder, Transformer and the code argmax stay fp32 so the indices stay exact.
+        # 'fp16': the same split with IEEE-half operands (same speed, 3 more mantissa bits: ~8x smaller pixel error).
         self.precision = os.environ.get('CODEFORMER_HIP_PRECISION', 'fp32')
         # Optional HIP-graph replay of the whole forward (one graph per input shape / w / flags): takes the ~250 host launches
         # per call off the critical path.  Measured: no gain at B=1..16 on an otherwise idle host (the kernels, not the launches,
@@ -217,9 +218,9 @@ class CodeFormer(VQAutoEncoder):
                                     lq=tokens.view(B, T, -1) if adain else None)
         quant = quant.view(B, lq.shape[1], lq.shape[2], -1)
 
-        if self.precision not in ('fp32', 'bf16'):
-            raise ValueError(f"precision must be 'fp32' or 'bf16', got {self.precision!r}")
-        bf16 = self.precision == 'bf16'
+        if self.precision not in ('fp32', 'bf16', 'fp16'):
+            raise ValueError(f"precision must be 'fp32', 'bf16' or 'fp16', got {self.precision!r}")
+        bf16 = {'fp32': 0, 'bf16': 1, 'fp16': 2}[self.precision]   # MFMA operand code of the generator + CFT 3x3 convs
         gen_taps = None
         if w > 0:
             def fuse(t):

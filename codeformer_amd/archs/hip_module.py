@@ -32,9 +32,9 @@ class HipModule(nn.Module):
 
     def _pw_conv(self, name, bf16=False, up2x=False, f16=False):
         conv = getattr(self, name) if isinstance(name, str) else name
-        key = (name if isinstance(name, str) else id(conv), bool(bf16), bool(up2x), bool(f16))
-        return self._packed(key, lambda: ops.pack_weight(conv.weight, conv.bias, bf16=bf16, up2x=up2x, f16=f16), conv.weight,
-                            conv.bias)
+        code = 2 if f16 else int(bf16)   # MFMA operand format: 0 fp32, 1 bf16, 2 IEEE half (`bf16` may carry the code)
+        key = (name if isinstance(name, str) else id(conv), code, bool(up2x))
+        return self._packed(key, lambda: ops.pack_weight(conv.weight, conv.bias, bf16=code, up2x=up2x), conv.weight, conv.bias)
 
     def invalidate_packed_weights(self):
         """Drop every cached packed weight of this module tree.  The cache already follows load_state_dict / .to() /

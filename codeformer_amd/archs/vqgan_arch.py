@@ -219,13 +219,12 @@ class _Conv3x3(HipModule):
         self.in_channels, self.out_channels = cin, cout
 
     def pw(self, bf16=False):
-        return self._packed(('w', bool(bf16)), lambda: ops.pack_weight(self.weight, self.bias, bf16=bf16), self.weight,
+        return self._packed(('w', int(bf16)), lambda: ops.pack_weight(self.weight, self.bias, bf16=int(bf16)), self.weight,
                             self.bias)
 
     def forward_nhwc(self, x, bf16=False, **kw):
-        bf16 = bf16 and self.in_channels % 32 == 0 and self.out_channels % 4 == 0 and not kw.get('out_nchw') \
-            and not kw.get('in_nchw')
-        return ops.conv2d(x, self.pw(bf16), **kw)
+        ok16 = self.in_channels % 32 == 0 and self.out_channels % 4 == 0 and not kw.get('out_nchw') and not kw.get('in_nchw')
+        return ops.conv2d(x, self.pw(int(bf16) if ok16 else 0), **kw)   # bf16 carries the operand code (0 / 1 bf16 / 2 f16)
 
     def forward_host(self, x):
         return F.conv2d(x, self.weight, self.bias, stride=1, padding=1)

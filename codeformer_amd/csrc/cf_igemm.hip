@@ -109,14 +109,15 @@ __device__ __forceinline__ float swishf(float y) { return y * (1.0f / (1.0f + ex
 // of wider NHWC buffers (ld0 / ld1 / ldo), image sizes need not be tile multiples (edge tiles are masked in the epilogue;
 // the gather already zero-fills outside the image), and the epilogue set is {none, residual, leaky, axpy, axpy2}.  Kept
 // behind a template flag so the CodeFormer instantiations stay instruction-for-instruction what they were.
-// F16 = true (EXT only): as BF16 but IEEE half operands on v_mfma_f32_32x32x16_f16 -- the operand format of the reference's
-// `half=True` Real-ESRGAN (inference_codeformer.py:23-27,44), with fp32 accumulation and fp32 tensors in HBM.
+// F16 = true: as BF16 but IEEE half operands on v_mfma_f32_32x32x16_f16 (3 more mantissa bits, same MFMA rate) -- the operand
+// format of the reference's `half=True` Real-ESRGAN (inference_codeformer.py:23-27,44) and of CodeFormer's precision='fp16';
+// fp32 accumulation and fp32 tensors in HBM.
 template <int TAPS, int STRIDE, int WM, int WN, int MI, int NI, bool IN_NCHW, bool BF16 = false, bool EXT = false, bool F16 = false>
 __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const ArgsOf<EXT> a) {
   using C = Cfg<TAPS, STRIDE, WM, WN, MI, NI>;
   constexpr bool LP = BF16 || F16;  // 16-bit MFMA operands
   static_assert(!LP || (TAPS > 1 && STRIDE == 1 && !IN_NCHW), "16-bit operand path: 3x3 stride 1 NHWC only");
-  static_assert(!(BF16 && F16) && (!F16 || EXT), "one operand format; f16 exists for the EXT instantiations only");
+  static_assert(!(BF16 && F16), "one operand format");
   static_assert(!EXT || (TAPS > 1 && STRIDE == 1 && !IN_NCHW && !BF16 && CF_EPI_WAVESYNC), "EXT: 3x3 / folded 2x2, stride 1, NHWC, fp32 or f16");
   constexpr int KC = LP ? 32 : CF_BK;  // channels per K slab
   constexpr int AV = LP ? 2 : 1;       // float4 fetched per gather item (8 / 4 channels)
@@ -1124,7 +1125,8 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
              "cf_conv2d: channel strides (%d,%d,%d) smaller than the channel counts (%d,%d,%d)", ld0, ld1, ldo, d->c0, d->c1,
              d->cout);
   const bool few_cout = d->taps == 9 && d->stride == 1 && d->out_nchw && d->cout <= 4 && !d->upsample && d->c1 == 0 && !d->in_nchw;
-  const bool ext = ld0 != d->c0 || ld1 != d->c1 || ldo != d->cout || d->epilogue >= CF_EPI_LEAKY || d->bf16_mfma == CF_OPERAND_F16 ||
+  const bool ext = ld0 != d->c0 || ld1 != d->c1 || ldo != d->cout || d->epilogue >= CF_EPI_LEAKY ||
+                   (d->bf16_mfma == CF_OPERAND_F16 && d->cout_pad % 64 != 0) ||
                    (d->taps == 9 && d->stride == 1 && !d->in_nchw && !few_cout && (d->hout % 16 != 0 || d->wout % 16 != 0));
   if (ext) {
     CF_REQUIRE(d->taps == 9 && d->stride == 1 && !d->in_nchw && !d->out_nchw && d->bf16_mfma != CF_OPERAND_BF16 && !d->stats_out &&
@@ -1194,6 +1196,11 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
     return launch<9, 1, 4, 1, 2, 1, false, false, true>(a, stream, pq);  // cout_pad % 32 == 0 (checked above)
   }
   if (d->upsample) {  // nearest x2 + 3x3 as four 2x2 sub-pixel convolutions; weight packed by cf_pack_conv_weight_up2x[_bf16]
+    if (d->bf16_mfma == CF_OPERAND_F16) {
+      if (narrow) return launch<4, 1, 2, 2, 2, 1, false, false, false, true>(a, stream, pq);
+      if (cp % 128 == 0) return launch<4, 1, 2, 2, 2, 2, false, false, false, true>(a, stream, pq);
+      return launch<4, 1, 4, 1, 2, 2, false, false, false, true>(a, stream, pq);
+    }
     if (d->bf16_mfma) {
       if (narrow) return launch<4, 1, 2, 2, 2, 1, false, true>(a, stream, pq);
       if (cp % 128 == 0) return launch<4, 1, 2, 2, 2, 2, false, true>(a, stream, pq);
@@ -1204,6 +1211,11 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
     if (cp == 64) return launch<4, 1, 4, 1, 2, 2, false>(a, stream, pq);
     cf_set_error("cf_conv2d: upsample path needs cout_pad 64 or a multiple of 128 (got %d)", cp);
     return CF_ERR_ARG;
+  }
+  if (d->bf16_mfma == CF_OPERAND_F16) {
+    if (narrow) return launch<9, 1, 2, 2, 2, 1, false, false, false, true>(a, stream, pq);
+    if (cp % 128 == 0) return launch<9, 1, 2, 2, 2, 2, false, false, false, true>(a, stream, pq);
+    return launch<9, 1, 4, 1, 2, 2, false, false, false, true>(a, stream, pq);  // cout_pad == 64
   }
   if (d->bf16_mfma) {
     if (narrow) return launch<9, 1, 2, 2, 2, 1, false, true>(a, stream, pq);

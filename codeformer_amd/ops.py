@@ -62,11 +62,13 @@ def pack_weight(weight, bias=None, bf16=False, up2x=False, f16=False):
     f16=True (3x3 only, cin % 32 == 0): IEEE-half operands (general instantiations; RRDBNet's half mode).
     up2x=True (3x3 only): taps folded for conv2d(upsample=True) -- nearest x2 + 3x3 as four 2x2 sub-pixel convolutions."""
     lib = L.load()
+    code = 2 if f16 else int(bf16)   # callers may pass the operand code (0 fp32 / 1 bf16 / 2 f16) through `bf16`
+    f16, bf16 = code == 2, code == 1
     if f16:
         w = _f32(weight.detach()).contiguous()
         cout, cin = w.shape[0], w.shape[1]
-        if bf16 or w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or cin % 32:
-            raise ValueError('f16 packing needs a 3x3 weight with cin % 32 == 0 (and not bf16)')
+        if w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or cin % 32:
+            raise ValueError('f16 packing needs a 3x3 weight with cin % 32 == 0')
         cout_pad = max(64, _cout_pad(cout)) if up2x else _cout_pad(cout)
         b = None if bias is None else _f32(bias.detach()).contiguous().clone()
         packed = torch.empty((16 if up2x else 9) * cin * cout_pad, dtype=torch.float16, device=w.device)

@@ -72,8 +72,9 @@ enum cf_epilogue {
 enum cf_operand {
   CF_OPERAND_F32 = 0,   /* v_mfma_f32_32x32x2_f32, exact fp32 */
   CF_OPERAND_BF16 = 1,  /* v_mfma_f32_32x32x16_bf16; weight from cf_pack_conv_weight[_up2x]_bf16 */
-  CF_OPERAND_F16 = 2,   /* v_mfma_f32_32x32x16_f16 (general instantiations only); weight from cf_pack_conv_weight[_up2x]_f16.
-                           The operand format of the reference's half-precision Real-ESRGAN (inference_codeformer.py:23-27,44) */
+  CF_OPERAND_F16 = 2,   /* v_mfma_f32_32x32x16_f16; weight from cf_pack_conv_weight[_up2x]_f16.  The operand format of the
+                           reference's half-precision Real-ESRGAN (inference_codeformer.py:23-27,44); same speed as bf16
+                           with 3 more mantissa bits (conv inputs here are O(1): no range problem) */
 };
 
 typedef struct cf_conv_desc {
@@ -113,7 +114,7 @@ typedef struct cf_conv_desc {
    * (c0 / c1 / cout).  res and res2 share ld_out.  A dense block (rrdbnet_arch.py:32-39) keeps x1..x4 in one 128-channel
    * buffer: conv_k reads cat(x, growth[:, :32(k-1)]) through (in0, in1, ld_in1 = 128) and writes its 32 channels in place
    * at out = growth + 32(k-1), ld_out = 128 -- torch.cat never materialises.  Any stride other than dense, the epilogues
-   * >= CF_EPI_LEAKY, CF_OPERAND_F16, and output sizes that are not a multiple of the 16x16 pixel tile (edge tiles are masked)
+   * >= CF_EPI_LEAKY, and output sizes that are not a multiple of the 16x16 pixel tile (edge tiles are masked)
    * select the general instantiations: 3x3 stride-1 NHWC, cout_pad 32 or 64, no statistics, fp32 or f16 operands. */
   int32_t ld_in0, ld_in1, ld_out;
 } cf_conv_desc;

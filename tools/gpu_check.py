@@ -468,8 +468,17 @@ def g_bf16():
               f'rms={float((d ** 2).mean().sqrt()):.5f} ref_std={float(ref.std()):.3f} indices_equal={neq == 0}', flush=True)
         report('bf16 mode out vs fp32 reference golden (bf16 gate)', out, torch.from_numpy(gold['out']), 0.25)
         RESULTS.append(('bf16 mode mean error gate', float(d.mean()) < 0.02, float(d.mean())))
+        net.precision = 'fp16'   # IEEE-half operands: same split, same speed, 3 more mantissa bits
+        out, logits, lq = net(x, w=0.5, adain=True)
+        report('fp16 mode: logits bitwise equal to the fp32 mode', logits, o32[1], 0)
+        neq = int((net.last_indices.cpu().numpy() != gold['idx']).sum())
+        RESULTS.append(('fp16 mode indices exact', neq == 0, neq))
+        d = (out.cpu().double() - torch.from_numpy(gold['out']).double()).abs()
+        print(f'   fp16 mode out vs fp32 reference golden: max|d|={float(d.max()):.4f} mean|d|={float(d.mean()):.5f}', flush=True)
+        report('fp16 mode out vs fp32 reference golden (fp16 gate)', out, torch.from_numpy(gold['out']), 0.04)
+        RESULTS.append(('fp16 mode mean error gate', float(d.mean()) < 0.003, float(d.mean())))
         xb = seeded_input(16).to(DEV)
-        for prec in ('fp32', 'bf16'):
+        for prec in ('fp32', 'bf16', 'fp16'):
             net.precision = prec
             for _ in range(2):
                 net(xb, w=0.5, adain=True)

@@ -68,7 +68,17 @@ struct ConvArgs {
 // (the kernarg size feeds register allocation: growing it perturbed every instantiation's code).
 struct ConvArgsExt : ConvArgs {
   int ld0, ld1, ldo;  // channel strides of in0 / in1 / out (and res, res2)
+  int pad_mode;       // CF_PAD_ZERO / CF_PAD_REFLECT (3x3) / CF_PAD_EDGE (folded upsample)
+  int pad_lo;         // stride 2: rows / columns of padding on the top / left (0 = CodeFormer Downsample, 1 = symmetric)
 };
+// border handling of the gather for the EXT instantiations: coordinate remap instead of zero fill
+__device__ __forceinline__ int cf_border(int i, int n, int mode) {
+  if (mode == CF_PAD_REFLECT) {
+    i = i < 0 ? -i : i;
+    i = i >= n ? 2 * n - 2 - i : i;
+  }
+  return i < 0 ? 0 : (i >= n ? n - 1 : i);  // (also keeps the overhang of masked edge tiles addressable)
+}
 template <bool EXT>
 using ArgsOf = std::conditional_t<EXT, ConvArgsExt, ConvArgs>;
 template <bool EXT>
@@ -118,7 +128,7 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Arg
   constexpr bool LP = BF16 || F16;  // 16-bit MFMA operands
   static_assert(!LP || (TAPS > 1 && STRIDE == 1 && !IN_NCHW), "16-bit operand path: 3x3 stride 1 NHWC only");
   static_assert(!(BF16 && F16), "one operand format");
-  static_assert(!EXT || (TAPS > 1 && STRIDE == 1 && !IN_NCHW && !BF16 && CF_EPI_WAVESYNC), "EXT: 3x3 / folded 2x2, stride 1, NHWC, fp32 or f16");
+  static_assert(!EXT || (TAPS > 1 && !IN_NCHW && !BF16 && CF_EPI_WAVESYNC), "EXT: 3x3 / folded 2x2, NHWC, fp32 or f16");
   constexpr int KC = LP ? 32 : CF_BK;  // channels per K slab
   constexpr int AV = LP ? 2 : 1;       // float4 fetched per gather item (8 / 4 channels)
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -177,15 +187,28 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Arg
         // parity 0 reads source rows (y-1, y), parity 1 reads (y, y+1): the 2x2 footprint of the folded taps
         const int hy = p / C::HWD;
         const int hx = p - hy * C::HWD;
-        const int iy = y0 - 1 + sub_y + hy;
-        const int ix = x0 - 1 + sub_x + hx;
+        int iy = y0 - 1 + sub_y + hy;
+        int ix = x0 - 1 + sub_x + hx;
+        if constexpr (EXT) {
+          if (a.pad_mode != CF_PAD_ZERO) {
+            iy = cf_border(iy, a.hin, a.pad_mode);
+            ix = cf_border(ix, a.win, a.pad_mode);
+          }
+        }
         if (iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win) v = (b * a.hin + iy) * a.win + ix;
       } else if (TAPS == 9) {
         const int hy = p / C::HWD;
         const int hx = p - hy * C::HWD;
-        const int pad = (STRIDE == 1) ? 1 : 0;
-        const int iy = y0 * STRIDE - pad + hy;
-        const int ix = x0 * STRIDE - pad + hx;
+        int pad = (STRIDE == 1) ? 1 : 0;
+        if constexpr (EXT && STRIDE == 2) pad = a.pad_lo;
+        int iy = y0 * STRIDE - pad + hy;
+        int ix = x0 * STRIDE - pad + hx;
+        if constexpr (EXT) {
+          if (a.pad_mode != CF_PAD_ZERO) {
+            iy = cf_border(iy, a.hin, a.pad_mode);
+            ix = cf_border(ix, a.win, a.pad_mode);
+          }
+        }
         if (iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win) v = IN_NCHW ? (iy * a.win + ix) : ((b * a.hin + iy) * a.win + ix);
       } else {
         v = m0 + p;
@@ -818,7 +841,7 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Arg
 // layer is HBM-bound anyway (reads 64 channels, writes 3): one thread per output pixel on the vector ALU, the same LDS
 // halo patch + prologue as the MFMA kernel, weights fetched through the scalar cache (wave-uniform addresses), coalesced
 // per-plane NCHW stores.  Accumulation order: slab, tap, channel (a plain fp32 FMA chain).
-__global__ __launch_bounds__(256) void conv3x3_few_cout_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256) void conv3x3_few_cout_kernel(const ConvArgsExt a) {
   constexpr int TH = 16, TW = 16, HWD = TW + 2, NPIX = (TH + 2) * HWD, APT = (NPIX * 4 + 255) / 256;
   __shared__ __attribute__((aligned(16))) float As[NPIX * CF_LDK];
   const int tid = threadIdx.x;
@@ -834,7 +857,11 @@ __global__ __launch_bounds__(256) void conv3x3_few_cout_kernel(const ConvArgs a)
     int v = -1;
     if (p < NPIX) {
       const int hy = p / HWD, hx = p - hy * HWD;
-      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+      int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+      if (a.pad_mode != CF_PAD_ZERO) {
+        iy = cf_border(iy, a.hin, a.pad_mode);
+        ix = cf_border(ix, a.win, a.pad_mode);
+      }
       if (iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win) v = (b * a.hin + iy) * a.win + ix;
     }
     pix[j] = v;
@@ -1125,11 +1152,19 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
              "cf_conv2d: channel strides (%d,%d,%d) smaller than the channel counts (%d,%d,%d)", ld0, ld1, ldo, d->c0, d->c1,
              d->cout);
   const bool few_cout = d->taps == 9 && d->stride == 1 && d->out_nchw && d->cout <= 4 && !d->upsample && d->c1 == 0 && !d->in_nchw;
+  CF_REQUIRE(d->pad_mode >= CF_PAD_ZERO && d->pad_mode <= CF_PAD_EDGE && (d->pad_lo == 0 || d->pad_lo == 1),
+             "cf_conv2d: bad pad_mode %d / pad_lo %d", d->pad_mode, d->pad_lo);
+  CF_REQUIRE(d->pad_mode != CF_PAD_REFLECT || (d->taps == 9 && !d->upsample && d->hin >= 2 && d->win >= 2),
+             "cf_conv2d: reflect padding is for plain 3x3 convs on images of at least 2x2");
+  CF_REQUIRE(d->pad_mode != CF_PAD_EDGE || d->upsample, "cf_conv2d: edge padding belongs to the folded upsample conv");
+  CF_REQUIRE(d->pad_lo == 0 || d->stride == 2, "cf_conv2d: pad_lo applies to stride 2");
   const bool ext = ld0 != d->c0 || ld1 != d->c1 || ldo != d->cout || d->epilogue >= CF_EPI_LEAKY ||
+                   ((d->pad_mode != CF_PAD_ZERO || d->pad_lo) && !(d->out_nchw && d->cout <= 4)) ||
                    (d->bf16_mfma == CF_OPERAND_F16 && d->cout_pad % 64 != 0) ||
                    (d->taps == 9 && d->stride == 1 && !d->in_nchw && !few_cout && (d->hout % 16 != 0 || d->wout % 16 != 0));
   if (ext) {
-    CF_REQUIRE(d->taps == 9 && d->stride == 1 && !d->in_nchw && !d->out_nchw && d->bf16_mfma != CF_OPERAND_BF16 && !d->stats_out &&
+    CF_REQUIRE(d->taps == 9 && (d->stride == 1 || (d->bf16_mfma == CF_OPERAND_F32 && d->cout_pad % 128 == 0)) && !d->in_nchw &&
+                   !d->out_nchw && d->bf16_mfma != CF_OPERAND_BF16 && !d->stats_out &&
                    !(pq && d->stats_cpg) && d->cout % 4 == 0 && d->epilogue != CF_EPI_SFT && d->epilogue != CF_EPI_GELU,
                "cf_conv2d: strided slices / leaky|axpy epilogues / off-grid sizes (%dx%d) need a 3x3 stride-1 fp32 / f16-operand NHWC conv with "
                "cout %% 4 == 0, no statistics, epilogue in {none, residual, leaky, axpy, axpy2}", d->hout, d->wout);
@@ -1174,6 +1209,8 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
   a.ld0 = ld0;
   a.ld1 = ld1;
   a.ldo = ldo;
+  a.pad_mode = d->pad_mode;
+  a.pad_lo = d->pad_lo;
 
   const int cp = d->cout_pad;
   // Small-M layers (16x16 / 32x32 latents): at batch 16 a 128x128 tiling yields only 128-256 workgroups for 256 CUs;
@@ -1183,15 +1220,18 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
   const bool narrow = cp % 128 == 0 && (long)d->hout * d->wout <= 1024;
   if (ext) {
     const bool f16 = d->bf16_mfma == CF_OPERAND_F16;
+    if (d->stride == 2) return launch<9, 2, 2, 2, 2, 2, false, false, true>(a, stream, pq);  // fp32, cout_pad % 128 == 0 (checked)
     if (d->upsample) {
       CF_REQUIRE(cp % 64 == 0, "cf_conv2d: general upsample path needs cout_pad %% 64 == 0 (got %d)", cp);
       if (f16) return launch<4, 1, 4, 1, 2, 2, false, false, true, true>(a, stream, pq);
+      if (cp % 128 == 0) return launch<4, 1, 2, 2, 2, 2, false, false, true>(a, stream, pq);
       return launch<4, 1, 4, 1, 2, 2, false, false, true>(a, stream, pq);
     }
     if (f16) {
       if (cp % 64 == 0) return launch<9, 1, 4, 1, 2, 2, false, false, true, true>(a, stream, pq);
       return launch<9, 1, 4, 1, 2, 1, false, false, true, true>(a, stream, pq);
     }
+    if (cp % 128 == 0) return launch<9, 1, 2, 2, 2, 2, false, false, true>(a, stream, pq);
     if (cp % 64 == 0) return launch<9, 1, 4, 1, 2, 2, false, false, true>(a, stream, pq);
     return launch<9, 1, 4, 1, 2, 1, false, false, true>(a, stream, pq);  // cout_pad % 32 == 0 (checked above)
   }
@@ -1233,7 +1273,7 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
     if (few_cout && !pq) {  // any image size: edge tiles are masked
       a.tiles_x = (d->wout + 15) / 16;
       a.tiles_per_img = a.tiles_x * ((d->hout + 15) / 16);
-      hipLaunchKernelGGL(conv3x3_few_cout_kernel, dim3(a.tiles_per_img * d->batch), dim3(256), 0, stream, static_cast<const ConvArgs&>(a));
+      hipLaunchKernelGGL(conv3x3_few_cout_kernel, dim3(a.tiles_per_img * d->batch), dim3(256), 0, stream, a);
       CF_CHECK_LAUNCH("cf_conv2d");
       return CF_OK;
     }

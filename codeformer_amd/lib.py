@@ -14,9 +14,10 @@ LIB_PATH = os.environ.get('CF_LIB_PATH') or os.path.join(_PKG, 'libcodeformer_hi
 
 c_float_p = ctypes.c_void_p  # device pointers are passed as integers
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 PRO_NONE, PRO_AFFINE, PRO_AFFINE_SWISH, PRO_LEAKY = 0, 1, 2, 3
 EPI_NONE, EPI_RESIDUAL, EPI_SFT, EPI_GELU, EPI_LEAKY, EPI_AXPY, EPI_AXPY2 = 0, 1, 2, 3, 4, 5, 6
+PAD_ZERO, PAD_REFLECT, PAD_EDGE = 0, 1, 2
 
 
 class ConvDesc(ctypes.Structure):
@@ -37,6 +38,7 @@ class ConvDesc(ctypes.Structure):
         ('out', ctypes.c_void_p),
         ('stats_out', ctypes.c_void_p), ('stats_cpg', ctypes.c_int32), ('bf16_mfma', ctypes.c_int32),
         ('ld_in0', ctypes.c_int32), ('ld_in1', ctypes.c_int32), ('ld_out', ctypes.c_int32),
+        ('pad_mode', ctypes.c_int32), ('pad_lo', ctypes.c_int32),
     ]
 
 

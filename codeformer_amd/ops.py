@@ -11,7 +11,7 @@ import torch
 
 from . import lib as L
 from .lib import (EPI_AXPY, EPI_AXPY2, EPI_GELU, EPI_LEAKY, EPI_NONE, EPI_RESIDUAL, EPI_SFT, PRO_AFFINE, PRO_AFFINE_SWISH,
-                  PRO_LEAKY, PRO_NONE)
+                  PAD_EDGE, PAD_REFLECT, PAD_ZERO, PRO_LEAKY, PRO_NONE)
 
 GN_GROUPS = 32
 GN_EPS = 1e-6
@@ -144,14 +144,16 @@ def _nhwc_ld(t, what):
 
 def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale=None, shift=None,
            epilogue=EPI_NONE, res=None, sft_scale=None, sft_w=0.0, in_nchw=False, out_nchw=False, emit_stats=False,
-           out=None):
+           out=None, pad_mode=PAD_ZERO, pad_lo=0):
     """Implicit-GEMM conv (3x3 / 1x1).  x: (B,H,W,C0) [x2: (B,H,W,C1) concatenated after x]; returns (B,Ho,Wo,cout)
     (or (B,cout,Ho,Wo) when out_nchw).  With in_nchw, x is (B,C<=4,H,W).
     emit_stats: also write the GroupNorm(32) partial statistics of the output in the epilogue and attach them to the
     returned tensor (`._cf_stats`), so a following groupnorm_tables() does not re-read the tensor.
     x, x2 and `out` (optional destination) may be channel slices `buf[..., a:b]` of wider NHWC buffers -- the dense-block
     pattern of RRDBNet, where torch.cat never materialises; res / sft_scale (= res2 of EPI_AXPY2) then share out's stride.
-    EPI_LEAKY / EPI_AXPY / EPI_AXPY2 use sft_w as alpha (see cf_epilogue in the header)."""
+    EPI_LEAKY / EPI_AXPY / EPI_AXPY2 use sft_w as alpha (see cf_epilogue in the header).
+    pad_mode: PAD_ZERO, PAD_REFLECT (ReflectionPad2d(1) + unpadded 3x3) or PAD_EDGE (with upsample: reflection padding of the
+    upsampled image); pad_lo=1 with stride 2: one padded row / column on every side instead of right / bottom only."""
     lib = L.load()
     _f32(x)
     if in_nchw:
@@ -202,7 +204,7 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
         out_nchw=int(bool(out_nchw)), prologue=prologue, epilogue=epilogue, pro_scale=L.ptr(scale),
         pro_shift=L.ptr(shift), weight=L.ptr(pw.w), bias=L.ptr(pw.bias), res=L.ptr(res, True),
         sft_scale=L.ptr(sft_scale, True), sft_w=float(sft_w), out=L.ptr(out, not out_nchw), bf16_mfma=int(pw.bf16),
-        ld_in0=ld0, ld_in1=ld1, ld_out=ldo)
+        ld_in0=ld0, ld_in1=ld1, ld_out=ldo, pad_mode=int(pad_mode), pad_lo=int(pad_lo))
     if emit_stats and not out_nchw and pw.cout % GN_GROUPS == 0 and pw.cout // GN_GROUPS >= 2:
         d.stats_cpg = pw.cout // GN_GROUPS
         parts = lib.cf_conv2d_stats_parts(ctypes.byref(d))

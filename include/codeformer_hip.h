@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 6
+#define CF_ABI_VERSION 7
 
 typedef void* cf_stream_t; /* hipStream_t */
 
@@ -77,6 +77,14 @@ enum cf_operand {
                            with 3 more mantissa bits (conv inputs here are O(1): no range problem) */
 };
 
+/* Border handling of the 3x3 gather (general instantiations; CodeFormer itself only uses zero padding) */
+enum cf_pad {
+  CF_PAD_ZERO = 0,     /* F.conv2d(padding=1) / Downsample's F.pad(0,1,0,1) */
+  CF_PAD_REFLECT = 1,  /* nn.ReflectionPad2d(1) before an unpadded conv (facelib/parsing/parsenet.py:99,107-109) */
+  CF_PAD_EDGE = 2,     /* with `upsample`: reflection padding of the nearest-x2 image == edge replication of the source,
+                          so the folded sub-pixel kernel clamps its 2x2 footprint (parsenet.py:96-97,105-109) */
+};
+
 typedef struct cf_conv_desc {
   const float* in0;       /* first input  [batch][hin][win][c0]  (or NCHW when in_nchw) */
   const float* in1;       /* optional second input, channel-concatenated after in0      */
@@ -117,6 +125,9 @@ typedef struct cf_conv_desc {
    * >= CF_EPI_LEAKY, and output sizes that are not a multiple of the 16x16 pixel tile (edge tiles are masked)
    * select the general instantiations: 3x3 stride-1 NHWC, cout_pad 32 or 64, no statistics, fp32 or f16 operands. */
   int32_t ld_in0, ld_in1, ld_out;
+  int32_t pad_mode;       /* enum cf_pad */
+  int32_t pad_lo;         /* stride 2 only: 0 = pad right/bottom only (vqgan_arch.py:123), 1 = one row/column on every side
+                             (parsenet.py ConvLayer scale='down': ReflectionPad2d(1) + stride-2 conv); needs cout_pad % 128 == 0 */
 } cf_conv_desc;
 
 int cf_conv2d(const cf_conv_desc* d, cf_stream_t stream);

@@ -88,3 +88,13 @@ def load_reference_rrdbnet():
             del sys.modules[k]
         sys.modules.update(saved)
     return arch, esr
+
+
+def load_reference_parsenet():
+    """The reference's facelib/parsing/parsenet.py (imports only numpy + torch) as a stand-alone module."""
+    if not available():
+        raise RuntimeError(f'reference not found under {REF}')
+    spec = importlib.util.spec_from_file_location('_ref_parsenet', f'{REF}/facelib/parsing/parsenet.py')
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m

@@ -105,6 +105,15 @@ def test_inpainting_config(chk):
     assert float((logits.cpu() - torch.from_numpy(g['logits'])).abs().max()) <= 1e-4
     assert np.array_equal(net.last_indices.cpu().numpy(), g['idx'])
     assert float((out.cpu()[:, :, ::4, ::4] - torch.from_numpy(g['out_sub'])).abs().max()) <= 1e-3
+    # BASELINE config 5 names bf16: 16-bit operands in generator + CFT only -> logits bitwise those of fp32 mode, indices
+    # exact, pixels inside the gates of tools/gpu_check.py:g_bf16 (bf16 0.25 max, fp16 0.04 max on outputs of std ~0.5)
+    for prec, gate in (('bf16', 0.25), ('fp16', 0.04)):
+        net.precision = prec
+        out16, logits16, _ = net(seeded_input(1).cuda(), w=1, adain=False)
+        assert torch.equal(logits16, logits) and np.array_equal(net.last_indices.cpu().numpy(), g['idx'])
+        d = (out16 - out).abs()
+        print(f'inpainting config {prec}: max|d| {float(d.max()):.4f} mean|d| {float(d.mean()):.5f}')
+        assert float(d.max()) <= gate
 
 
 # ---- size-independent properties at BASELINE config-2 sizes (the CPU oracle is too slow there) -------------------------

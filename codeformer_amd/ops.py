@@ -63,64 +63,36 @@ def pack_weight(weight, bias=None, bf16=False, up2x=False, f16=False):
     up2x=True (3x3 only): taps folded for conv2d(upsample=True) -- nearest x2 + 3x3 as four 2x2 sub-pixel convolutions."""
     lib = L.load()
     code = 2 if f16 else int(bf16)   # callers may pass the operand code (0 fp32 / 1 bf16 / 2 f16) through `bf16`
-    f16, bf16 = code == 2, code == 1
-    if f16:
-        w = _f32(weight.detach()).contiguous()
-        cout, cin = w.shape[0], w.shape[1]
-        if w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or cin % 32:
-            raise ValueError('f16 packing needs a 3x3 weight with cin % 32 == 0')
-        cout_pad = max(64, _cout_pad(cout)) if up2x else _cout_pad(cout)
-        b = None if bias is None else _f32(bias.detach()).contiguous().clone()
-        packed = torch.empty((16 if up2x else 9) * cin * cout_pad, dtype=torch.float16, device=w.device)
-        if up2x:
-            L.check(lib.cf_pack_conv_weight_up2x_f16(L.ptr(w), cout, cin, cout_pad, cin, L.ptr(packed), L.stream_ptr()),
-                    'cf_pack_conv_weight_up2x_f16')
-        else:
-            L.check(lib.cf_pack_conv_weight_f16(L.ptr(w), cout, cin, 9, cout_pad, cin, L.ptr(packed), L.stream_ptr()),
-                    'cf_pack_conv_weight_f16')
-        return PackedWeight(packed, b, cout, cin, 9, cout_pad, cin, bf16=2, up2x=bool(up2x))
-    if up2x:
-        w = _f32(weight.detach()).contiguous()
-        cout, cin = w.shape[0], w.shape[1]
-        if w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or cin % (32 if bf16 else 16):
-            raise ValueError('up2x packing needs a 3x3 weight with cin % 16 == 0 (32 for bf16)')
-        cout_pad = max(64, _cout_pad(cout))
-        b = None if bias is None else _f32(bias.detach()).contiguous().clone()
-        if bf16:
-            packed = torch.empty(16 * cin * cout_pad, dtype=torch.bfloat16, device=w.device)
-            L.check(lib.cf_pack_conv_weight_up2x_bf16(L.ptr(w), cout, cin, cout_pad, cin, L.ptr(packed), L.stream_ptr()),
-                    'cf_pack_conv_weight_up2x_bf16')
-        else:
-            packed = torch.empty(16 * cin * cout_pad, dtype=torch.float32, device=w.device)
-            L.check(lib.cf_pack_conv_weight_up2x(L.ptr(w), cout, cin, cout_pad, cin, L.ptr(packed), L.stream_ptr()),
-                    'cf_pack_conv_weight_up2x')
-        return PackedWeight(packed, b, cout, cin, 9, cout_pad, cin, bf16=bf16, up2x=True)
-    if bf16:
-        w = _f32(weight.detach()).contiguous()
-        cout, cin = w.shape[0], w.shape[1]
-        if w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or cin % 32:
-            raise ValueError('bf16 packing needs a 3x3 weight with cin % 32 == 0')
-        cout_pad = max(64, _cout_pad(cout))
-        packed = torch.empty(9 * cin * cout_pad, dtype=torch.bfloat16, device=w.device)
-        L.check(lib.cf_pack_conv_weight_bf16(L.ptr(w), cout, cin, 9, cout_pad, cin, L.ptr(packed), L.stream_ptr()),
-                'cf_pack_conv_weight_bf16')
-        b = None if bias is None else _f32(bias.detach()).contiguous().clone()
-        return PackedWeight(packed, b, cout, cin, 9, cout_pad, cin, bf16=True)
     w = _f32(weight.detach()).contiguous()
+    b = None if bias is None else _f32(bias.detach()).contiguous().clone()
     cout, cin = w.shape[0], w.shape[1]
-    taps = 1
     if w.dim() == 4:
         if w.shape[2] != w.shape[3] or w.shape[2] not in (1, 3):
             raise ValueError(f'unsupported kernel size {tuple(w.shape[2:])}')
         taps = w.shape[2] * w.shape[3]
-    elif w.dim() != 2:
+    elif w.dim() == 2:
+        taps = 1
+    else:
         raise ValueError('weight must be 2-D or 4-D')
-    cout_pad, cin_pad = _cout_pad(cout), (cin + 15) // 16 * 16
-    packed = torch.empty(lib.cf_packed_weight_elems(cin_pad, taps, cout_pad), dtype=torch.float32, device=w.device)
-    L.check(lib.cf_pack_conv_weight(L.ptr(w), cout, cin, taps, cout_pad, cin_pad, L.ptr(packed), L.stream_ptr()),
-            'cf_pack_conv_weight')
-    b = None if bias is None else _f32(bias.detach()).contiguous().clone()
-    return PackedWeight(packed, b, cout, cin, taps, cout_pad, cin_pad)
+    if code or up2x:   # 16-bit operands and the folded upsample exist for 3x3 convs whose channels fill whole K slabs
+        slab = 32 if code else 16
+        if taps != 9 or cin % slab:
+            raise ValueError(f"{('fp32', 'bf16', 'f16')[code]}{' up2x' if up2x else ''} packing needs a 3x3 weight with "
+                             f'cin % {slab} == 0')
+    if not code and not up2x:
+        cout_pad, cin_pad = _cout_pad(cout), (cin + 15) // 16 * 16
+        packed = torch.empty(lib.cf_packed_weight_elems(cin_pad, taps, cout_pad), dtype=torch.float32, device=w.device)
+        L.check(lib.cf_pack_conv_weight(L.ptr(w), cout, cin, taps, cout_pad, cin_pad, L.ptr(packed), L.stream_ptr()),
+                'cf_pack_conv_weight')
+        return PackedWeight(packed, b, cout, cin, taps, cout_pad, cin_pad)
+    # bf16 kernels and every upsample kernel have N tiles of at least 64; the f16 general instantiation also has a 32-wide one
+    cout_pad = _cout_pad(cout) if (code == 2 and not up2x) else max(64, _cout_pad(cout))
+    dtype = (torch.float32, torch.bfloat16, torch.float16)[code]
+    packed = torch.empty((16 if up2x else 9) * cin * cout_pad, dtype=dtype, device=w.device)
+    name = 'cf_pack_conv_weight' + ('_up2x' if up2x else '') + ('', '_bf16', '_f16')[code]
+    args = (L.ptr(w), cout, cin) + (() if up2x else (9,)) + (cout_pad, cin, L.ptr(packed), L.stream_ptr())
+    L.check(getattr(lib, name)(*args), name)
+    return PackedWeight(packed, b, cout, cin, 9, cout_pad, cin, bf16=code, up2x=bool(up2x))
 
 
 def pack_weight_cat(weights, biases):

@@ -4,7 +4,8 @@
 
 A "step" is one CodeFormer.forward(x, w=0.5, adain=True) over one batch of 16 synthetic faces per GPU (config 2 of
 BASELINE.json: fp32, seeded rand(16,3,512,512)*2-1, seed-0 random-init weights unless weights/CodeFormer/codeformer.pth
-exists) followed, for N>1, by the single gather of the restored faces to rank 0.  Inputs are resident in HBM before the
+exists) followed, for N>1, by the single gather of the restored faces to rank 0 (left in flight while the next step computes;
+all K gathers are joined inside the timed region).  Inputs are resident in HBM before the
 timed region; host PNG decode/encode is outside the path and outside the timed region.  Weak scaling: 16 faces per GPU.
 
 Rank 0 prints ONE JSON line with the contract fields plus
@@ -164,18 +165,30 @@ def main():
     x = seeded_input(B, seed=1234 + rank).to(dev)     # weak scaling: every rank restores its own 16 faces
     total = B * world
 
+    # One gather is kept in flight: step i's restored faces travel to rank 0 (RCCL, its own stream) while step i+1 computes.
+    # Every gather of the timed steps is joined before the closing synchronize, so the K steps are complete inside the bracket.
+    pending = [None]
+
     def step():
-        faces, _ = parallel.restore_sharded(net, x, total, w=args.w, adain=True, dst=0)
+        handle, _ = parallel.restore_sharded_async(net, x, total, w=args.w, adain=True, dst=0)
+        prev, pending[0] = pending[0], handle
+        return prev.wait() if prev is not None else None
+
+    def drain():
+        faces = pending[0].wait() if pending[0] is not None else None
+        pending[0] = None
         return faces
 
     for _ in range(args.warmup):
         step()
+    drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -59,15 +59,35 @@ def shard(x, rank, world):
     return x[b[rank]:b[rank + 1]]
 
 
-def gather_faces(local, total, dst=0, group=None):
+class PendingGather:
+    """Handle of a gather that may still be in flight (see gather_faces(async_op=True)); wait() returns what the blocking
+    call returns: the (total, ...) tensor on the destination rank, None elsewhere."""
+
+    def __init__(self, work, finish, keep):
+        self._work, self._finish, self._keep = work, finish, keep   # keep: buffers the collective reads / writes
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()      # NCCL: the current stream waits for the collective's stream; gloo: blocks the host
+            self._work = None
+        out = self._finish() if self._finish is not None else None
+        self._finish = self._keep = None
+        return out
+
+
+def gather_faces(local, total, dst=0, group=None, async_op=False):
     """Gather per-rank outputs (n_r, ...) to `dst` in rank order with ONE collective.
 
     Shards may be uneven (shard_bounds); every rank pads to the largest shard so a plain `gather` can be used.
     Returns the (total, ...) tensor on dst, None elsewhere.
+
+    async_op=True returns a PendingGather instead: the collective is enqueued (RCCL runs it on its own stream, ordered
+    after the kernels that produced `local`) and the caller goes on launching the next batch; `wait()` later joins it.
+    A serving loop keeps one gather in flight, so the xGMI transfer of batch i overlaps the compute of batch i+1.
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
-        return local
+        return PendingGather(None, lambda: local, None) if async_op else local
     rank = dist.get_rank(group)
     bounds = shard_bounds(total, world)
     nmax = max(bounds[r + 1] - bounds[r] for r in range(world))
@@ -77,27 +97,32 @@ def gather_faces(local, total, dst=0, group=None):
         send = torch.cat([local, pad], dim=0)
     else:
         send = local.contiguous()
+    slab = work = None
     if _GATHER_IMPL[0] == 'gather':
         try:
             if rank == dst:
                 slab = torch.empty((world, nmax) + tuple(tail), dtype=local.dtype, device=local.device)
-                dist.gather(send, gather_list=list(slab.unbind(0)), dst=dst, group=group)
+                work = dist.gather(send, gather_list=list(slab.unbind(0)), dst=dst, group=group, async_op=True)
             else:
-                dist.gather(send, gather_list=None, dst=dst, group=group)
-                return None
+                work = dist.gather(send, gather_list=None, dst=dst, group=group, async_op=True)
         except (NotImplementedError, RuntimeError) as e:  # a backend without gather: every rank takes the same branch
             if 'gather' not in str(e).lower() and not isinstance(e, NotImplementedError):
                 raise
             _GATHER_IMPL[0] = 'all_gather'
     if _GATHER_IMPL[0] == 'all_gather':
         slab = torch.empty((world, nmax) + tuple(tail), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(slab.view((world * nmax,) + tuple(tail)), send, group=group)
+        work = dist.all_gather_into_tensor(slab.view((world * nmax,) + tuple(tail)), send, group=group, async_op=True)
+
+    def finish():
         if rank != dst:
             return None
-    parts = [slab[r, :bounds[r + 1] - bounds[r]] for r in range(world)]
-    if all(p.shape[0] == nmax for p in parts):
-        return slab.view((world * nmax,) + tuple(tail))
-    return torch.cat(parts, dim=0)
+        parts = [slab[r, :bounds[r + 1] - bounds[r]] for r in range(world)]
+        if all(p.shape[0] == nmax for p in parts):
+            return slab.view((world * nmax,) + tuple(tail))
+        return torch.cat(parts, dim=0)
+
+    pending = PendingGather(work, finish, (send, slab))
+    return pending if async_op else pending.wait()
 
 
 @torch.no_grad()
@@ -108,3 +133,11 @@ def restore_sharded(net, x_local, total, w=0.5, adain=True, dst=0):
     """
     out = net(x_local, w=w, adain=adain)
     return gather_faces(out[0], total, dst=dst), out
+
+
+@torch.no_grad()
+def restore_sharded_async(net, x_local, total, w=0.5, adain=True, dst=0):
+    """As restore_sharded, but the gather is left in flight: returns (PendingGather, local tuple).  Call `.wait()` on the
+    handle after launching the next batch (bench.py keeps exactly one gather pending)."""
+    out = net(x_local, w=w, adain=adain)
+    return gather_faces(out[0], total, dst=dst, async_op=True), out

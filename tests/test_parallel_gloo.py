@@ -48,11 +48,17 @@ def _worker(rank, world, port, total, q):
     x = torch.arange(total * 3 * 4 * 4, dtype=torch.float32).view(total, 3, 4, 4) / 100.0
     local = parallel.shard(x, rank, world)
     faces, out = parallel.restore_sharded(TinyNet(), local, total, w=0.5, adain=True, dst=0)
+    # the pipelined form bench.py uses: two batches, one gather in flight while the next batch is computed
+    h1, _ = parallel.restore_sharded_async(TinyNet(), local, total, w=0.5, adain=True, dst=0)
+    h2, _ = parallel.restore_sharded_async(TinyNet(), local * 2, total, w=0.25, adain=True, dst=0)
+    f1, f2 = h1.wait(), h2.wait()
     if rank == 0:
         ref = TinyNet()(x, w=0.5)[0]
-        q.put(bool(torch.equal(faces, ref)) and faces.shape[0] == total)
+        ok = bool(torch.equal(faces, ref)) and faces.shape[0] == total
+        ok = ok and bool(torch.equal(f1, ref)) and bool(torch.equal(f2, TinyNet()(x * 2, w=0.25)[0]))
+        q.put(ok)
     else:
-        assert faces is None
+        assert faces is None and f1 is None and f2 is None
     dist.barrier()
     dist.destroy_process_group()
 

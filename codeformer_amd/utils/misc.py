@@ -26,22 +26,18 @@ def _mps_available():
 
 
 def gpu_is_available():
-    if _mps_available():
-        return True
-    return bool(torch.cuda.is_available() and torch.backends.cudnn.is_available())
+    """True on Apple MPS or when torch sees a GPU with a working conv backend (MIOpen answers for cudnn on ROCm)."""
+    return _mps_available() or bool(torch.cuda.is_available() and torch.backends.cudnn.is_available())
 
 
 def get_device(gpu_id=None):
-    if gpu_id is None:
-        gpu_str = ''
-    elif isinstance(gpu_id, int):
-        gpu_str = f':{gpu_id}'
-    else:
+    """torch.device for `gpu_id` (int or None): mps > cuda (== HIP on ROCm) > cpu, as misc.py:27-47 orders them."""
+    if gpu_id is not None and not isinstance(gpu_id, int):
         raise TypeError('Input should be int value.')
+    index = '' if gpu_id is None else f':{gpu_id}'
     if _mps_available():
-        return torch.device('mps' + gpu_str)
-    # MIOpen answers for cudnn on ROCm; torch.cuda IS the HIP runtime there
-    return torch.device('cuda' + gpu_str if torch.cuda.is_available() and torch.backends.cudnn.is_available() else 'cpu')
+        return torch.device(f'mps{index}')
+    return torch.device(f'cuda{index}' if gpu_is_available() else 'cpu')
 
 
 def set_random_seed(seed):
@@ -77,8 +73,10 @@ def scandir(dir_path, suffix=None, recursive=False, full_path=False):
 
 
 def sizeof_fmt(size, suffix='B'):
-    for unit in ['', 'K', 'M', 'G', 'T', 'P', 'E', 'Z']:
-        if abs(size) < 1024.0:
-            return f'{size:3.1f} {unit}{suffix}'
+    """Human-readable byte count with binary prefixes ('1.5 KB')."""
+    units = ('', 'K', 'M', 'G', 'T', 'P', 'E', 'Z', 'Y')
+    i = 0
+    while abs(size) >= 1024.0 and i < len(units) - 1:
         size /= 1024.0
-    return f'{size:3.1f} Y{suffix}'
+        i += 1
+    return f'{size:3.1f} {units[i]}{suffix}'

@@ -1,51 +1,45 @@
-"""Name -> class registries (API of the reference's basicsr/utils/registry.py:4-82).
+"""Name -> class tables: the plugin boundary of the reference (basicsr/utils/registry.py:4-82).
 
-`ARCH_REGISTRY.get('CodeFormer')` is the plugin boundary the reference's entrypoints use
-(inference_codeformer.py:135); behaviour kept: duplicate registration asserts, unknown name raises KeyError.
+`ARCH_REGISTRY.get('CodeFormer')` is how the reference's entrypoints obtain the network class (inference_codeformer.py:135).
+Behaviour kept from the reference: registering a name twice is an AssertionError, looking up an unknown name is a KeyError
+with the same message, `register` works both as a decorator factory and as a plain call.
 """
 
 
 class Registry:
+    """A named dict of callables keyed by their `__name__`."""
 
     def __init__(self, name):
-        self._name = name
-        self._obj_map = {}
+        self.name = name
+        self.table = {}
 
-    def _do_register(self, name, obj):
-        assert name not in self._obj_map, (f"An object named '{name}' was already registered "
-                                           f"in '{self._name}' registry!")
-        self._obj_map[name] = obj
+    def _add(self, thing):
+        key = thing.__name__
+        assert key not in self.table, f"An object named '{key}' was already registered in '{self.name}' registry!"
+        self.table[key] = thing
+        return thing
 
     def register(self, obj=None):
-        """Use as `@REG.register()` or `REG.register(obj)`; the key is `obj.__name__`."""
-        if obj is not None:
-            self._do_register(obj.__name__, obj)
-            return None
-
-        def decorator(target):
-            self._do_register(target.__name__, target)
-            return target
-
-        return decorator
+        """`@REG.register()` above a class / function, or `REG.register(obj)` directly (returns None in that form)."""
+        if obj is None:
+            return self._add
+        self._add(obj)
 
     def get(self, name):
-        try:
-            return self._obj_map[name]
-        except KeyError:
-            raise KeyError(f"No object named '{name}' found in '{self._name}' registry!") from None
+        if name not in self.table:
+            raise KeyError(f"No object named '{name}' found in '{self.name}' registry!")
+        return self.table[name]
 
     def __contains__(self, name):
-        return name in self._obj_map
+        return name in self.table
 
     def __iter__(self):
-        return iter(self._obj_map.items())
+        return iter(self.table.items())
 
     def keys(self):
-        return self._obj_map.keys()
+        return self.table.keys()
 
 
-DATASET_REGISTRY = Registry('dataset')
 ARCH_REGISTRY = Registry('arch')
-MODEL_REGISTRY = Registry('model')
-LOSS_REGISTRY = Registry('loss')
-METRIC_REGISTRY = Registry('metric')
+# the reference also instantiates these (training-side plugins; nothing registers into them here)
+DATASET_REGISTRY, MODEL_REGISTRY, LOSS_REGISTRY, METRIC_REGISTRY = (Registry(n) for n in ('dataset', 'model', 'loss', 'metric'))

@@ -130,10 +130,11 @@ class Fuse_sft_block(HipModule):
 
     def forward_nhwc(self, enc, dec, w=1, bf16=False):
         e = self.encode_enc.forward_nhwc(enc, dec, bf16=bf16)
-        s = ops.conv2d(e, self._pw_conv(self.scale[0], bf16))
-        s = ops.conv2d(s, self._pw_conv(self.scale[2], bf16), prologue=PRO_LEAKY)
-        h = ops.conv2d(e, self._pw_conv(self.shift[0], bf16))
-        return ops.conv2d(h, self._pw_conv(self.shift[2], bf16), prologue=PRO_LEAKY, epilogue=EPI_SFT, res=dec, sft_scale=s,
+        hw = e.shape[1:3]
+        s = ops.conv2d(e, self._pw_conv(self.scale[0], bf16, hw=hw))
+        s = ops.conv2d(s, self._pw_conv(self.scale[2], bf16, hw=hw), prologue=PRO_LEAKY)
+        h = ops.conv2d(e, self._pw_conv(self.shift[0], bf16, hw=hw))
+        return ops.conv2d(h, self._pw_conv(self.shift[2], bf16, hw=hw), prologue=PRO_LEAKY, epilogue=EPI_SFT, res=dec, sft_scale=s,
                           sft_w=float(w), emit_stats=True)
 
     def forward(self, enc_feat, dec_feat, w=1):
@@ -162,6 +163,11 @@ class CodeFormer(VQAutoEncoder):
         # operands with fp32 accumulate; encoder, Transformer and the code argmax stay fp32 so the indices stay exact.
         # 'fp16': the same split with IEEE-half operands (same speed, 3 more mantissa bits: ~8x smaller pixel error).
         self.precision = os.environ.get('CODEFORMER_HIP_PRECISION', 'fp32')
+        # fp32 mode: evaluate the generator + CFT 3x3 stride-1 convolutions with Winograd F(2x2,3x3) -- the same function in fp32
+        # with 2.25x fewer multiplies (cf_winograd.hip).  Encoder / Transformer / argmax stay on the direct kernel, so logits and
+        # code indices are bitwise those of the direct mode; pixels move by ~1e-5 (tolerance 1e-3).  Set False (or
+        # CODEFORMER_HIP_WINOGRAD=0) for the direct evaluation everywhere.
+        self.winograd = os.environ.get('CODEFORMER_HIP_WINOGRAD', '1') != '0'
         # Optional HIP-graph replay of the whole forward (one graph per input shape / w / flags): takes the ~250 host launches
         # per call off the critical path.  Measured: no gain at B=1..16 on an otherwise idle host (the kernels, not the launches,
         # bound even B=1), so it is off by default; useful when the host thread is busy (decode / encode of PNGs).
@@ -220,7 +226,9 @@ class CodeFormer(VQAutoEncoder):
 
         if self.precision not in ('fp32', 'bf16', 'fp16'):
             raise ValueError(f"precision must be 'fp32', 'bf16' or 'fp16', got {self.precision!r}")
-        bf16 = {'fp32': 0, 'bf16': 1, 'fp16': 2}[self.precision]   # MFMA operand code of the generator + CFT 3x3 convs
+        bf16 = {'fp32': 0, 'bf16': 1, 'fp16': 2}[self.precision]   # operand code of the generator + CFT 3x3 convs
+        if bf16 == 0 and self.winograd:
+            bf16 = ops.WINOGRAD
         gen_taps = None
         if w > 0:
             def fuse(t):
@@ -265,7 +273,7 @@ class CodeFormer(VQAutoEncoder):
     def _forward_graphed(self, x, w, code_only, adain):
         """Capture-once / replay-many execution of _forward_hip on the current stream.  Outputs are copies, so callers may
         keep them across calls.  A graph is re-captured when any packed weight was rebuilt since its capture."""
-        key = (tuple(x.shape), float(w), bool(code_only), bool(adain), self.precision, str(x.device))
+        key = (tuple(x.shape), float(w), bool(code_only), bool(adain), self.precision, bool(self.winograd), str(x.device))
         ent = self._graphs.get(key)
         if ent is None or ent['epoch'] != PACK_EPOCH[0]:
             static_x = x.float().contiguous().clone()

@@ -30,9 +30,13 @@ class HipModule(nn.Module):
             PACK_EPOCH[0] += 1
         return ent[1]
 
-    def _pw_conv(self, name, bf16=False, up2x=False, f16=False):
+    def _pw_conv(self, name, bf16=False, up2x=False, f16=False, hw=None):
         conv = getattr(self, name) if isinstance(name, str) else name
-        code = 2 if f16 else int(bf16)   # MFMA operand format: 0 fp32, 1 bf16, 2 IEEE half (`bf16` may carry the code)
+        code = 2 if f16 else int(bf16)   # 0 fp32, 1 bf16, 2 IEEE half operands, 3 fp32 Winograd (`bf16` may carry the code)
+        if code == ops.WINOGRAD:         # needs the output size (`hw`); shapes the Winograd kernel does not cover run direct
+            cout, cin = conv.weight.shape[:2]
+            if up2x or hw is None or tuple(conv.weight.shape[2:]) != (3, 3) or not ops.winograd_ok(cin, cout, hw[0], hw[1]):
+                code = 0
         key = (name if isinstance(name, str) else id(conv), code, bool(up2x))
         return self._packed(key, lambda: ops.pack_weight(conv.weight, conv.bias, bf16=code, up2x=up2x), conv.weight, conv.bias)
 

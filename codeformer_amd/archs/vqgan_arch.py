@@ -153,13 +153,14 @@ class ResBlock(HipModule):
         """bf16=True: both 3x3 convs run on bf16 MFMA operands (fp32 accumulate / storage); the 1x1 skip stays fp32."""
         xs = (x,) if x2 is None else (x, x2)
         sc, sh = _gn_tables(self.norm1, *xs)
-        h = ops.conv2d(x, self._pw_conv('conv1', bf16), x2=x2, prologue=PRO_AFFINE_SWISH, scale=sc, shift=sh, emit_stats=True)
+        hw = x.shape[1:3]
+        h = ops.conv2d(x, self._pw_conv('conv1', bf16, hw=hw), x2=x2, prologue=PRO_AFFINE_SWISH, scale=sc, shift=sh, emit_stats=True)
         sc, sh = _gn_tables(self.norm2, h)
         if self.in_channels != self.out_channels:
             skip = ops.conv2d(x, self._pw_conv('conv_out'), x2=x2)
         else:
             skip = x
-        return ops.conv2d(h, self._pw_conv('conv2', bf16), prologue=PRO_AFFINE_SWISH, scale=sc, shift=sh,
+        return ops.conv2d(h, self._pw_conv('conv2', bf16, hw=hw), prologue=PRO_AFFINE_SWISH, scale=sc, shift=sh,
                           epilogue=EPI_RESIDUAL, res=skip, emit_stats=True)
 
     def forward_host(self, x_in):
@@ -223,8 +224,13 @@ class _Conv3x3(HipModule):
                             self.bias)
 
     def forward_nhwc(self, x, bf16=False, **kw):
-        ok16 = self.in_channels % 32 == 0 and self.out_channels % 4 == 0 and not kw.get('out_nchw') and not kw.get('in_nchw')
-        return ops.conv2d(x, self.pw(int(bf16) if ok16 else 0), **kw)   # bf16 carries the operand code (0 / 1 bf16 / 2 f16)
+        plain = not kw.get('out_nchw') and not kw.get('in_nchw')
+        code = int(bf16)                 # operand code: 0 fp32 / 1 bf16 / 2 f16 / 3 fp32 Winograd
+        if code == ops.WINOGRAD:
+            code = code if plain and ops.winograd_ok(self.in_channels, self.out_channels, x.shape[1], x.shape[2]) else 0
+        elif not (plain and self.in_channels % 32 == 0 and self.out_channels % 4 == 0):
+            code = 0
+        return ops.conv2d(x, self.pw(code), **kw)
 
     def forward_host(self, x):
         return F.conv2d(x, self.weight, self.bias, stride=1, padding=1)

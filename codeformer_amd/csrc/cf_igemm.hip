@@ -1102,6 +1102,8 @@ extern "C" int cf_pack_conv_weight(const float* w, int cout, int cin, int taps, 
   return CF_OK;
 }
 
+int cf_winograd_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query);  // cf_winograd.hip
+
 static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
   CF_REQUIRE(d, "cf_conv2d: null descriptor");
   CF_REQUIRE(pq || (d->in0 && d->weight && d->out), "cf_conv2d: null in0/weight/out");
@@ -1175,6 +1177,8 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
   CF_REQUIRE(!(d->out_nchw && (d->taps != 9 || d->epilogue != CF_EPI_NONE)), "cf_conv2d: out_nchw needs 3x3, no epilogue");
   CF_REQUIRE(d->cout_pad >= d->cout && d->cout_pad % 32 == 0, "cf_conv2d: cout_pad %d invalid for cout %d", d->cout_pad,
              d->cout);
+
+  if (d->winograd) return cf_winograd_launch(d, stream, pq);
 
   ConvArgsExt a;
   a.in0 = d->in0;

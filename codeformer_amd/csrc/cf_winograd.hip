@@ -1,0 +1,509 @@
+// Winograd F(2x2, 3x3) convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32) for gfx950.
+//
+// For a 3x3 stride-1 convolution (vqgan_arch.py:147-164 ResBlock convs, codeformer_arch.py:142-156 fusion convs) each 2x2
+// block of outputs is   Y = A^T [ (G g G^T) (.) (B^T d B) ] A   with d the 4x4 input patch, g the 3x3 kernel and
+//   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]   A^T = [1 1 1 0; 0 1 -1 -1]
+// so the contraction over input channels becomes 16 independent GEMMs (one per position (xi, nu) of the 4x4 transform domain)
+//   M[xi,nu][tile][n] = sum_c V[xi,nu][tile][c] * U[xi,nu][c][n]
+// with 16 instead of 36 multiplies per 2x2 outputs: 2.25x fewer MFMA cycles than the direct implicit GEMM (cf_igemm.hip),
+// which already runs at the clock-limited MFMA rate.  All arithmetic is fp32; this is an exact algebraic identity evaluated
+// in a different order (error vs fp64 about 3x that of the direct kernel), used for the generator / fusion convolutions only:
+// encoder and Transformer stay on the direct kernel, so logits and code indices are bitwise unchanged.
+//
+// Work decomposition (256 threads = 4 waves):
+//   * a workgroup owns an 8x16 output patch of ONE image (32 Winograd tiles) x 64 output channels;
+//   * per 16-channel K slab the 10x18 halo patch is gathered into LDS once -- GroupNorm-apply/swish or LeakyReLU prologue,
+//     channel concat and zero padding resolved in the gather exactly as in cf_igemm.hip -- and transformed IN LDS to
+//     V[16 positions][32 tiles][16 ch] (thread = (tile, channel quad, half of the xi rows): 12 ds_read_b128, 16 vector adds,
+//     8 ds_write_b128);
+//   * wave xi (0..3) owns the four positions (xi, 0..3): per position a 32(tiles) x 64(n) accumulator = 2 MFMA tiles, 128
+//     accumulator registers per lane in total.  A fragments come from V in LDS; B fragments (the transformed weights
+//     U[pos][slab][n][16]) are used by exactly one wave, so they go global/L2 -> registers directly, issued at the top of the
+//     slab iteration and consumed after the gather-store and transform phases have covered their latency;
+//   * two barriers per slab (patch visible / V visible); two workgroups per CU (55 KB LDS, <= 256 registers) overlap one
+//     workgroup's gather + transform with the other's MFMA phase;
+//   * epilogue: each wave contracts its own nu axis in registers (R[xi][b] = M[xi][.] A), the xi axis is contracted across waves
+//     through LDS, then thread = (tile, channel quad) holds the 2x2 output pixels as float4s and applies bias / residual / SFT,
+//     16-byte stores, and the GroupNorm statistics of what it wrote (fp64 partials, fixed shuffle order) like cf_igemm.hip.
+#include <type_traits>
+
+#include "cf_common.h"
+
+// CF_WABLATE: timing-only ablation builds (tools/ab_variants.sh); 0 / undefined in every product build.
+#ifndef CF_WABLATE
+#define CF_WABLATE 0
+#endif
+#ifndef CF_WINO_GROUPS
+#define CF_WINO_GROUPS 1     // 1: one four-wave group per workgroup, two workgroups per CU ; 2: ping-pong pair (see the kernel)
+#endif
+
+namespace {
+
+constexpr int WG_TH = 8, WG_TW = 16;                      // output patch of a workgroup
+constexpr int WG_PH = WG_TH + 2, WG_PW = WG_TW + 2;       // halo patch 10 x 18
+constexpr int WG_NPIX = WG_PH * WG_PW;                    // 180
+constexpr int WG_NT = (WG_TH / 2) * (WG_TW / 2);          // 32 Winograd tiles = one MFMA row tile
+constexpr int WG_NI = 2;                                  // 32-channel MFMA tiles per consumer wave
+constexpr int WG_BN = WG_NI * 32;                         // output channels per workgroup (64)
+constexpr int WG_PATCH_FLOATS = 192 * CF_LDK;             // 3840: 180 halo pixels, padded to 3 x 64 so the gather-store needs no guard
+// Floats between consecutive positions of V: 32 rows of 20 floats + 4 floats of padding.  4*PS*4 B = 64 (mod 256), so the four
+// xi rows written by neighbouring lanes of the transform land in distinct 64-byte bank groups (unpadded they all aliased).
+constexpr int WG_PS = WG_NT * CF_LDK + 4;                 // 644
+constexpr int WG_V_FLOATS = 16 * WG_PS;                   // 10304
+constexpr int WG_RLD = 36;                                // epilogue staging row: 32 channels + 4 pad (144 B, 16 B aligned)
+constexpr int WG_R_FLOATS = 8 * WG_NT * WG_RLD;           // 9216 <= WG_V_FLOATS (staging reuses the V region)
+static_assert(WG_R_FLOATS <= WG_V_FLOATS, "epilogue staging must fit the V region");
+
+struct WinoArgs {
+  const float* in0;
+  const float* in1;
+  int c0, c1, cin, nchunks;
+  int batch, h, w;
+  int cout, cout_pad;
+  int prologue, epilogue;
+  const float* pro_scale;
+  const float* pro_shift;
+  const float* weight;  // [16 pos][nchunks][cout_pad][16]
+  const float* bias;
+  const float* res;
+  const float* sft_scale;
+  float sft_w;
+  float* out;
+  double* stats_out;
+  int stats_cpg, nparts;
+  int tiles_x, tiles_per_img, ntn;
+};
+
+__device__ __forceinline__ f32x4 v4add(f32x4 a, f32x4 b) { return a + b; }
+__device__ __forceinline__ f32x4 v4sub(f32x4 a, f32x4 b) { return a - b; }
+
+// Eight waves per workgroup = two groups of four waves, each group computing its OWN 8x16 output patch (two neighbouring
+// patches of one image, same 64 output channels) with its own LDS patch / V buffers.  Inside a group, wave xi owns the four
+// transform-domain positions (xi, 0..3) x 64 channels = 128 accumulator registers, and every wave also does its share of the
+// gather / prologue / transform work.  A slab takes four time slots, separated by workgroup barriers:
+//     slot 0: gather-store (prologue) -> patch      slot 2: MFMA positions nu 0,1
+//     slot 1: transform patch -> V                  slot 3: MFMA positions nu 2,3
+// and group 1 runs two slots behind group 0 ("ping-pong"): whenever one group is in its MFMA slots the other is in its
+// VALU / LDS slots, and wave w of group 0 shares a SIMD with wave w of group 1 -- so every SIMD always has one MFMA stream and
+// one VALU / LDS stream.  (Symmetric co-resident workgroups running this sequence fall into lock step -- MFMA phases together,
+// VALU phases together -- and the phase costs add up instead of overlapping: measured, 1.88 ms = 1.27 + 0.61.)
+// G = 2: the ping-pong pair described above (one workgroup per CU).  G = 1: a single group per workgroup, two barriers per slab,
+// two independent workgroups per CU.
+template <int G>
+__global__ __launch_bounds__(256 * G, 2) void winograd_kernel(const WinoArgs a) {
+  constexpr int NI = WG_NI;
+  constexpr int GT = 256;                                        // threads per group
+  constexpr int APT = (WG_NPIX * 4 + GT - 1) / GT;               // float4 gather items per thread (3)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int grp = wave >> 2;
+  const int xi = wave & 3;
+  const int gtid = tid & (GT - 1);
+  const int half = lane >> 5;
+  const int l31 = lane & 31;
+  float* const patch = smem + grp * (WG_PATCH_FLOATS + WG_V_FLOATS);
+  float* const V = patch + WG_PATCH_FLOATS;
+
+  int bid = blockIdx.x;
+  {  // XCD-contiguous tile order (see cf_igemm.hip)
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int nt = bid % a.ntn;
+  const int mt = (bid / a.ntn) * G + grp;  // this group's output patch (G = 2: tiles_per_img is even, both belong to one image)
+  const int n0 = nt * WG_BN;
+  const int b = mt / a.tiles_per_img;
+  const int rt = mt - b * a.tiles_per_img;
+  const int tyw = rt / a.tiles_x;
+  const int y0 = tyw * WG_TH;
+  const int x0 = (rt - tyw * a.tiles_x) * WG_TW;
+  const int n = a.nchunks;
+
+  // ---- gather geometry: item j of this thread is float4 #k4 of halo pixel p = (gtid>>2) + 64*j ----
+  const int k4 = gtid & 3;
+  int pix[APT];
+#pragma unroll
+  for (int j = 0; j < APT; ++j) {
+    const int p = (gtid >> 2) + 64 * j;
+    int v = -1;
+    if (p < WG_NPIX) {
+      const int hy = p / WG_PW;
+      const int hx = p - hy * WG_PW;
+      const int iy = y0 - 1 + hy;
+      const int ix = x0 - 1 + hx;
+      if (iy >= 0 && iy < a.h && ix >= 0 && ix < a.w) v = (b * a.h + iy) * a.w + ix;
+    }
+    pix[j] = v;
+  }
+  // unconditional loads from clamped addresses (a load under a divergent branch is waited for on the spot); out-of-image
+  // items are zeroed in store_patch -- touching the value here would make the wave wait for the fetch right away
+  // The GroupNorm scale / shift rows of the slab travel with the activations (fetched a slab ahead): loading them inside
+  // store_patch put an s_waitcnt vmcnt(0) there, which also drained the weight fragments requested just before.
+  const bool affine = a.prologue == CF_PRO_AFFINE || a.prologue == CF_PRO_AFFINE_SWISH;
+  const float* const tab_sc = affine ? a.pro_scale + (size_t)b * a.cin : a.weight;  // (any valid address when unused)
+  const float* const tab_sh = affine ? a.pro_shift + (size_t)b * a.cin : a.weight;
+  f32x4 rsc, rsh;
+  auto load_A = [&](int chunk, f32x4(&ra)[APT]) {
+    const int c = chunk * CF_BK + k4 * 4;
+    rsc = *reinterpret_cast<const f32x4*>(tab_sc + (affine ? c : 0));
+    rsh = *reinterpret_cast<const f32x4*>(tab_sh + (affine ? c : 0));
+    const bool first = c < a.c0;
+    const float* src = first ? a.in0 : a.in1;
+    const int cs = first ? a.c0 : a.c1;
+    const int cc = first ? c : c - a.c0;
+#pragma unroll
+    for (int j = 0; j < APT; ++j) {
+      const int pj = pix[j] < 0 ? 0 : pix[j];
+      ra[j] = *reinterpret_cast<const f32x4*>(src + (size_t)pj * cs + cc);
+    }
+  };
+  // prologue + write to the LDS patch; zero padding stays exactly zero (it pads the post-activation tensor)
+  auto store_patch_mode = [&](const f32x4(&ra)[APT], int chunk, auto mode) {
+    constexpr int PRO = decltype(mode)::value;
+    const f32x4 sc = rsc, sh = rsh;  // (fetched with the activations; only read by the affine modes)
+#pragma unroll
+    for (int j = 0; j < APT; ++j) {
+      const int p = (gtid >> 2) + 64 * j;  // (p >= 180: padding rows of the patch buffer, written as zeros -- no branch)
+      {
+        const bool valid = pix[j] >= 0;
+        f32x4 v = ra[j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float y = v[e];
+          if (PRO == CF_PRO_AFFINE) y = y * sc[e] + sh[e];
+          if (PRO == CF_PRO_AFFINE_SWISH) {
+            y = y * sc[e] + sh[e];
+            y = y * __frcp_rn(1.0f + __expf(-y));  // same hardware exp / rcp swish as the direct kernel
+          }
+          if (PRO == CF_PRO_LEAKY) y = y > 0.f ? y : 0.2f * y;
+          v[e] = valid ? y : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(patch + p * CF_LDK + k4 * 4) = v;
+      }
+    }
+  };
+  auto store_patch = [&](const f32x4(&ra)[APT], int chunk) {
+    switch (a.prologue) {
+      case CF_PRO_AFFINE: store_patch_mode(ra, chunk, std::integral_constant<int, CF_PRO_AFFINE>{}); break;
+      case CF_PRO_AFFINE_SWISH: store_patch_mode(ra, chunk, std::integral_constant<int, CF_PRO_AFFINE_SWISH>{}); break;
+      case CF_PRO_LEAKY: store_patch_mode(ra, chunk, std::integral_constant<int, CF_PRO_LEAKY>{}); break;
+      default: store_patch_mode(ra, chunk, std::integral_constant<int, CF_PRO_NONE>{}); break;
+    }
+  };
+  // input transform: item -> (tile, channel quad, xi row): 8 ds_read_b128, 8 vector adds, 4 ds_write_b128; 2 items per thread
+  auto transform = [&]() {
+#pragma unroll
+    for (int it = gtid; it < 512; it += GT) {
+      const int t_c4 = it & 3, t_xi = (it >> 2) & 3, t_tile = it >> 4;
+      const int t_ty = t_tile >> 3, t_tx = t_tile & 7;  // tile = ty*8 + tx, outputs (2ty..2ty+1, 2tx..2tx+1) of the patch
+      // B^T d along rows: xi0 = r0 - r2, xi1 = r1 + r2, xi2 = r2 - r1, xi3 = r1 - r3  ->  two patch rows per item, combined
+      // as sa*ra + sb*rb with sa, sb = +-1 (exact): a per-lane choice of add / sub compiled into divergent branches with an
+      // LDS wait inside each, which serialised the eight reads of an item
+      const int ra_ = t_xi == 0 ? 0 : 1, rb_ = t_xi == 3 ? 3 : 2;
+      const float sa = t_xi == 2 ? -1.f : 1.f, sb = (t_xi == 1 || t_xi == 2) ? 1.f : -1.f;
+      const float* pa = patch + ((2 * t_ty + ra_) * WG_PW + 2 * t_tx) * CF_LDK + t_c4 * 4;
+      const float* pb = patch + ((2 * t_ty + rb_) * WG_PW + 2 * t_tx) * CF_LDK + t_c4 * 4;
+      f32x4 t[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 da = *reinterpret_cast<const f32x4*>(pa + c * CF_LDK);
+        const f32x4 db = *reinterpret_cast<const f32x4*>(pb + c * CF_LDK);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[c][e] = __fmaf_rn(db[e], sb, da[e] * sa);
+      }
+      // (.) B along columns: nu0 = t0 - t2, nu1 = t1 + t2, nu2 = t2 - t1, nu3 = t1 - t3
+      float* vo = V + t_xi * 4 * WG_PS + t_tile * CF_LDK + t_c4 * 4;  // position (xi, nu = 0)
+      *reinterpret_cast<f32x4*>(vo + 0 * WG_PS) = v4sub(t[0], t[2]);
+      *reinterpret_cast<f32x4*>(vo + 1 * WG_PS) = v4add(t[1], t[2]);
+      *reinterpret_cast<f32x4*>(vo + 2 * WG_PS) = v4sub(t[2], t[1]);
+      *reinterpret_cast<f32x4*>(vo + 3 * WG_PS) = v4sub(t[1], t[3]);
+    }
+  };
+
+  f32x16 acc[4][NI];  // [nu][n tile]
+#pragma unroll
+  for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nu][ni][r] = 0.f;
+
+  // this lane's B fragments.  The packed weights are stored in MFMA-operand order,
+  //   U[pos = xi*4 + nu][chunk][n tile of 32][kg][lane][4]  (element = U[n = tile*32 + (lane & 31)][k = kg*8 + (lane >> 5)*4 + e]),
+  // so every fragment load of a wave is one contiguous 1 KB block; they go global/L2 -> registers (each is used by one wave).
+  const size_t pos_stride = (size_t)n * a.cout_pad * CF_BK;
+  const float* const wlane = a.weight + (size_t)(xi * 4) * pos_stride + (size_t)(n0 / 32) * 512 + lane * 4;
+  const float* const alane = V + (xi * 4) * WG_PS + l31 * CF_LDK + half * 4;
+  f32x4 bq[4][NI][2];
+  auto load_B = [&](int chunk, int nu) {
+    const float* wc = wlane + (size_t)chunk * a.cout_pad * CF_BK + nu * pos_stride;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) bq[nu][ni][kg] = *reinterpret_cast<const f32x4*>(wc + ni * 512 + kg * 256);
+  };
+  auto mma = [&](int nu) {
+    f32x4 aq[2];
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) aq[kg] = *reinterpret_cast<const f32x4*>(alane + nu * WG_PS + kg * 8);
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[nu][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[kg][j], bq[nu][ni][kg][j], acc[nu][ni], 0, 0, 0);
+  };
+
+  f32x4 ra[APT];
+  load_A(0, ra);
+  if (G == 2 && grp == 1) {  // group 1 starts two slots late
+    __syncthreads();
+    __syncthreads();
+  }
+  for (int chunk = 0; chunk < n; ++chunk) {
+    // slot 0: gather-store.  Weight fragments of positions nu 0,1 are requested first: two slots of cover.
+    load_B(chunk, 0);
+    load_B(chunk, 1);
+    __builtin_amdgcn_sched_barrier(0);  // keep the fetches up here (hipcc would sink them next to their first use)
+#if CF_WABLATE != 2 && CF_WABLATE != 7
+    store_patch(ra, chunk);
+#endif
+    __syncthreads();
+    // slot 1: next slab's activations are requested (a whole slab of cover), then the transform
+    load_A(chunk + 1 < n ? chunk + 1 : chunk, ra);  // unconditional (clamped): a load under a branch makes hipcc drain vmcnt
+    __builtin_amdgcn_sched_barrier(0);
+#if CF_WABLATE != 1 && CF_WABLATE != 7
+    transform();
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    load_B(chunk, 2);  // the transform's registers are free again; consumed two barriers later
+    load_B(chunk, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    // slot 2
+#if CF_WABLATE != 3
+    mma(0);
+    mma(1);
+#endif
+    if (G == 2) __syncthreads();
+    // slot 3
+#if CF_WABLATE != 3
+    mma(2);
+    mma(3);
+#endif
+    if (G == 2) __syncthreads();  // (G = 1: the barrier after the next gather-store separates these reads of V from its rewrite)
+  }
+  if (G == 2 && grp == 0) {
+    __syncthreads();
+    __syncthreads();
+  }
+  if (G == 1) __syncthreads();  // V reads retired before it becomes the staging buffer
+
+  // ---- epilogue (both groups, each for its own patch) ------------------------------------------------------------------------
+  // NI passes of 32 channels: every wave contracts its nu axis in registers and stages R[xi][bb] in its group's (idle) V
+  // buffer; then item = (tile, output column bb, channel quad) contracts xi and owns two output pixels (rows aa = 0, 1).
+  float* const R = V;  // [(xi*2 + bb)][tile][WG_RLD]
+#pragma unroll
+  for (int pass = 0; pass < NI; ++pass) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float m0 = acc[0][pass][r], m1 = acc[1][pass][r], m2 = acc[2][pass][r], m3 = acc[3][pass][r];
+      const int row = cf_acc_row(r, lane);
+      R[((xi * 2 + 0) * WG_NT + row) * WG_RLD + l31] = (m0 + m1) + m2;  // nu axis: R[xi][0] = M0 + M1 + M2
+      R[((xi * 2 + 1) * WG_NT + row) * WG_RLD + l31] = (m1 - m2) - m3;  //          R[xi][1] = M1 - M2 - M3
+    }
+    __syncthreads();
+    const int e_n4 = gtid & 7;  // (the item stride is a multiple of 8: both items of a thread have the same channel quad)
+    const int nn = n0 + pass * 32 + e_n4 * 4;
+    const bool nvalid = nn < a.cout;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias && nvalid) bias4 = *reinterpret_cast<const f32x4*>(a.bias + nn);
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = gtid; it < 512; it += GT) {
+      const int e_bb = (it >> 3) & 1, e_tile = it >> 4;
+      const int e_ty = e_tile >> 3, e_tx = e_tile & 7;
+      f32x4 x[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        x[q] = *reinterpret_cast<const f32x4*>(R + ((q * 2 + e_bb) * WG_NT + e_tile) * WG_RLD + e_n4 * 4);
+      f32x4 o[2];
+      o[0] = v4add(v4add(x[0], x[1]), x[2]);  // xi axis: Y[0][bb] = R0 + R1 + R2 ; Y[1][bb] = R1 - R2 - R3
+      o[1] = v4sub(v4sub(x[1], x[2]), x[3]);
+#pragma unroll
+      for (int aa = 0; aa < 2; ++aa) {
+        const size_t pixel = ((size_t)b * a.h + (y0 + 2 * e_ty + aa)) * a.w + (x0 + 2 * e_tx + e_bb);
+        const size_t off = pixel * a.cout + nn;
+        if (nvalid) {
+          f32x4 v = o[aa];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bias4[e];
+          if (a.epilogue == CF_EPI_RESIDUAL) {
+            const f32x4 rr = *reinterpret_cast<const f32x4*>(a.res + off);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += rr[e];
+          } else if (a.epilogue == CF_EPI_SFT) {
+            const f32x4 dec = *reinterpret_cast<const f32x4*>(a.res + off);
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.sft_scale + off);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = dec[e] + a.sft_w * (dec[e] * sc[e] + v[e]);
+          }
+          *reinterpret_cast<f32x4*>(a.out + off) = v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            ssum[e] += v[e];
+            ssq[e] += v[e] * v[e];
+          }
+        }
+      }
+    }
+    if (a.stats_out) {
+      // GroupNorm statistics of the values just written (fp64 partials, fixed shuffle order): one partial per
+      // (image, group, output patch, wave of its group) -- nparts = tiles_per_img * 4
+      const int cpg = a.stats_cpg;
+      double d0, q0, d1 = 0, q1 = 0;
+      if (cpg == 2) {
+        d0 = (double)ssum[0] + ssum[1];
+        q0 = (double)ssq[0] + ssq[1];
+        d1 = (double)ssum[2] + ssum[3];
+        q1 = (double)ssq[2] + ssq[3];
+      } else {
+        d0 = ((double)ssum[0] + ssum[1]) + ((double)ssum[2] + ssum[3]);
+        q0 = ((double)ssq[0] + ssq[1]) + ((double)ssq[2] + ssq[3]);
+      }
+      for (int o = 8; o < 64; o <<= 1) {  // the (tile, bb) items of this wave: lanes with the same channel quad
+        d0 += __shfl_xor(d0, o, 64);
+        q0 += __shfl_xor(q0, o, 64);
+        d1 += __shfl_xor(d1, o, 64);
+        q1 += __shfl_xor(q1, o, 64);
+      }
+      for (int o = 1; o * 4 < cpg; o <<= 1) {  // adjacent channel quads of one group (cpg >= 8)
+        d0 += __shfl_xor(d0, o, 64);
+        q0 += __shfl_xor(q0, o, 64);
+      }
+      if ((lane >> 3) == 0 && nvalid && (nn % cpg) == 0) {
+        const size_t pidx = (size_t)rt * 4 + xi;
+        const int ng = a.cout / cpg;
+        double* o = a.stats_out + (((size_t)b * ng + nn / cpg) * a.nparts + pidx) * 2;
+        o[0] = d0;
+        o[1] = q0;
+        if (cpg == 2) {
+          o[(size_t)a.nparts * 2] = d1;
+          o[(size_t)a.nparts * 2 + 1] = q1;
+        }
+      }
+    }
+    __syncthreads();  // staging is rewritten by the next 32 channels
+  }
+}
+
+// U = G g G^T per (n, c), evaluated in fp64 and rounded once, stored in MFMA-operand order
+// [pos][cin_pad/16][cout_pad/32][kg 2][lane 64][4]: element = U[n = tile*32 + (lane&31)][c = chunk*16 + kg*8 + (lane>>5)*4 + e]
+__global__ void pack_weight_winograd_kernel(const float* __restrict__ w, int cout, int cin, int cout_pad, int nchunks,
+                                            float* __restrict__ packed, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int e = (int)(i & 3), ln = (int)((i >> 2) & 63), kg = (int)((i >> 8) & 1);
+  long r = i >> 9;
+  const int ntiles = cout_pad / 32;
+  const int n = (int)(r % ntiles) * 32 + (ln & 31);
+  r /= ntiles;
+  const int chunk = (int)(r % nchunks);
+  const int pos = (int)(r / nchunks);
+  const int c = chunk * CF_BK + kg * 8 + (ln >> 5) * 4 + e;
+  float val = 0.f;
+  if (n < cout && c < cin) {
+    const float* g = w + ((long)n * cin + c) * 9;
+    const int xi = pos >> 2, nu = pos & 3;
+    // row xi of G g : combination of the three kernel rows
+    double row[3];
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+      const double g0 = g[x], g1 = g[3 + x], g2 = g[6 + x];
+      row[x] = xi == 0 ? g0 : (xi == 1 ? 0.5 * (g0 + g1 + g2) : (xi == 2 ? 0.5 * (g0 - g1 + g2) : g2));
+    }
+    const double u = nu == 0 ? row[0] : (nu == 1 ? 0.5 * (row[0] + row[1] + row[2]) : (nu == 2 ? 0.5 * (row[0] - row[1] + row[2]) : row[2]));
+    val = (float)u;
+  }
+  packed[i] = val;
+}
+
+}  // namespace
+
+extern "C" int cf_pack_conv_weight_winograd(const float* w, int cout, int cin, int cout_pad, int cin_pad, float* packed,
+                                            cf_stream_t stream) {
+  CF_REQUIRE(w && packed, "cf_pack_conv_weight_winograd: null pointer");
+  CF_REQUIRE(cin_pad % CF_BK == 0 && cin_pad >= cin && cout_pad >= cout && cout_pad % 64 == 0,
+             "cf_pack_conv_weight_winograd: bad padding cin %d->%d cout %d->%d", cin, cin_pad, cout, cout_pad);
+  const long total = 16L * cin_pad * cout_pad;
+  hipLaunchKernelGGL(pack_weight_winograd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
+                     cout, cin, cout_pad, cin_pad / CF_BK, packed, total);
+  CF_CHECK_LAUNCH("cf_pack_conv_weight_winograd");
+  return CF_OK;
+}
+
+// Called by cf_conv2d (cf_igemm.hip) for descriptors with winograd != 0; the common argument checks have run there.
+int cf_winograd_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query) {
+  CF_REQUIRE(d->taps == 9 && d->stride == 1 && !d->upsample && !d->in_nchw && !d->out_nchw && d->bf16_mfma == CF_OPERAND_F32,
+             "cf_conv2d: winograd covers fp32 3x3 stride-1 NHWC convolutions");
+  CF_REQUIRE(d->hout % WG_TH == 0 && d->wout % WG_TW == 0, "cf_conv2d: winograd needs an output of %dx%d multiples (got %dx%d)",
+             WG_TH, WG_TW, d->hout, d->wout);
+  CF_REQUIRE(d->cout_pad % 64 == 0 && d->cout % 4 == 0, "cf_conv2d: winograd needs cout_pad %% 64 == 0 and cout %% 4 == 0");
+  CF_REQUIRE(d->epilogue == CF_EPI_NONE || d->epilogue == CF_EPI_RESIDUAL || d->epilogue == CF_EPI_SFT,
+             "cf_conv2d: winograd epilogues are none / residual / SFT");
+  CF_REQUIRE(d->pad_mode == CF_PAD_ZERO && (d->ld_in0 == 0 || d->ld_in0 == d->c0) && (d->ld_in1 == 0 || d->ld_in1 == d->c1) &&
+                 (d->ld_out == 0 || d->ld_out == d->cout),
+             "cf_conv2d: winograd reads / writes dense tensors with zero padding");
+  WinoArgs a;
+  a.in0 = d->in0;
+  a.in1 = d->in1;
+  a.c0 = d->c0;
+  a.c1 = d->c1;
+  a.cin = d->c0 + d->c1;
+  a.nchunks = a.cin / CF_BK;
+  a.batch = d->batch;
+  a.h = d->hout;
+  a.w = d->wout;
+  a.cout = d->cout;
+  a.cout_pad = d->cout_pad;
+  a.prologue = d->prologue;
+  a.epilogue = d->epilogue;
+  a.pro_scale = d->pro_scale;
+  a.pro_shift = d->pro_shift;
+  a.weight = d->weight;
+  a.bias = d->bias;
+  a.res = d->res;
+  a.sft_scale = d->sft_scale;
+  a.sft_w = d->sft_w;
+  a.out = d->out;
+  a.stats_out = d->stats_out;
+  a.stats_cpg = d->stats_cpg > 0 ? d->stats_cpg : 1;
+  a.tiles_x = d->wout / WG_TW;
+  a.tiles_per_img = a.tiles_x * (d->hout / WG_TH);
+  constexpr int G = CF_WINO_GROUPS;
+  CF_REQUIRE(a.tiles_per_img % G == 0, "cf_conv2d: winograd pairs 8x16 output patches (got %d per image)", a.tiles_per_img);
+  a.nparts = a.tiles_per_img * 4;
+  a.ntn = d->cout_pad / WG_BN;
+  if (parts_query) {
+    *parts_query = a.nparts;
+    return CF_OK;
+  }
+  constexpr size_t lds = G * (WG_PATCH_FLOATS + WG_V_FLOATS) * sizeof(float);
+  static bool attr_set = false;  // benign race: the attribute call is idempotent
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) {
+      cf_set_error("cf_conv2d: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+      return CF_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(winograd_kernel<G>, dim3(a.tiles_per_img / G * d->batch * a.ntn), dim3(256 * G), lds, stream, a);
+  CF_CHECK_LAUNCH("cf_conv2d(winograd)");
+  return CF_OK;
+}

@@ -41,11 +41,11 @@ class PackedWeight:
     """A conv / linear weight in the kernel layout [tap][cin_pad/16][cout_pad][16] (+ bias).
     `bf16` is the operand code of cf_conv_desc.bf16_mfma: 0 / False fp32, 1 / True bf16, 2 IEEE half."""
 
-    __slots__ = ('w', 'bias', 'cout', 'cin', 'taps', 'cout_pad', 'cin_pad', 'bf16', 'up2x')
+    __slots__ = ('w', 'bias', 'cout', 'cin', 'taps', 'cout_pad', 'cin_pad', 'bf16', 'up2x', 'wino')
 
-    def __init__(self, w, bias, cout, cin, taps, cout_pad, cin_pad, bf16=False, up2x=False):
+    def __init__(self, w, bias, cout, cin, taps, cout_pad, cin_pad, bf16=False, up2x=False, wino=False):
         self.w, self.bias, self.cout, self.cin, self.taps = w, bias, cout, cin, taps
-        self.cout_pad, self.cin_pad, self.bf16, self.up2x = cout_pad, cin_pad, bf16, up2x
+        self.cout_pad, self.cin_pad, self.bf16, self.up2x, self.wino = cout_pad, cin_pad, bf16, up2x, wino
 
 
 def _cout_pad(cout):
@@ -56,16 +56,32 @@ def _cout_pad(cout):
     return (cout + 127) // 128 * 128
 
 
+WINOGRAD = 3   # value of the operand-code argument that selects the Winograd F(2x2,3x3) fp32 evaluation
+
+
+def winograd_ok(cin, cout, hout, wout):
+    """Shapes the Winograd kernel covers (3x3 stride-1 dense NHWC): an even number of whole 8x16 output patches per image,
+    64-wide channel tiles."""
+    return cin % 16 == 0 and cout % 64 == 0 and hout % 8 == 0 and wout % 16 == 0 and ((hout // 8) * (wout // 16)) % 2 == 0
+
+
 def pack_weight(weight, bias=None, bf16=False, up2x=False, f16=False):
     """weight: (cout, cin, 3, 3) | (cout, cin, 1, 1) | (cout, cin) CUDA fp32 -> PackedWeight.
     bf16=True (3x3 only, cin % 32 == 0): bf16 operands for the v_mfma_f32_32x32x16_bf16 path of cf_conv2d.
     f16=True (3x3 only, cin % 32 == 0): IEEE-half operands (general instantiations; RRDBNet's half mode).
     up2x=True (3x3 only): taps folded for conv2d(upsample=True) -- nearest x2 + 3x3 as four 2x2 sub-pixel convolutions."""
     lib = L.load()
-    code = 2 if f16 else int(bf16)   # callers may pass the operand code (0 fp32 / 1 bf16 / 2 f16) through `bf16`
+    code = 2 if f16 else int(bf16)   # callers may pass the operand code (0 fp32 / 1 bf16 / 2 f16 / 3 winograd) through `bf16`
     w = _f32(weight.detach()).contiguous()
     b = None if bias is None else _f32(bias.detach()).contiguous().clone()
     cout, cin = w.shape[0], w.shape[1]
+    if code == WINOGRAD:
+        if up2x or w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or cin % 16 or cout % 64:
+            raise ValueError('winograd packing needs a 3x3 weight with cin % 16 == 0 and cout % 64 == 0 (no up2x)')
+        packed = torch.empty(16 * cin * cout, dtype=torch.float32, device=w.device)
+        L.check(lib.cf_pack_conv_weight_winograd(L.ptr(w), cout, cin, cout, cin, L.ptr(packed), L.stream_ptr()),
+                'cf_pack_conv_weight_winograd')
+        return PackedWeight(packed, b, cout, cin, 9, cout, cin, wino=True)
     if w.dim() == 4:
         if w.shape[2] != w.shape[3] or w.shape[2] not in (1, 3):
             raise ValueError(f'unsupported kernel size {tuple(w.shape[2:])}')
@@ -176,7 +192,7 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
         out_nchw=int(bool(out_nchw)), prologue=prologue, epilogue=epilogue, pro_scale=L.ptr(scale),
         pro_shift=L.ptr(shift), weight=L.ptr(pw.w), bias=L.ptr(pw.bias), res=L.ptr(res, True),
         sft_scale=L.ptr(sft_scale, True), sft_w=float(sft_w), out=L.ptr(out, not out_nchw), bf16_mfma=int(pw.bf16),
-        ld_in0=ld0, ld_in1=ld1, ld_out=ldo, pad_mode=int(pad_mode), pad_lo=int(pad_lo))
+        ld_in0=ld0, ld_in1=ld1, ld_out=ldo, pad_mode=int(pad_mode), pad_lo=int(pad_lo), winograd=int(pw.wino))
     if emit_stats and not out_nchw and pw.cout % GN_GROUPS == 0 and pw.cout // GN_GROUPS >= 2:
         d.stats_cpg = pw.cout // GN_GROUPS
         parts = lib.cf_conv2d_stats_parts(ctypes.byref(d))
@@ -193,10 +209,12 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
     L.check(lib.cf_conv2d(ctypes.byref(d), L.stream_ptr()), 'cf_conv2d')
     e1.record()
     cin = c0 + c1
-    flops = 2.0 * B * Ho * Wo * pw.cout * cin * (4 if upsample else pw.taps)   # executed MACs (folded taps for up2x)
+    flops = 2.0 * B * Ho * Wo * pw.cout * cin * (4 if upsample else pw.taps)   # executed MACs (folded taps for up2x); Winograd
+    # launches are booked at the direct convolution's 9 taps (the algorithmic work), not at their 4 MFMA multiplies per output
     nbytes = 4.0 * (x.numel() + (0 if x2 is None else x2.numel()) + pw.cout * cin * pw.taps + out.numel()
                     + (0 if res is None else res.numel()) + (0 if sft_scale is None else sft_scale.numel()))
-    kind = ('conv3x3_s2' if stride == 2 else ('conv_up2x' if upsample else 'conv3x3')) if pw.taps == 9 else 'gemm1x1'
+    kind = ('conv3x3_s2' if stride == 2 else ('conv_up2x' if upsample else ('conv3x3_wino' if pw.wino else 'conv3x3'))) \
+        if pw.taps == 9 else 'gemm1x1'
     PROFILE.append((kind, flops, nbytes, e0, e1, (B, H, W, cin, pw.cout)))
     return out
 

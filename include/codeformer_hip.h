@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 7
+#define CF_ABI_VERSION 8
 
 typedef void* cf_stream_t; /* hipStream_t */
 
@@ -128,6 +128,12 @@ typedef struct cf_conv_desc {
   int32_t pad_mode;       /* enum cf_pad */
   int32_t pad_lo;         /* stride 2 only: 0 = pad right/bottom only (vqgan_arch.py:123), 1 = one row/column on every side
                              (parsenet.py ConvLayer scale='down': ReflectionPad2d(1) + stride-2 conv); needs cout_pad % 128 == 0 */
+  int32_t winograd;       /* 1: Winograd F(2x2,3x3) evaluation of a 3x3 stride-1 convolution: `weight` comes from
+                             cf_pack_conv_weight_winograd (U = G g G^T), 16 instead of 36 multiplies per 2x2 outputs, all in fp32 --
+                             the same function in a different summation order (error ~3x the direct kernel's).  Dense NHWC
+                             tensors, zero padding, hout % 8 == 0, wout % 16 == 0, cout_pad % 64 == 0; prologues as the direct
+                             kernel, epilogues none / residual / SFT, statistics supported.  Used for generator / fusion
+                             convolutions only (encoder + Transformer stay direct: logits and code indices unchanged) */
 } cf_conv_desc;
 
 int cf_conv2d(const cf_conv_desc* d, cf_stream_t stream);
@@ -139,6 +145,9 @@ int cf_conv2d_stats_parts(const cf_conv_desc* d);
 int cf_pack_conv_weight(const float* w, int cout, int cin, int taps, int cout_pad, int cin_pad,
                         float* packed, cf_stream_t stream);
 int64_t cf_packed_weight_elems(int cin_pad, int taps, int cout_pad);
+/* Winograd-domain weights for cf_conv_desc.winograd: [16 positions][cin_pad/16][cout_pad][16] fp32 (16*cin_pad*cout_pad values),
+ * U[xi*4+nu] = (G g G^T)[xi][nu] evaluated in fp64 and rounded once; cout_pad % 64 == 0 */
+int cf_pack_conv_weight_winograd(const float* w, int cout, int cin, int cout_pad, int cin_pad, float* packed, cf_stream_t stream);
 /* bf16 layout [tap][cin_pad/32][cout_pad][32] (round-to-nearest-even); cin_pad % 32 == 0, cout_pad % 64 == 0; the buffer
  * holds cf_packed_weight_elems(cin_pad, taps, cout_pad) bf16 values (half the bytes of the fp32 packing). */
 int cf_pack_conv_weight_bf16(const float* w, int cout, int cin, int taps, int cout_pad, int cin_pad, void* packed,

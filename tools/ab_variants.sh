@@ -7,7 +7,7 @@ if [ "$1" = build ]; then
   for spec in "$@"; do
     name=${spec%%:*}; flags=${spec#*:}
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $flags -Iinclude -Icodeformer_amd/csrc \
-      -o gpurun_ablate/lib_$name.so codeformer_amd/csrc/cf_igemm.hip codeformer_amd/csrc/cf_norm.hip \
+      -o gpurun_ablate/lib_$name.so codeformer_amd/csrc/cf_igemm.hip codeformer_amd/csrc/cf_winograd.hip codeformer_amd/csrc/cf_norm.hip \
       codeformer_amd/csrc/cf_attention.hip codeformer_amd/csrc/cf_misc.hip &
   done; wait; ls gpurun_ablate
 else

@@ -168,6 +168,11 @@ class CodeFormer(VQAutoEncoder):
         # code indices are bitwise those of the direct mode; pixels move by ~1e-5 (tolerance 1e-3).  Set False (or
         # CODEFORMER_HIP_WINOGRAD=0) for the direct evaluation everywhere.
         self.winograd = os.environ.get('CODEFORMER_HIP_WINOGRAD', '1') != '0'
+        # Also evaluate the ENCODER's 3x3 stride-1 convolutions with Winograd, in every precision mode (the encoder is always
+        # fp32, so logits / indices stay bitwise identical across 'fp32' / 'bf16' / 'fp16').  Measured against the reference:
+        # logits 4.3e-6 (direct kernel 5.5e-6), lq_feat 1.0e-5 (1.4e-5), indices exact on every seeded face incl. one whose
+        # top-2 gap is 1.7e-5 -- the Winograd form sums fewer products per output and is, if anything, the more accurate one.
+        self.winograd_encoder = os.environ.get('CODEFORMER_HIP_WINOGRAD_ENCODER', '1') != '0'
         # Optional HIP-graph replay of the whole forward (one graph per input shape / w / flags): takes the ~250 host launches
         # per call off the critical path.  Measured: no gain at B=1..16 on an otherwise idle host (the kernels, not the launches,
         # bound even B=1), so it is off by default; useful when the host thread is busy (decode / encode of PNGs).
@@ -205,7 +210,8 @@ class CodeFormer(VQAutoEncoder):
         enc_feat = {}
         enc_taps = {self.fuse_encoder_block[f]: (lambda t: enc_feat.__setitem__(str(t.shape[2]), t))
                     for f in self.connect_list}
-        lq = self.encoder.forward_nhwc(x, enc_taps)                       # (B,16,16,256) channels-last
+        enc_code = ops.WINOGRAD if (self.winograd and self.winograd_encoder) else 0
+        lq = self.encoder.forward_nhwc(x, enc_taps, bf16=enc_code)        # (B,16,16,256) channels-last
         T = lq.shape[1] * lq.shape[2]
         tokens = lq.view(B * T, lq.shape[3])
 
@@ -273,7 +279,7 @@ class CodeFormer(VQAutoEncoder):
     def _forward_graphed(self, x, w, code_only, adain):
         """Capture-once / replay-many execution of _forward_hip on the current stream.  Outputs are copies, so callers may
         keep them across calls.  A graph is re-captured when any packed weight was rebuilt since its capture."""
-        key = (tuple(x.shape), float(w), bool(code_only), bool(adain), self.precision, bool(self.winograd), str(x.device))
+        key = (tuple(x.shape), float(w), bool(code_only), bool(adain), self.precision, bool(self.winograd), bool(self.winograd_encoder), str(x.device))
         ent = self._graphs.get(key)
         if ent is None or ent['epoch'] != PACK_EPOCH[0]:
             static_x = x.float().contiguous().clone()

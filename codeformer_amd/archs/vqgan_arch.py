@@ -316,9 +316,11 @@ class Encoder(HipModule):
         with torch.no_grad():
             return ops.to_nchw(self.forward_nhwc(x.float().contiguous()))
 
-    def forward_nhwc(self, x_nchw, taps=None):
-        """x_nchw: the (B,3,H,W) network input (read directly by the first conv); returns NHWC."""
-        return _run_blocks_nhwc(self.blocks, x_nchw, taps, first_nchw=True)
+    def forward_nhwc(self, x_nchw, taps=None, bf16=False):
+        """x_nchw: the (B,3,H,W) network input (read directly by the first conv); returns NHWC.
+        bf16: operand code for the 3x3 convs (only 0 = direct fp32 or ops.WINOGRAD = fp32 Winograd make sense here: the code
+        indices depend on the encoder)."""
+        return _run_blocks_nhwc(self.blocks, x_nchw, taps, first_nchw=True, bf16=bf16)
 
     def forward_host(self, x):
         for blk in self.blocks:

@@ -9,10 +9,12 @@ all K gathers are joined inside the timed region).  Inputs are resident in HBM b
 timed region; host PNG decode/encode is outside the path and outside the timed region.  Weak scaling: 16 faces per GPU.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline:     dominant kernel = the 3x3 implicit-GEMM convolution (95 % of the FLOPs, compute-bound in fp32:
-                AI ~ 233 FLOP/B vs ridge ~ 20).  achieved = algorithmic FLOPs of all 3x3 launches of one forward
-                (2*B*Ho*Wo*Cout*Cin*9 each) / their summed durations, measured live with events on the launch stream;
-                peak = 157.3 TFLOP/s (fp32 MFMA, MI355X_MICROARCH.md).
+  roofline:     dominant kernel = the 3x3 stride-1 convolution (95 % of the FLOPs, compute-bound in fp32: AI ~ 233 FLOP/B vs
+                ridge ~ 20), evaluated as Winograd F(2x2,3x3) on fp32 MFMA (winograd_kernel; the direct implicit GEMM keeps the
+                shapes Winograd does not cover and is reported under roofline.direct_kernel).  achieved = algorithmic FLOPs of
+                those launches of one forward (2*B*Ho*Wo*Cout*Cin*9 each) / their summed durations, measured live with events
+                on the launch stream; `executed` = the 4/9 of them the MFMA pipe really performs; peak = 157.3 TFLOP/s (fp32
+                MFMA, MI355X_MICROARCH.md).
   cpu_baseline: the CPU oracle (oracle/codeformer_oracle.py, torch CPU fp32, all host threads) timed on a bounded sample
                 (batch-1 forwards for ~10-30 s) on rank 0 at N=1.
 """
@@ -51,11 +53,11 @@ def build_net(device):
     return net.to(device), sd_cpu, weights
 
 
-def recorded_traffic():
+def recorded_traffic(prefix='igemm_kernel<9, 1'):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_bench.json,
     produced by tools/pmc_bench.sh on this same bench step; bench.py cannot profile itself).  Per the MI355X guide:
     FETCH_SIZE / WRITE_SIZE are in KiB, and on gfx950 FETCH_SIZE reports half of the bytes of wide (16 B/lane) reads, so
-    bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024, launch-weighted over every 3x3 stride-1 instantiation."""
+    bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024, launch-weighted over the kernels whose name starts with `prefix`."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_bench.json')))
     if not files:
@@ -63,7 +65,7 @@ def recorded_traffic():
     d = json.load(open(files[-1]))
     n = tot = 0
     for k, v in d.items():
-        if k.startswith('igemm_kernel<9, 1') and 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
+        if k.startswith(prefix) and 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
             ln = v['FETCH_SIZE']['launches']
             n += ln
             tot += ln * (2.0 * v['FETCH_SIZE']['mean'] + v['WRITE_SIZE']['mean']) * 1024.0
@@ -100,23 +102,32 @@ def roofline_leg(net, x, w):
     table['by_shape (kind,B,H,W,Cin,Cout): launches, ms_total, TFLOP/s'] = {
         str(k): [v[2] // reps, round(v[1] / reps * 1e3, 3), round(v[0] / v[1] / 1e12, 1)]
         for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1])}
-    c = agg['conv3x3']
-    achieved = c[0] / c[2] / 1e12
-    roof = {'bound': 'mfma', 'kernel': 'igemm_kernel<9,1,...> (3x3 s1 implicit GEMM, fp32 MFMA)', 'achieved': round(achieved, 2),
-            'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-            'traffic': recorded_traffic(), 'alg_bytes_per_launch': round(c[1] / c[3]), 'avg_launch_ms': round(c[2] / c[3] * 1e3, 4), 'launches_per_step': c[3] // reps,
-            'gflop_per_step': round(c[0] / reps / 1e9, 1), 'ms_per_step': round(c[2] / reps * 1e3, 2)}
-    w = agg.get('conv3x3_wino')
-    if w:
-        # The generator / fusion 3x3 convolutions run as Winograd F(2x2,3x3): `achieved` books the ALGORITHMIC work (the direct
-        # convolution's 9 MACs per weight and output) and may therefore exceed the MFMA peak; `executed` is what the MFMA pipe
-        # really does (16 multiplies per 2x2 outputs = 4/9 of it) and is the figure to hold against the peak.
-        wa = w[0] / w[2] / 1e12
-        roof['winograd'] = {'bound': 'mfma', 'kernel': 'winograd_kernel (F(2x2,3x3), fp32 MFMA)', 'achieved': round(wa, 2),
-                            'executed': round(wa * 4.0 / 9.0, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                            'frac': round(wa / FP32_MFMA_PEAK_TFLOPS, 4), 'frac_executed': round(wa * 4.0 / 9.0 / FP32_MFMA_PEAK_TFLOPS, 4),
-                            'avg_launch_ms': round(w[2] / w[3] * 1e3, 4), 'launches_per_step': w[3] // reps,
-                            'gflop_per_step': round(w[0] / reps / 1e9, 1), 'ms_per_step': round(w[2] / reps * 1e3, 2)}
+    def entry(kind, name, executed_ratio):
+        c = agg[kind]
+        ach = c[0] / c[2] / 1e12
+        e = {'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+             'frac': round(ach / FP32_MFMA_PEAK_TFLOPS, 4), 'avg_launch_ms': round(c[2] / c[3] * 1e3, 4),
+             'launches_per_step': c[3] // reps, 'gflop_per_step': round(c[0] / reps / 1e9, 1), 'ms_per_step': round(c[2] / reps * 1e3, 2),
+             'alg_bytes_per_launch': round(c[1] / c[3])}
+        if executed_ratio != 1.0:
+            e['executed'] = round(ach * executed_ratio, 2)
+            e['frac_executed'] = round(ach * executed_ratio / FP32_MFMA_PEAK_TFLOPS, 4)
+        return e
+    direct = entry('conv3x3', 'igemm_kernel<9,1,...> (direct 3x3 s1 implicit GEMM, fp32 MFMA)', 1.0)
+    direct['traffic'] = recorded_traffic()
+    if 'conv3x3_wino' in agg and agg['conv3x3_wino'][2] > agg['conv3x3'][2]:
+        # Dominant kernel = the Winograd F(2x2,3x3) evaluation of the 3x3 stride-1 convolutions.  `achieved` books the ALGORITHMIC
+        # work of each launch (the convolution's 2*9*Cin*Cout FLOPs per output pixel) and can therefore exceed the
+        # MFMA peak; `executed` = the multiplies the MFMA pipe really performs (16 per 2x2 outputs = 4/9 of that) is the figure to
+        # hold against the peak.
+        roof = entry('conv3x3_wino', 'winograd_kernel (3x3 s1 as Winograd F(2x2,3x3), fp32 MFMA)', 4.0 / 9.0)
+        roof['traffic'] = recorded_traffic('winograd_kernel')   # null until a PMC pass of this kernel is committed
+        roof['direct_kernel'] = direct
+    else:
+        roof = direct
+    # executed (MFMA-issued) FLOPs of one step over every dense contraction + the attention matmuls (2.01 GF / face)
+    exec_flops = sum(v[0] * (4.0 / 9.0 if k == 'conv3x3_wino' else 1.0) for k, v in agg.items()) / reps + 2.01e9 * x.shape[0]
+    roof['executed_gflop_per_face_whole_path'] = round(exec_flops / x.shape[0] / 1e9, 2)
     return roof, table
 
 
@@ -229,6 +240,10 @@ def main():
         if not args.no_roofline and args.precision == 'fp32':
             roof, table = roofline_leg(net, x, args.w)
             line['roofline'] = roof
+            ex = roof.pop('executed_gflop_per_face_whole_path')      # measured: overrides the static direct-kernel estimate
+            line['whole_path']['executed_gflop_per_face'] = ex
+            line['whole_path']['executed_tflops_fp32'] = round(faces_per_s * ex / 1e3, 2)
+            line['whole_path']['frac_fp32_mfma_peak'] = round(faces_per_s * ex / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world), 4)
             if args.details:
                 print(json.dumps(table, indent=1), file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:

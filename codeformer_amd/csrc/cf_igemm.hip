@@ -1160,10 +1160,10 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
              "cf_conv2d: reflect padding is for plain 3x3 convs on images of at least 2x2");
   CF_REQUIRE(d->pad_mode != CF_PAD_EDGE || d->upsample, "cf_conv2d: edge padding belongs to the folded upsample conv");
   CF_REQUIRE(d->pad_lo == 0 || d->stride == 2, "cf_conv2d: pad_lo applies to stride 2");
-  const bool ext = ld0 != d->c0 || ld1 != d->c1 || ldo != d->cout || d->epilogue >= CF_EPI_LEAKY ||
+  const bool ext = !d->winograd && (ld0 != d->c0 || ld1 != d->c1 || ldo != d->cout || d->epilogue >= CF_EPI_LEAKY ||
                    ((d->pad_mode != CF_PAD_ZERO || d->pad_lo) && !(d->out_nchw && d->cout <= 4)) ||
                    (d->bf16_mfma == CF_OPERAND_F16 && d->cout_pad % 64 != 0) ||
-                   (d->taps == 9 && d->stride == 1 && !d->in_nchw && !few_cout && (d->hout % 16 != 0 || d->wout % 16 != 0));
+                   (d->taps == 9 && d->stride == 1 && !d->in_nchw && !few_cout && (d->hout % 16 != 0 || d->wout % 16 != 0)));
   if (ext) {
     CF_REQUIRE(d->taps == 9 && (d->stride == 1 || (d->bf16_mfma == CF_OPERAND_F32 && d->cout_pad % 128 == 0)) && !d->in_nchw &&
                    !d->out_nchw && d->bf16_mfma != CF_OPERAND_BF16 && !d->stats_out &&

@@ -6,25 +6,37 @@
 // so the contraction over input channels becomes 16 independent GEMMs (one per position (xi, nu) of the 4x4 transform domain)
 //   M[xi,nu][tile][n] = sum_c V[xi,nu][tile][c] * U[xi,nu][c][n]
 // with 16 instead of 36 multiplies per 2x2 outputs: 2.25x fewer MFMA cycles than the direct implicit GEMM (cf_igemm.hip),
-// which already runs at the clock-limited MFMA rate.  All arithmetic is fp32; this is an exact algebraic identity evaluated
-// in a different order (error vs fp64 about 3x that of the direct kernel), used for the generator / fusion convolutions only:
-// encoder and Transformer stay on the direct kernel, so logits and code indices are bitwise unchanged.
+// whose main loop already runs at the clock-limited MFMA rate.  All arithmetic is fp32; this is an exact algebraic identity
+// evaluated in a different order.  Measured against fp64 its error is BELOW the direct kernel's (1-6e-6 vs 2-14e-6 on O(5)
+// outputs: fewer products are summed per output), so it is used for every eligible 3x3 stride-1 convolution of the network,
+// encoder included (logits 4.7e-6 / indices exact against the reference).
 //
-// Work decomposition (256 threads = 4 waves):
+// Work decomposition (256 threads = 4 waves, two workgroups per CU):
 //   * a workgroup owns an 8x16 output patch of ONE image (32 Winograd tiles) x 64 output channels;
 //   * per 16-channel K slab the 10x18 halo patch is gathered into LDS once -- GroupNorm-apply/swish or LeakyReLU prologue,
 //     channel concat and zero padding resolved in the gather exactly as in cf_igemm.hip -- and transformed IN LDS to
-//     V[16 positions][32 tiles][16 ch] (thread = (tile, channel quad, half of the xi rows): 12 ds_read_b128, 16 vector adds,
-//     8 ds_write_b128);
+//     V[16 positions][32 tiles][16 ch] (item = (tile, channel quad, xi row): 8 ds_read_b128, 8 vector ops, 4 ds_write_b128);
 //   * wave xi (0..3) owns the four positions (xi, 0..3): per position a 32(tiles) x 64(n) accumulator = 2 MFMA tiles, 128
-//     accumulator registers per lane in total.  A fragments come from V in LDS; B fragments (the transformed weights
-//     U[pos][slab][n][16]) are used by exactly one wave, so they go global/L2 -> registers directly, issued at the top of the
-//     slab iteration and consumed after the gather-store and transform phases have covered their latency;
-//   * two barriers per slab (patch visible / V visible); two workgroups per CU (55 KB LDS, <= 256 registers) overlap one
-//     workgroup's gather + transform with the other's MFMA phase;
+//     accumulator registers per lane in total.  A fragments come from V in LDS; B fragments (the transformed weights, packed in
+//     MFMA-operand order so that a fragment load is one contiguous 1 KB block) are used by exactly one wave and go
+//     global/L2 -> registers directly;
+//   * two barriers per slab (patch visible / V visible);
 //   * epilogue: each wave contracts its own nu axis in registers (R[xi][b] = M[xi][.] A), the xi axis is contracted across waves
-//     through LDS, then thread = (tile, channel quad) holds the 2x2 output pixels as float4s and applies bias / residual / SFT,
-//     16-byte stores, and the GroupNorm statistics of what it wrote (fp64 partials, fixed shuffle order) like cf_igemm.hip.
+//     through LDS, then item = (tile, output column, channel quad) holds two output pixels as float4s and applies bias /
+//     residual / SFT, 16-byte stores, and the GroupNorm statistics of what it wrote (fp64 partials, fixed shuffle order).
+//
+// What the measurements said (interleaved ablations, tools/wino_ab.py; 128->128 @ 256x256 x16: direct 2.31 ms, this 1.58 ms):
+//   * fp32 MFMA and fp32 VALU do NOT overlap on this part -- the fp32 matrix peak equals the fp32 vector peak because it is the
+//     same FMA hardware.  MFMA-only, everything-else-only and the full kernel came out additive (1.35 + 0.55 = 1.90) even in a
+//     ping-pong variant (G = 2 below) that pins one MFMA wave and one VALU wave on every SIMD; so every VALU instruction of the
+//     gather / transform / epilogue is paid for in full, and what helped was removing instructions and stalls:
+//   * the per-lane add / sub choice of the transform compiled into divergent branches with an LDS wait in each (now sign
+//     multipliers, branch-free); the GroupNorm scale / shift rows loaded inside the gather-store put an s_waitcnt vmcnt(0) there
+//     that also drained the weight fragments just requested (now fetched a slab ahead with the activations); the guard on the
+//     third gather item was a branch (the patch buffer is padded to 192 pixels instead); touching the prefetched activations
+//     (zero-fill select) right after the load made the wave wait for HBM (the select moved to the store): 2.45 -> 1.58 ms;
+//   * producer / consumer wave specialisation (4 MFMA waves + 4 gather / transform waves) was slower (2.7 ms): four waves alone
+//     cannot hide the LDS / transcendental latencies of the A-side work.
 #include <type_traits>
 
 #include "cf_common.h"
@@ -77,18 +89,11 @@ struct WinoArgs {
 __device__ __forceinline__ f32x4 v4add(f32x4 a, f32x4 b) { return a + b; }
 __device__ __forceinline__ f32x4 v4sub(f32x4 a, f32x4 b) { return a - b; }
 
-// Eight waves per workgroup = two groups of four waves, each group computing its OWN 8x16 output patch (two neighbouring
-// patches of one image, same 64 output channels) with its own LDS patch / V buffers.  Inside a group, wave xi owns the four
-// transform-domain positions (xi, 0..3) x 64 channels = 128 accumulator registers, and every wave also does its share of the
-// gather / prologue / transform work.  A slab takes four time slots, separated by workgroup barriers:
-//     slot 0: gather-store (prologue) -> patch      slot 2: MFMA positions nu 0,1
-//     slot 1: transform patch -> V                  slot 3: MFMA positions nu 2,3
-// and group 1 runs two slots behind group 0 ("ping-pong"): whenever one group is in its MFMA slots the other is in its
-// VALU / LDS slots, and wave w of group 0 shares a SIMD with wave w of group 1 -- so every SIMD always has one MFMA stream and
-// one VALU / LDS stream.  (Symmetric co-resident workgroups running this sequence fall into lock step -- MFMA phases together,
-// VALU phases together -- and the phase costs add up instead of overlapping: measured, 1.88 ms = 1.27 + 0.61.)
-// G = 2: the ping-pong pair described above (one workgroup per CU).  G = 1: a single group per workgroup, two barriers per slab,
-// two independent workgroups per CU.
+// One group of four waves computes one 8x16 output patch (see the file header).  G = 1 (shipped): a workgroup is one group,
+// two barriers per slab, two independent workgroups per CU.  G = 2 (kept as a documented experiment, CF_WINO_GROUPS=2): a
+// workgroup holds two groups working on neighbouring patches with group 1 running two barrier slots behind group 0 ("ping-pong":
+// slot 0 gather-store, slot 1 transform, slots 2-3 MFMA), so that every SIMD always has one MFMA wave and one VALU / LDS wave;
+// it measured 1.90 ms against 1.58 ms for G = 1 because the two streams share the fp32 FMA hardware instead of overlapping.
 template <int G>
 __global__ __launch_bounds__(256 * G, 2) void winograd_kernel(const WinoArgs a) {
   constexpr int NI = WG_NI;

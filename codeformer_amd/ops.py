@@ -60,9 +60,8 @@ WINOGRAD = 3   # value of the operand-code argument that selects the Winograd F(
 
 
 def winograd_ok(cin, cout, hout, wout):
-    """Shapes the Winograd kernel covers (3x3 stride-1 dense NHWC): an even number of whole 8x16 output patches per image,
-    64-wide channel tiles."""
-    return cin % 16 == 0 and cout % 64 == 0 and hout % 8 == 0 and wout % 16 == 0 and ((hout // 8) * (wout // 16)) % 2 == 0
+    """Shapes the Winograd kernel covers (3x3 stride-1 dense NHWC): whole 8x16 output patches, 64-wide channel tiles."""
+    return cin % 16 == 0 and cout % 64 == 0 and hout % 8 == 0 and wout % 16 == 0
 
 
 def pack_weight(weight, bias=None, bf16=False, up2x=False, f16=False):

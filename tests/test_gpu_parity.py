@@ -234,3 +234,39 @@ def test_code_only_and_vqautoencoder_module_api(chk):
     with torch.no_grad():
         ref = vq.generator(zq.cpu())                        # host (stock torch) generator on the same quantised latent
     assert float((vq_gpu.generator(zq).cpu() - ref).abs().max()) < 1e-3
+
+
+def test_winograd_conv_kernel(chk):
+    """cf_conv2d(winograd=1) -- the F(2x2,3x3) evaluation of the 3x3 stride-1 convolutions -- against fp64 references, for every
+    prologue / epilogue / concat combination the network uses and for all its layer widths: tolerance 2e-5 + 1e-5*|ref| (the bound
+    of the direct kernel; measured errors are 1-6e-6, below the direct kernel's), epilogue GroupNorm partials relative 1e-5,
+    run-to-run and batch bitwise.  Shapes the kernel does not cover are refused by the C ABI, not silently rerouted."""
+    import importlib.util
+    import torch
+    from codeformer_amd import ops
+    spec = importlib.util.spec_from_file_location('wino_check', os.path.join(ROOT, 'tools', 'wino_check.py'))
+    wc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(wc)
+    cases = [dict(B=1, H=16, W=16, cin=16, cout=64),
+             dict(B=2, H=16, W=32, cin=32, cout=64, seed=1),
+             dict(B=2, H=16, W=16, cin=64, cout=128, prologue=ops.PRO_AFFINE_SWISH, epilogue=ops.EPI_RESIDUAL, stats=True, seed=2),
+             dict(B=2, H=32, W=32, cin=128, cout=64, c_split=64, prologue=ops.PRO_LEAKY, epilogue=ops.EPI_SFT, seed=3),
+             dict(B=2, H=16, W=16, cin=512, cout=512, prologue=ops.PRO_AFFINE_SWISH, stats=True, seed=4),
+             dict(B=1, H=64, W=64, cin=256, cout=256, prologue=ops.PRO_AFFINE, stats=True, seed=5),
+             dict(B=1, H=40, W=48, cin=64, cout=64, prologue=ops.PRO_AFFINE_SWISH, epilogue=ops.EPI_RESIDUAL, stats=True, seed=6,
+                  direct=False)]   # 40 rows: off the direct kernel's 16-row grid, where it has no statistics epilogue
+    for c in cases:
+        B, H, W, cin, cout = (c.pop(k) for k in ('B', 'H', 'W', 'cin', 'cout'))
+        ed, ew, es, rmax = wc.case(B, H, W, cin, cout, timing=False, **c)
+        assert ew <= 2e-5 + 1e-5 * rmax and es <= 1e-5, (B, H, W, cin, cout, c, ew, es)
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(3, 32, 48, 128, generator=g).cuda()
+    pw = ops.pack_weight((torch.randn(128, 128, 3, 3, generator=g) * 0.03).cuda(), torch.randn(128, generator=g).cuda(),
+                         bf16=ops.WINOGRAD)
+    y = ops.conv2d(x, pw)
+    assert torch.equal(y, ops.conv2d(x, pw)) and torch.equal(y[1:2], ops.conv2d(x[1:2].contiguous(), pw))
+    with pytest.raises(RuntimeError, match='winograd'):
+        ops.conv2d(x[:, :20].contiguous(), pw)       # 20 rows: not a whole number of 8x16 patches
+    with pytest.raises(RuntimeError, match='winograd'):
+        ops.conv2d(x, pw, stride=2)
+    assert ops.winograd_ok(128, 128, 32, 48) and not ops.winograd_ok(128, 128, 20, 48) and not ops.winograd_ok(128, 96, 32, 48)

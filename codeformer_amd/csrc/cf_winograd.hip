@@ -45,6 +45,10 @@
 #ifndef CF_WABLATE
 #define CF_WABLATE 0
 #endif
+#ifndef CF_WINO_WIDE
+#define CF_WINO_WIDE 0       // 1: layers with cout % 128 == 0 use the eight-wave / 128-channel workgroup (NH = 2); measured
+                             //    no faster than two four-wave workgroups per CU (128->128 @256^2: 1.65 vs 1.57 ms), kept for A/B
+#endif
 #ifndef CF_WINO_GROUPS
 #define CF_WINO_GROUPS 1     // 1: one four-wave group per workgroup, two workgroups per CU ; 2: ping-pong pair (see the kernel)
 #endif
@@ -57,7 +61,8 @@ constexpr int WG_NPIX = WG_PH * WG_PW;                    // 180
 constexpr int WG_NT = (WG_TH / 2) * (WG_TW / 2);          // 32 Winograd tiles = one MFMA row tile
 constexpr int WG_NI = 2;                                  // 32-channel MFMA tiles per consumer wave
 constexpr int WG_BN = WG_NI * 32;                         // output channels per workgroup (64)
-constexpr int WG_PATCH_FLOATS = 192 * CF_LDK;             // 3840: 180 halo pixels, padded to 3 x 64 so the gather-store needs no guard
+constexpr int WG_PATCH_FLOATS = 256 * CF_LDK;             // 5120: 180 halo pixels, padded to a whole number of gather rounds
+                                                          // (3 x 64 or 2 x 128 pixels) so the gather-store needs no guard
 // Floats between consecutive positions of V: 32 rows of 20 floats + 4 floats of padding.  4*PS*4 B = 64 (mod 256), so the four
 // xi rows written by neighbouring lanes of the transform land in distinct 64-byte bank groups (unpadded they all aliased).
 constexpr int WG_PS = WG_NT * CF_LDK + 4;                 // 644
@@ -94,18 +99,23 @@ __device__ __forceinline__ f32x4 v4sub(f32x4 a, f32x4 b) { return a - b; }
 // workgroup holds two groups working on neighbouring patches with group 1 running two barrier slots behind group 0 ("ping-pong":
 // slot 0 gather-store, slot 1 transform, slots 2-3 MFMA), so that every SIMD always has one MFMA wave and one VALU / LDS wave;
 // it measured 1.90 ms against 1.58 ms for G = 1 because the two streams share the fp32 FMA hardware instead of overlapping.
-template <int G>
-__global__ __launch_bounds__(256 * G, 2) void winograd_kernel(const WinoArgs a) {
+// NH = 2 (experiment, CF_WINO_WIDE=1): a group has EIGHT waves -- wave (xi, nh) accumulates positions (xi, 0..3) for the nh-th
+// 64 channels -- and owns 128 output channels, so the gather / prologue / transform work is spent once per 128 instead of once
+// per 64 channels; one such workgroup per CU turned out no faster than two independent four-wave workgroups.
+template <int G, int NH>
+__global__ __launch_bounds__(256 * G * NH, 2) void winograd_kernel(const WinoArgs a) {
+  static_assert(G == 1 || NH == 1, "the ping-pong experiment exists for four-wave groups only");
   constexpr int NI = WG_NI;
-  constexpr int GT = 256;                                        // threads per group
-  constexpr int APT = (WG_NPIX * 4 + GT - 1) / GT;               // float4 gather items per thread (3)
+  constexpr int GT = 256 * NH;                                   // threads per group
+  constexpr int APT = (WG_NPIX * 4 + GT - 1) / GT;               // float4 gather items per thread (3 or 2)
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int grp = wave >> 2;
+  const int grp = NH == 1 ? wave >> 2 : 0;
   const int xi = wave & 3;
+  const int nh = NH == 1 ? 0 : wave >> 2;  // which 64-channel half of the workgroup's channels
   const int gtid = tid & (GT - 1);
   const int half = lane >> 5;
   const int l31 = lane & 31;
@@ -119,7 +129,7 @@ __global__ __launch_bounds__(256 * G, 2) void winograd_kernel(const WinoArgs a) 
   }
   const int nt = bid % a.ntn;
   const int mt = (bid / a.ntn) * G + grp;  // this group's output patch (G = 2: tiles_per_img is even, both belong to one image)
-  const int n0 = nt * WG_BN;
+  const int n0 = nt * (WG_BN * NH);
   const int b = mt / a.tiles_per_img;
   const int rt = mt - b * a.tiles_per_img;
   const int tyw = rt / a.tiles_x;
@@ -132,7 +142,7 @@ __global__ __launch_bounds__(256 * G, 2) void winograd_kernel(const WinoArgs a) 
   int pix[APT];
 #pragma unroll
   for (int j = 0; j < APT; ++j) {
-    const int p = (gtid >> 2) + 64 * j;
+    const int p = (gtid >> 2) + (GT / 4) * j;
     int v = -1;
     if (p < WG_NPIX) {
       const int hy = p / WG_PW;
@@ -171,7 +181,7 @@ __global__ __launch_bounds__(256 * G, 2) void winograd_kernel(const WinoArgs a) 
     const f32x4 sc = rsc, sh = rsh;  // (fetched with the activations; only read by the affine modes)
 #pragma unroll
     for (int j = 0; j < APT; ++j) {
-      const int p = (gtid >> 2) + 64 * j;  // (p >= 180: padding rows of the patch buffer, written as zeros -- no branch)
+      const int p = (gtid >> 2) + (GT / 4) * j;  // (p >= 180: padding rows of the patch buffer, written as zeros -- no branch)
       {
         const bool valid = pix[j] >= 0;
         f32x4 v = ra[j];
@@ -240,7 +250,7 @@ __global__ __launch_bounds__(256 * G, 2) void winograd_kernel(const WinoArgs a) 
   //   U[pos = xi*4 + nu][chunk][n tile of 32][kg][lane][4]  (element = U[n = tile*32 + (lane & 31)][k = kg*8 + (lane >> 5)*4 + e]),
   // so every fragment load of a wave is one contiguous 1 KB block; they go global/L2 -> registers (each is used by one wave).
   const size_t pos_stride = (size_t)n * a.cout_pad * CF_BK;
-  const float* const wlane = a.weight + (size_t)(xi * 4) * pos_stride + (size_t)(n0 / 32) * 512 + lane * 4;
+  const float* const wlane = a.weight + (size_t)(xi * 4) * pos_stride + (size_t)(n0 / 32 + nh * NI) * 512 + lane * 4;
   const float* const alane = V + (xi * 4) * WG_PS + l31 * CF_LDK + half * 4;
   f32x4 bq[4][NI][2];
   auto load_B = [&](int chunk, int nu) {
@@ -313,13 +323,20 @@ __global__ __launch_bounds__(256 * G, 2) void winograd_kernel(const WinoArgs a) 
   // buffer; then item = (tile, output column bb, channel quad) contracts xi and owns two output pixels (rows aa = 0, 1).
   float* const R = V;  // [(xi*2 + bb)][tile][WG_RLD]
 #pragma unroll
-  for (int pass = 0; pass < NI; ++pass) {
+  for (int pass = 0; pass < NH * NI; ++pass) {
+    if (nh == pass / NI) {  // (NH = 2: the four waves that own these 32 channels)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float m0 = acc[0][pass][r], m1 = acc[1][pass][r], m2 = acc[2][pass][r], m3 = acc[3][pass][r];
-      const int row = cf_acc_row(r, lane);
-      R[((xi * 2 + 0) * WG_NT + row) * WG_RLD + l31] = (m0 + m1) + m2;  // nu axis: R[xi][0] = M0 + M1 + M2
-      R[((xi * 2 + 1) * WG_NT + row) * WG_RLD + l31] = (m1 - m2) - m3;  //          R[xi][1] = M1 - M2 - M3
+      for (int ni = 0; ni < NI; ++ni) {
+        if (ni == pass % NI) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float m0 = acc[0][ni][r], m1 = acc[1][ni][r], m2 = acc[2][ni][r], m3 = acc[3][ni][r];
+            const int row = cf_acc_row(r, lane);
+            R[((xi * 2 + 0) * WG_NT + row) * WG_RLD + l31] = (m0 + m1) + m2;  // nu axis: R[xi][0] = M0 + M1 + M2
+            R[((xi * 2 + 1) * WG_NT + row) * WG_RLD + l31] = (m1 - m2) - m3;  //          R[xi][1] = M1 - M2 - M3
+          }
+        }
+      }
     }
     __syncthreads();
     const int e_n4 = gtid & 7;  // (the item stride is a multiple of 8: both items of a thread have the same channel quad)
@@ -368,7 +385,7 @@ __global__ __launch_bounds__(256 * G, 2) void winograd_kernel(const WinoArgs a) 
     }
     if (a.stats_out) {
       // GroupNorm statistics of the values just written (fp64 partials, fixed shuffle order): one partial per
-      // (image, group, output patch, wave of its group) -- nparts = tiles_per_img * 4
+      // (image, group, output patch, wave of its group) -- nparts = tiles_per_img * 4 * NH
       const int cpg = a.stats_cpg;
       double d0, q0, d1 = 0, q1 = 0;
       if (cpg == 2) {
@@ -391,7 +408,7 @@ __global__ __launch_bounds__(256 * G, 2) void winograd_kernel(const WinoArgs a) 
         q0 += __shfl_xor(q0, o, 64);
       }
       if ((lane >> 3) == 0 && nvalid && (nn % cpg) == 0) {
-        const size_t pidx = (size_t)rt * 4 + xi;
+        const size_t pidx = (size_t)rt * (4 * NH) + (NH == 1 ? xi : wave);
         const int ng = a.cout / cpg;
         double* o = a.stats_out + (((size_t)b * ng + nn / cpg) * a.nparts + pidx) * 2;
         o[0] = d0;
@@ -491,24 +508,25 @@ int cf_winograd_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_que
   a.tiles_per_img = a.tiles_x * (d->hout / WG_TH);
   constexpr int G = CF_WINO_GROUPS;
   CF_REQUIRE(a.tiles_per_img % G == 0, "cf_conv2d: winograd pairs 8x16 output patches (got %d per image)", a.tiles_per_img);
-  a.nparts = a.tiles_per_img * 4;
-  a.ntn = d->cout_pad / WG_BN;
+  const bool wide = G == 1 && CF_WINO_WIDE && d->cout_pad % 128 == 0;  // a property of the layer, never of the batch
+  a.nparts = a.tiles_per_img * (wide ? 8 : 4);
+  a.ntn = d->cout_pad / (wide ? 2 * WG_BN : WG_BN);
   if (parts_query) {
     *parts_query = a.nparts;
     return CF_OK;
   }
   constexpr size_t lds = G * (WG_PATCH_FLOATS + WG_V_FLOATS) * sizeof(float);
-  static bool attr_set = false;  // benign race: the attribute call is idempotent
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
+  auto kern = wide ? winograd_kernel<1, 2> : winograd_kernel<G, 1>;
+  static bool attr_set[2] = {false, false};  // benign race: the attribute call is idempotent
+  if (!attr_set[wide]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       cf_set_error("cf_conv2d: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
       return CF_ERR_LAUNCH;
     }
-    attr_set = true;
+    attr_set[wide] = true;
   }
-  hipLaunchKernelGGL(winograd_kernel<G>, dim3(a.tiles_per_img / G * d->batch * a.ntn), dim3(256 * G), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3(a.tiles_per_img / G * d->batch * a.ntn), dim3(wide ? 512 : 256 * G), lds, stream, a);
   CF_CHECK_LAUNCH("cf_conv2d(winograd)");
   return CF_OK;
 }

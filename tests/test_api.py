@@ -117,3 +117,16 @@ def test_bundled_ops_shim_cpu():
         upfirdn2d(x.requires_grad_(True), k)
     with pytest.raises(RuntimeError):
         fused_leaky_relu(x.detach(), m.bias.detach())   # no CPU implementation, as in the reference
+
+
+def test_winograd_eligibility_rule():
+    """Which 3x3 stride-1 layers take the Winograd kernel is a pure function of the layer shape (never of the batch): whole 8x16
+    output patches, cin % 16 == 0, cout % 64 == 0.  Every such conv of CodeFormer's encoder / generator / fusion blocks qualifies;
+    the 3-channel stem / head and odd sizes do not."""
+    from codeformer_amd import ops
+    for cin, cout, h in ((64, 64, 512), (128, 128, 256), (128, 128, 128), (256, 256, 64), (256, 256, 32), (512, 512, 16),
+                         (256, 512, 16), (512, 256, 32), (128, 64, 512), (64, 128, 256)):
+        assert ops.winograd_ok(cin, cout, h, h), (cin, cout, h)
+    assert not ops.winograd_ok(3, 64, 512, 512) and not ops.winograd_ok(64, 3, 512, 512)
+    assert not ops.winograd_ok(64, 64, 20, 32) and not ops.winograd_ok(64, 64, 16, 24) and not ops.winograd_ok(64, 96, 16, 16)
+    assert ops.WINOGRAD == 3

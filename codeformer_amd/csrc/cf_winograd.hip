@@ -28,7 +28,7 @@
 // What the measurements said (interleaved ablations, tools/wino_ab.py; 128->128 @ 256x256 x16: direct 2.31 ms, this 1.58 ms):
 //   * fp32 MFMA and fp32 VALU do NOT overlap on this part -- the fp32 matrix peak equals the fp32 vector peak because it is the
 //     same FMA hardware.  MFMA-only, everything-else-only and the full kernel came out additive (1.35 + 0.55 = 1.90) even in a
-//     ping-pong variant (G = 2 below) that pins one MFMA wave and one VALU wave on every SIMD; so every VALU instruction of the
+//     ping-pong variant that pins one MFMA wave and one VALU wave on every SIMD; so every VALU instruction of the
 //     gather / transform / epilogue is paid for in full, and what helped was removing instructions and stalls:
 //   * the per-lane add / sub choice of the transform compiled into divergent branches with an LDS wait in each (now sign
 //     multipliers, branch-free); the GroupNorm scale / shift rows loaded inside the gather-store put an s_waitcnt vmcnt(0) there
@@ -45,14 +45,6 @@
 #ifndef CF_WABLATE
 #define CF_WABLATE 0
 #endif
-#ifndef CF_WINO_WIDE
-#define CF_WINO_WIDE 0       // 1: layers with cout % 128 == 0 use the eight-wave / 128-channel workgroup (NH = 2); measured
-                             //    no faster than two four-wave workgroups per CU (128->128 @256^2: 1.65 vs 1.57 ms), kept for A/B
-#endif
-#ifndef CF_WINO_GROUPS
-#define CF_WINO_GROUPS 1     // 1: one four-wave group per workgroup, two workgroups per CU ; 2: ping-pong pair (see the kernel)
-#endif
-
 namespace {
 
 constexpr int WG_TH = 8, WG_TW = 16;                      // output patch of a workgroup
@@ -94,32 +86,24 @@ struct WinoArgs {
 __device__ __forceinline__ f32x4 v4add(f32x4 a, f32x4 b) { return a + b; }
 __device__ __forceinline__ f32x4 v4sub(f32x4 a, f32x4 b) { return a - b; }
 
-// One group of four waves computes one 8x16 output patch (see the file header).  G = 1 (shipped): a workgroup is one group,
-// two barriers per slab, two independent workgroups per CU.  G = 2 (kept as a documented experiment, CF_WINO_GROUPS=2): a
-// workgroup holds two groups working on neighbouring patches with group 1 running two barrier slots behind group 0 ("ping-pong":
-// slot 0 gather-store, slot 1 transform, slots 2-3 MFMA), so that every SIMD always has one MFMA wave and one VALU / LDS wave;
-// it measured 1.90 ms against 1.58 ms for G = 1 because the two streams share the fp32 FMA hardware instead of overlapping.
-// NH = 2 (experiment, CF_WINO_WIDE=1): a group has EIGHT waves -- wave (xi, nh) accumulates positions (xi, 0..3) for the nh-th
-// 64 channels -- and owns 128 output channels, so the gather / prologue / transform work is spent once per 128 instead of once
-// per 64 channels; one such workgroup per CU turned out no faster than two independent four-wave workgroups.
-template <int G, int NH>
-__global__ __launch_bounds__(256 * G * NH, 2) void winograd_kernel(const WinoArgs a) {
-  static_assert(G == 1 || NH == 1, "the ping-pong experiment exists for four-wave groups only");
+// One workgroup (four waves) computes one 8x16 output patch x 64 channels; see the file header.  Two measured variants are not
+// shipped (git history): a "ping-pong" pair of groups per workgroup running two barrier slots apart so that every SIMD always has
+// one MFMA wave and one VALU / LDS wave (1.90 ms against 1.58 ms on 128->128 @256x256x16 -- the two streams do not co-execute,
+// SQ_VALU_MFMA_COEXEC_CYCLES = 0), and an eight-wave workgroup owning 128 channels (1.65 ms).
+__global__ __launch_bounds__(256, 2) void winograd_kernel(const WinoArgs a) {
   constexpr int NI = WG_NI;
-  constexpr int GT = 256 * NH;                                   // threads per group
-  constexpr int APT = (WG_NPIX * 4 + GT - 1) / GT;               // float4 gather items per thread (3 or 2)
+  constexpr int GT = 256;                                        // threads
+  constexpr int APT = (WG_NPIX * 4 + GT - 1) / GT;               // float4 gather items per thread (3)
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int grp = NH == 1 ? wave >> 2 : 0;
   const int xi = wave & 3;
-  const int nh = NH == 1 ? 0 : wave >> 2;  // which 64-channel half of the workgroup's channels
-  const int gtid = tid & (GT - 1);
+  const int gtid = tid;
   const int half = lane >> 5;
   const int l31 = lane & 31;
-  float* const patch = smem + grp * (WG_PATCH_FLOATS + WG_V_FLOATS);
+  float* const patch = smem;
   float* const V = patch + WG_PATCH_FLOATS;
 
   int bid = blockIdx.x;
@@ -128,8 +112,8 @@ __global__ __launch_bounds__(256 * G * NH, 2) void winograd_kernel(const WinoArg
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
   }
   const int nt = bid % a.ntn;
-  const int mt = (bid / a.ntn) * G + grp;  // this group's output patch (G = 2: tiles_per_img is even, both belong to one image)
-  const int n0 = nt * (WG_BN * NH);
+  const int mt = bid / a.ntn;  // this workgroup's output patch
+  const int n0 = nt * WG_BN;
   const int b = mt / a.tiles_per_img;
   const int rt = mt - b * a.tiles_per_img;
   const int tyw = rt / a.tiles_x;
@@ -250,7 +234,7 @@ __global__ __launch_bounds__(256 * G * NH, 2) void winograd_kernel(const WinoArg
   //   U[pos = xi*4 + nu][chunk][n tile of 32][kg][lane][4]  (element = U[n = tile*32 + (lane & 31)][k = kg*8 + (lane >> 5)*4 + e]),
   // so every fragment load of a wave is one contiguous 1 KB block; they go global/L2 -> registers (each is used by one wave).
   const size_t pos_stride = (size_t)n * a.cout_pad * CF_BK;
-  const float* const wlane = a.weight + (size_t)(xi * 4) * pos_stride + (size_t)(n0 / 32 + nh * NI) * 512 + lane * 4;
+  const float* const wlane = a.weight + (size_t)(xi * 4) * pos_stride + (size_t)(n0 / 32) * 512 + lane * 4;
   const float* const alane = V + (xi * 4) * WG_PS + l31 * CF_LDK + half * 4;
   f32x4 bq[4][NI][2];
   auto load_B = [&](int chunk, int nu) {
@@ -275,10 +259,6 @@ __global__ __launch_bounds__(256 * G * NH, 2) void winograd_kernel(const WinoArg
 
   f32x4 ra[APT];
   load_A(0, ra);
-  if (G == 2 && grp == 1) {  // group 1 starts two slots late
-    __syncthreads();
-    __syncthreads();
-  }
   for (int chunk = 0; chunk < n; ++chunk) {
     // slot 0: gather-store.  Weight fragments of positions nu 0,1 are requested first: two slots of cover.
     load_B(chunk, 0);
@@ -304,39 +284,27 @@ __global__ __launch_bounds__(256 * G * NH, 2) void winograd_kernel(const WinoArg
     mma(0);
     mma(1);
 #endif
-    if (G == 2) __syncthreads();
     // slot 3
 #if CF_WABLATE != 3
     mma(2);
     mma(3);
 #endif
-    if (G == 2) __syncthreads();  // (G = 1: the barrier after the next gather-store separates these reads of V from its rewrite)
+    // (the barrier after the next gather-store separates these reads of V from its rewrite)
   }
-  if (G == 2 && grp == 0) {
-    __syncthreads();
-    __syncthreads();
-  }
-  if (G == 1) __syncthreads();  // V reads retired before it becomes the staging buffer
+  __syncthreads();  // V reads retired before it becomes the staging buffer
 
   // ---- epilogue (both groups, each for its own patch) ------------------------------------------------------------------------
   // NI passes of 32 channels: every wave contracts its nu axis in registers and stages R[xi][bb] in its group's (idle) V
   // buffer; then item = (tile, output column bb, channel quad) contracts xi and owns two output pixels (rows aa = 0, 1).
   float* const R = V;  // [(xi*2 + bb)][tile][WG_RLD]
 #pragma unroll
-  for (int pass = 0; pass < NH * NI; ++pass) {
-    if (nh == pass / NI) {  // (NH = 2: the four waves that own these 32 channels)
+  for (int pass = 0; pass < NI; ++pass) {
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        if (ni == pass % NI) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float m0 = acc[0][ni][r], m1 = acc[1][ni][r], m2 = acc[2][ni][r], m3 = acc[3][ni][r];
-            const int row = cf_acc_row(r, lane);
-            R[((xi * 2 + 0) * WG_NT + row) * WG_RLD + l31] = (m0 + m1) + m2;  // nu axis: R[xi][0] = M0 + M1 + M2
-            R[((xi * 2 + 1) * WG_NT + row) * WG_RLD + l31] = (m1 - m2) - m3;  //          R[xi][1] = M1 - M2 - M3
-          }
-        }
-      }
+    for (int r = 0; r < 16; ++r) {
+      const float m0 = acc[0][pass][r], m1 = acc[1][pass][r], m2 = acc[2][pass][r], m3 = acc[3][pass][r];
+      const int row = cf_acc_row(r, lane);
+      R[((xi * 2 + 0) * WG_NT + row) * WG_RLD + l31] = (m0 + m1) + m2;  // nu axis: R[xi][0] = M0 + M1 + M2
+      R[((xi * 2 + 1) * WG_NT + row) * WG_RLD + l31] = (m1 - m2) - m3;  //          R[xi][1] = M1 - M2 - M3
     }
     __syncthreads();
     const int e_n4 = gtid & 7;  // (the item stride is a multiple of 8: both items of a thread have the same channel quad)
@@ -385,7 +353,7 @@ __global__ __launch_bounds__(256 * G * NH, 2) void winograd_kernel(const WinoArg
     }
     if (a.stats_out) {
       // GroupNorm statistics of the values just written (fp64 partials, fixed shuffle order): one partial per
-      // (image, group, output patch, wave of its group) -- nparts = tiles_per_img * 4 * NH
+      // (image, group, output patch, wave) -- nparts = tiles_per_img * 4
       const int cpg = a.stats_cpg;
       double d0, q0, d1 = 0, q1 = 0;
       if (cpg == 2) {
@@ -408,7 +376,7 @@ __global__ __launch_bounds__(256 * G * NH, 2) void winograd_kernel(const WinoArg
         q0 += __shfl_xor(q0, o, 64);
       }
       if ((lane >> 3) == 0 && nvalid && (nn % cpg) == 0) {
-        const size_t pidx = (size_t)rt * (4 * NH) + (NH == 1 ? xi : wave);
+        const size_t pidx = (size_t)rt * 4 + xi;
         const int ng = a.cout / cpg;
         double* o = a.stats_out + (((size_t)b * ng + nn / cpg) * a.nparts + pidx) * 2;
         o[0] = d0;
@@ -506,27 +474,24 @@ int cf_winograd_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_que
   a.stats_cpg = d->stats_cpg > 0 ? d->stats_cpg : 1;
   a.tiles_x = d->wout / WG_TW;
   a.tiles_per_img = a.tiles_x * (d->hout / WG_TH);
-  constexpr int G = CF_WINO_GROUPS;
-  CF_REQUIRE(a.tiles_per_img % G == 0, "cf_conv2d: winograd pairs 8x16 output patches (got %d per image)", a.tiles_per_img);
-  const bool wide = G == 1 && CF_WINO_WIDE && d->cout_pad % 128 == 0;  // a property of the layer, never of the batch
-  a.nparts = a.tiles_per_img * (wide ? 8 : 4);
-  a.ntn = d->cout_pad / (wide ? 2 * WG_BN : WG_BN);
+  a.nparts = a.tiles_per_img * 4;
+  a.ntn = d->cout_pad / WG_BN;
   if (parts_query) {
     *parts_query = a.nparts;
     return CF_OK;
   }
-  constexpr size_t lds = G * (WG_PATCH_FLOATS + WG_V_FLOATS) * sizeof(float);
-  auto kern = wide ? winograd_kernel<1, 2> : winograd_kernel<G, 1>;
-  static bool attr_set[2] = {false, false};  // benign race: the attribute call is idempotent
-  if (!attr_set[wide]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  constexpr size_t lds = (WG_PATCH_FLOATS + WG_V_FLOATS) * sizeof(float);  // 61.7 KB: two workgroups per CU
+  static bool attr_set = false;  // benign race: the attribute call is idempotent
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
     if (e != hipSuccess) {
       cf_set_error("cf_conv2d: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
       return CF_ERR_LAUNCH;
     }
-    attr_set[wide] = true;
+    attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.tiles_per_img / G * d->batch * a.ntn), dim3(wide ? 512 : 256 * G), lds, stream, a);
+  hipLaunchKernelGGL(winograd_kernel, dim3(a.tiles_per_img * d->batch * a.ntn), dim3(256), lds, stream, a);
   CF_CHECK_LAUNCH("cf_conv2d(winograd)");
   return CF_OK;
 }

@@ -368,8 +368,12 @@ __global__ __launch_bounds__(256, 2) void winograd_kernel(const WinoArgs a) {
       for (int o = 8; o < 64; o <<= 1) {  // the (tile, bb) items of this wave: lanes with the same channel quad
         d0 += __shfl_xor(d0, o, 64);
         q0 += __shfl_xor(q0, o, 64);
-        d1 += __shfl_xor(d1, o, 64);
-        q1 += __shfl_xor(q1, o, 64);
+      }
+      if (cpg == 2) {  // (second group of the lane: 64-channel layers only -- a wave-uniform branch)
+        for (int o = 8; o < 64; o <<= 1) {
+          d1 += __shfl_xor(d1, o, 64);
+          q1 += __shfl_xor(q1, o, 64);
+        }
       }
       for (int o = 1; o * 4 < cpg; o <<= 1) {  // adjacent channel quads of one group (cpg >= 8)
         d0 += __shfl_xor(d0, o, 64);

@@ -1,0 +1,604 @@
+// 3x3 convolution with fp32-grade accuracy on the f16 MFMA pipe (v_mfma_f32_32x32x16_f16) for gfx950: split operands.
+//
+// The fp32 MFMA runs at the fp32 VECTOR rate (157 TFLOP/s, 1/16 of the 16-bit matrix rate) and shares the FMA pipe with the
+// VALU work of the gather, so the exact-fp32 kernels (cf_igemm.hip / cf_winograd.hip) top out near 140 TFLOP/s of issued
+// multiplies.  Here every fp32 operand x is written as x = hi + lo with hi = f16(x) and lo = f16(x - hi) (both round-to-nearest-
+// even; |x - hi - lo| <= 2^-22 |x|), and a product is evaluated as
+//      a * b  ~=  a_hi*b_hi + a_hi*b_lo + a_lo*b_hi            (the dropped a_lo*b_lo term is <= 2^-22 |a b|)
+// i.e. THREE f16 MFMAs with fp32 accumulation per fp32 multiply-add: 3/16 of the fp32-MFMA issue time, on a pipe that
+// co-executes with the VALU.  Operands carry 22 instead of 24 significant bits; accumulation is fp32.  Measured against fp64
+// the error of a layer is 1-3x that of the exact-fp32 kernels (tests/test_gpu_split.py), against the reference the whole
+// network stays inside the 1e-3 pixel tolerance by more than an order of magnitude.  Used for the generator / fusion (CFT)
+// convolutions only (reference: vqgan_arch.py:132-164,276-323, codeformer_arch.py:136-157): encoder, Transformer and the code
+// argmax stay on exact fp32, so logits and code indices are bitwise those of the fp32 mode.
+//
+// Range: hi is an IEEE half, so conv INPUTS (post-activation values) must stay below 65504 in magnitude -- an overflow becomes
+// inf / NaN in the output, never a silently wrong finite value.  Weights are scaled at pack time by a power of two (exact) so
+// that max|w'| lies in [2^14, 2^15): the lo parts of all but negligible weights are then normal halves; the accumulator is
+// scaled back by the exact inverse in the epilogue.  Small activations whose lo part is a subnormal half lose nothing that
+// matters: the absolute error of a subnormal lo is <= 2^-25.
+//
+// Work decomposition (512 threads = 8 waves, one workgroup per CU):
+//   * a workgroup owns a 16x16 output tile of ONE image (BM = 256 pixels) x BN = 128 (or 64) output channels; waves 4 (M) x 2 (N),
+//     each 64 pixels x 64 (32) channels = 2 x 2 (2 x 1) MFMA tiles of 32x32, 64 (32) accumulator registers;
+//   * K loop over 32-channel slabs: the 18x18 halo patch of the slab is gathered once -- GroupNorm-apply / swish or LeakyReLU
+//     prologue, channel concat and zero padding resolved in the gather exactly as in cf_igemm.hip -- split into hi / lo halves
+//     and written to LDS ([pixel][hi 32 | lo 32 | pad], 144-byte rows); all nine taps reuse it;
+//   * the weight slab of one (tap, K slab) -- [n][hi 32 | lo 32] halves, packed by cf_pack_conv_weight_f16x2 -- rides in a
+//     3-deep LDS ring: fetched two steps ahead into registers, written one step ahead, so no wave waits on a fetch;
+//   * per step (tap x 32 channels) a wave issues 24 MFMAs (768 matrix-pipe cycles) between two workgroup barriers, against 16
+//     ds_read_b128 of operand fragments;
+//   * nearest-x2 + 3x3 (Upsample, vqgan_arch.py:134-138) runs in the folded sub-pixel form of cf_igemm.hip (TAPS = 4: one output
+//     parity class per workgroup, a 17x17 source patch, taps pre-summed at pack time);
+//   * epilogue as in cf_igemm.hip: per-wave LDS transpose, 16-byte stores, bias / residual / SFT, fp64 GroupNorm partials.
+#include <type_traits>
+
+#include "cf_common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int SP_NT = 512;     // threads per workgroup
+constexpr int SP_WM = 4;       // waves along M (64 pixels = 4 tile rows each)
+constexpr int SP_KC = 32;      // channels per K slab
+constexpr int SP_ROW = 36;     // floats per LDS row: 32 hi halves (64 B) | 32 lo halves (64 B) | 16 B pad.  9 x 16 B: odd, so 16
+                               // consecutive rows occupy 16 distinct 16-byte slots of the 256-byte bank window (ds_read_b128)
+constexpr int SP_PITCH = 704;  // floats between patch rows: 2816 B = 11 x 256 B, so the two patch rows a 32-lane fragment read
+                               // touches (16 pixels each) keep their bank slots disjoint (18 x 144 B unpadded would alias 4 of 16)
+constexpr int SP_LO = 16;      // float offset of the lo halves inside a row
+
+struct SplitArgs {
+  const float* in0;
+  const float* in1;
+  int c0, c1, cin, nchunks;
+  int batch, hin, win, hout, wout;
+  int cout, cout_pad;
+  int prologue, epilogue;
+  const float* pro_scale;
+  const float* pro_shift;
+  const float* weight;  // [slab][cin/32][cout_pad][hi 32 | lo 32] halves = 32 floats per row
+  const float* bias;
+  const float* res;
+  const float* sft_scale;
+  float sft_w;
+  float acc_scale;  // exact power of two: 1 / (weight scale applied at pack time)
+  float* out;
+  double* stats_out;
+  int stats_cpg, nparts;
+  int tiles_x, tiles_per_img, ntn;
+};
+
+template <int TAPS, int NI>
+struct SplitCfg {
+  static constexpr int BN = 2 * NI * 32;
+  static constexpr int HH = TAPS == 9 ? 18 : 17;  // halo patch rows = columns
+  static constexpr int NPIX = HH * HH;
+  static constexpr int APT = (NPIX + 127) / 128;  // gather items (pixel, channel octet) per thread
+  static constexpr int BPT = BN * 8 / SP_NT;      // 16-byte weight items per thread and step
+  static constexpr int A_FLOATS = HH * SP_PITCH;
+  static constexpr int B_FLOATS = 3 * BN * SP_ROW;
+  static constexpr int LDW = NI * 32 + 4;
+  static constexpr int EPI_FLOATS = 8 * 32 * LDW;
+  static constexpr int LDS_FLOATS = (A_FLOATS + B_FLOATS) > EPI_FLOATS ? (A_FLOATS + B_FLOATS) : EPI_FLOATS;
+};
+
+// x -> (hi, lo) halves of two neighbouring channels, packed for the LDS rows
+__device__ __forceinline__ void split2(float x0, float x1, float& hi, float& lo) {
+  const f16x2 h = {(_Float16)x0, (_Float16)x1};
+  const f16x2 l = {(_Float16)(x0 - (float)h[0]), (_Float16)(x1 - (float)h[1])};
+  hi = __builtin_bit_cast(float, h);
+  lo = __builtin_bit_cast(float, l);
+}
+
+template <int TAPS, int NI>
+__global__ __launch_bounds__(SP_NT) void split_conv_kernel(const SplitArgs a) {
+  using C = SplitCfg<TAPS, NI>;
+  constexpr int MI = 2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const As = smem;
+  float* const Bs = smem + C::A_FLOATS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1;
+  const int wn = wave & 1;
+  const int half = lane >> 5;
+  const int l31 = lane & 31;
+
+  int bid = blockIdx.x;
+  {  // XCD-contiguous tile order (see cf_igemm.hip): neighbouring tiles share halos and weight slabs in one L2
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int nt = bid % a.ntn;
+  const int mt = bid / a.ntn;
+  const int n0 = nt * C::BN;
+  const int b = mt / a.tiles_per_img;
+  int rt = mt - b * a.tiles_per_img;
+  int sub_y = 0, sub_x = 0;  // TAPS == 4: output parity class of this workgroup; y0 / x0 are SOURCE coordinates
+  if (TAPS == 4) {
+    const int src_tiles = a.tiles_per_img >> 2;
+    const int cls = rt / src_tiles;
+    rt -= cls * src_tiles;
+    sub_y = cls >> 1;
+    sub_x = cls & 1;
+  }
+  const int tyw = rt / a.tiles_x;
+  const int y0 = tyw * 16;
+  const int x0 = (rt - tyw * a.tiles_x) * 16;
+
+  // ---- gather geometry: item j of this thread = channel octet k8 of halo pixel p = (tid >> 2) + 128 j ----
+  const int k8 = tid & 3;
+  int pix[C::APT];   // source pixel index, -1 = zero padding / past the patch
+  int aoff[C::APT];  // LDS float offset of the item's hi halves
+#pragma unroll
+  for (int j = 0; j < C::APT; ++j) {
+    const int p = (tid >> 2) + 128 * j;
+    int v = -1, off = 0;
+    if (p < C::NPIX) {
+      const int hy = p / C::HH;
+      const int hx = p - hy * C::HH;
+      const int iy = y0 - 1 + (TAPS == 4 ? sub_y : 0) + hy;
+      const int ix = x0 - 1 + (TAPS == 4 ? sub_x : 0) + hx;
+      if (iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win) v = (b * a.hin + iy) * a.win + ix;
+      off = hy * SP_PITCH + hx * SP_ROW + k8 * 4;
+    }
+    pix[j] = v;
+    aoff[j] = p < C::NPIX ? off : -1;
+  }
+
+  const bool affine = a.prologue == CF_PRO_AFFINE || a.prologue == CF_PRO_AFFINE_SWISH;
+  const float* const tab_sc = affine ? a.pro_scale + (size_t)b * a.cin : a.in0;  // (any valid address when unused)
+  const float* const tab_sh = affine ? a.pro_shift + (size_t)b * a.cin : a.in0;
+
+  // raw fp32 activations of the next slab (fetched a slab ahead), then -- converted in place -- their hi / lo halves
+  f32x4 ra[C::APT][2];
+  f32x4 rsc[2], rsh[2];
+  // Loads are issued unconditionally from clamped addresses (a load under a divergent branch is waited for on the spot);
+  // out-of-image items are zeroed at conversion time.
+  auto load_A = [&](int chunk) {
+    const int c = chunk * SP_KC + k8 * 8;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      rsc[u] = *reinterpret_cast<const f32x4*>(tab_sc + (affine ? c + 4 * u : 0));
+      rsh[u] = *reinterpret_cast<const f32x4*>(tab_sh + (affine ? c + 4 * u : 0));
+    }
+    const bool first = c < a.c0;
+    const float* src = first ? a.in0 : a.in1;
+    const int cs = first ? a.c0 : a.c1;
+    const int cc = first ? c : c - a.c0;
+#pragma unroll
+    for (int j = 0; j < C::APT; ++j) {
+      const int pj = pix[j] < 0 ? 0 : pix[j];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) ra[j][u] = *reinterpret_cast<const f32x4*>(src + (size_t)pj * cs + cc + 4 * u);
+    }
+  };
+  // prologue (GroupNorm apply / swish / LeakyReLU) + split: ra[j][0] <- 8 hi halves, ra[j][1] <- 8 lo halves.
+  // Zero padding stays exactly zero: it pads the conv INPUT, i.e. the post-activation tensor.
+  auto convert_mode = [&](auto mode) {
+    constexpr int PRO = decltype(mode)::value;
+#pragma unroll
+    for (int j = 0; j < C::APT; ++j) {
+      const bool valid = pix[j] >= 0;
+      float y[8];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = ra[j][u][e];
+          if (PRO == CF_PRO_AFFINE) v = v * rsc[u][e] + rsh[u][e];
+          if (PRO == CF_PRO_AFFINE_SWISH) {
+            v = v * rsc[u][e] + rsh[u][e];
+            v = v * __frcp_rn(1.0f + __expf(-v));  // hardware exp / rcp swish, as the fp32 kernels (~3 ulp of x*sigmoid(x))
+          }
+          if (PRO == CF_PRO_LEAKY) v = v > 0.f ? v : 0.2f * v;
+          y[u * 4 + e] = valid ? v : 0.f;
+        }
+      f32x4 hi, lo;
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        float ph, pl;
+        split2(y[2 * h], y[2 * h + 1], ph, pl);
+        hi[h] = ph;
+        lo[h] = pl;
+      }
+      ra[j][0] = hi;
+      ra[j][1] = lo;
+    }
+  };
+  auto convert = [&]() {
+    switch (a.prologue) {
+      case CF_PRO_AFFINE: convert_mode(std::integral_constant<int, CF_PRO_AFFINE>{}); break;
+      case CF_PRO_AFFINE_SWISH: convert_mode(std::integral_constant<int, CF_PRO_AFFINE_SWISH>{}); break;
+      case CF_PRO_LEAKY: convert_mode(std::integral_constant<int, CF_PRO_LEAKY>{}); break;
+      default: convert_mode(std::integral_constant<int, CF_PRO_NONE>{}); break;
+    }
+  };
+  auto store_A = [&]() {
+#pragma unroll
+    for (int j = 0; j < C::APT; ++j) {
+      if ((j + 1) * 128 <= C::NPIX || aoff[j] >= 0) {
+        *reinterpret_cast<f32x4*>(As + aoff[j]) = ra[j][0];
+        *reinterpret_cast<f32x4*>(As + aoff[j] + SP_LO) = ra[j][1];
+      }
+    }
+  };
+
+  f32x4 rb[C::BPT];
+  auto load_B = [&](int step) {
+    const int chunk = step / TAPS;
+    const int tap = step - chunk * TAPS;
+    const int cls_tap = (TAPS == 4) ? (sub_y * 2 + sub_x) * 4 + tap : tap;  // folded upsample: [class][tap] slabs
+    const float* src = a.weight + ((size_t)(cls_tap * a.nchunks + chunk) * a.cout_pad + n0) * 32;
+#pragma unroll
+    for (int j = 0; j < C::BPT; ++j) rb[j] = *reinterpret_cast<const f32x4*>(src + (tid + SP_NT * j) * 4);
+  };
+  auto store_B = [&](int slot) {
+    float* dst = Bs + slot * (C::BN * SP_ROW);
+#pragma unroll
+    for (int j = 0; j < C::BPT; ++j) {
+      const int f = tid + SP_NT * j;
+      *reinterpret_cast<f32x4*>(dst + (f >> 3) * SP_ROW + (f & 7) * 4) = rb[j];
+    }
+  };
+
+  // ---- MFMA operand rows of this lane: lane l holds row l & 31, k = (l >> 5) * 8 .. + 7 of a 16-wide K block ----
+  int a_off[MI], b_off[NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int row = wm * 64 + mi * 32 + l31;
+    a_off[mi] = (row >> 4) * SP_PITCH + (row & 15) * SP_ROW + half * 4;
+  }
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) b_off[ni] = (wn * (NI * 32) + ni * 32 + l31) * SP_ROW + half * 4;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  struct Frags {
+    f32x4 ah[MI], al[MI], bh[NI], bl[NI];
+  };
+  auto read_frags = [&](Frags& f, int tapoff, int slot, int kk) {  // kk: 16-wide K block of the slab (0 / 1)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      f.ah[mi] = *reinterpret_cast<const f32x4*>(As + a_off[mi] + tapoff + kk * 8);
+      f.al[mi] = *reinterpret_cast<const f32x4*>(As + a_off[mi] + tapoff + kk * 8 + SP_LO);
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      f.bh[ni] = *reinterpret_cast<const f32x4*>(Bs + slot * (C::BN * SP_ROW) + b_off[ni] + kk * 8);
+      f.bl[ni] = *reinterpret_cast<const f32x4*>(Bs + slot * (C::BN * SP_ROW) + b_off[ni] + kk * 8 + SP_LO);
+    }
+  };
+  // hi*hi + hi*lo + lo*hi; consecutive MFMAs go to different accumulators
+  auto mma = [&](const Frags& f) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.al[mi]), __builtin_bit_cast(f16x8, f.bh[ni]),
+                                                             acc[mi][ni], 0, 0, 0);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.ah[mi]), __builtin_bit_cast(f16x8, f.bl[ni]),
+                                                             acc[mi][ni], 0, 0, 0);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.ah[mi]), __builtin_bit_cast(f16x8, f.bh[ni]),
+                                                             acc[mi][ni], 0, 0, 0);
+  };
+  auto tap_off = [](int tap) { return TAPS == 4 ? (tap >> 1) * SP_PITCH + (tap & 1) * SP_ROW : (tap / 3) * SP_PITCH + (tap % 3) * SP_ROW; };
+
+  // ---- software-pipelined main loop (the schedule of cf_igemm.hip) -----------------------------------------------------------
+  //     step s:  [barrier] fetch B(s+2) | read frags(s, k 16..31) | 12 MFMA on frags(s, k 0..15)
+  //                        read frags(s+1, k 0..15) | 12 MFMA on frags(s, k 16..31) | LDS write B(s+2)
+  // RAW: B(s+1) was written before the barrier opening step s.  WAR: ring slot (s+2)%3 last held B(s-1), whose reads every wave
+  // finished before the barrier opening step s.  The halo patch is single-buffered: the slab boundary (1 step in 9) drains --
+  // barrier, patch write, barrier -- but the next slab's activations were fetched at tap 0 and converted (prologue + split) at
+  // tap 4 in the shadow of the MFMAs, so only the twelve LDS stores sit between the two barriers.
+  const int nsteps = a.nchunks * TAPS;
+  load_A(0);
+  load_B(0);
+  {
+    f32x4 rb0[C::BPT];
+#pragma unroll
+    for (int j = 0; j < C::BPT; ++j) rb0[j] = rb[j];
+    load_B(1 < nsteps ? 1 : 0);
+    convert();
+    store_A();
+    {
+      float* dst = Bs;
+#pragma unroll
+      for (int j = 0; j < C::BPT; ++j) {
+        const int f = tid + SP_NT * j;
+        *reinterpret_cast<f32x4*>(dst + (f >> 3) * SP_ROW + (f & 7) * 4) = rb0[j];
+      }
+    }
+    store_B(1);
+  }
+  __syncthreads();
+  Frags fx, fy;
+  read_frags(fx, tap_off(0), 0, 0);
+  int slot = 0;
+  int step = 0;
+  constexpr int CONV_TAP = TAPS == 9 ? 4 : 2;
+  for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap, ++step) {
+      const int slot1 = slot == 2 ? 0 : slot + 1;
+      const int slot2 = slot1 == 2 ? 0 : slot1 + 1;
+      load_B(step + 2 < nsteps ? step + 2 : nsteps - 1);  // clamped: the tail prefetches are harmless re-reads
+      if (tap == 0) load_A(chunk + 1 < a.nchunks ? chunk + 1 : chunk);
+      read_frags(fy, tap_off(tap), slot, 1);
+      __builtin_amdgcn_sched_barrier(0);  // pin the fetches above the MFMA block (hipcc would sink them next to their use)
+      mma(fx);
+      if (tap == CONV_TAP) convert();
+      __builtin_amdgcn_sched_barrier(0);
+      if (tap != TAPS - 1) read_frags(fx, tap_off(tap + 1), slot1, 0);
+      mma(fy);
+      __builtin_amdgcn_sched_barrier(0);
+      store_B(slot2);
+      __syncthreads();
+      if (tap == TAPS - 1 && chunk + 1 < a.nchunks) {
+        store_A();
+        __syncthreads();
+        read_frags(fx, tap_off(0), slot1, 0);
+      }
+      slot = slot1;
+    }
+  }
+
+  // ---- epilogue (cf_igemm.hip's): per-wave transpose through LDS, 32 rows at a time, 16-byte accesses -----------------------
+  // (the loop's closing barrier retired every LDS read of the main loop)
+  constexpr int LDW = C::LDW;
+  constexpr int Q = NI * 8;   // float4 per tile row
+  constexpr int RPP = 64 / Q;  // rows per pass
+  constexpr int PASSES = 32 / RPP;
+  auto epilogue = [&](auto mode) {
+    constexpr int EPI = decltype(mode)::value;
+    float* stage = smem + wave * (32 * LDW);
+    const int cq = lane % Q, rl = lane / Q;
+    const int n = n0 + wn * (NI * 32) + cq * 4;
+    const bool nvalid = n < a.cout;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias && nvalid) bias4 = *reinterpret_cast<const f32x4*>(a.bias + n);
+    const float s = a.acc_scale;
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      size_t offs[PASSES];
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p) {
+        const int row = wm * 64 + mi * 32 + p * RPP + rl;
+        size_t pixel;
+        if (TAPS == 4)
+          pixel = ((size_t)b * a.hout + (2 * (y0 + (row >> 4)) + sub_y)) * a.wout + (2 * (x0 + (row & 15)) + sub_x);
+        else
+          pixel = ((size_t)b * a.hout + (y0 + (row >> 4))) * a.wout + (x0 + (row & 15));
+        offs[p] = pixel * a.cout + n;
+      }
+      // residual / SFT operands are requested before the transpose so that their latency overlaps it
+      f32x4 r0[PASSES], r1[PASSES];
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p) {
+        r0[p] = r1[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (nvalid && (EPI == CF_EPI_RESIDUAL || EPI == CF_EPI_SFT)) r0[p] = *reinterpret_cast<const f32x4*>(a.res + offs[p]);
+        if (nvalid && EPI == CF_EPI_SFT) r1[p] = *reinterpret_cast<const f32x4*>(a.sft_scale + offs[p]);
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stage[cf_acc_row(r, lane) * LDW + ni * 32 + l31] = acc[mi][ni][r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(stage + (p * RPP + rl) * LDW + cq * 4);
+        if (nvalid) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] * s + bias4[e];
+          if (EPI == CF_EPI_RESIDUAL) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += r0[p][e];
+          } else if (EPI == CF_EPI_SFT) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = r0[p][e] + a.sft_w * (r0[p][e] * r1[p][e] + v[e]);
+          }
+          *reinterpret_cast<f32x4*>(a.out + offs[p]) = v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            ssum[e] += v[e];
+            ssq[e] += v[e] * v[e];
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();  // the staging rows are rewritten by the next 32-row block
+    }
+    if (a.stats_out) {
+      // GroupNorm statistics of the values just written (fp64 partials, fixed shuffle order): one partial per
+      // (image, group, tile, wave row) -- nparts = tiles_per_img * 4
+      const int cpg = a.stats_cpg;
+      double d0, q0, d1 = 0, q1 = 0;
+      if (cpg == 2) {  // two groups per lane
+        d0 = (double)ssum[0] + ssum[1];
+        q0 = (double)ssq[0] + ssq[1];
+        d1 = (double)ssum[2] + ssum[3];
+        q1 = (double)ssq[2] + ssq[3];
+      } else {
+        d0 = ((double)ssum[0] + ssum[1]) + ((double)ssum[2] + ssum[3]);
+        q0 = ((double)ssq[0] + ssq[1]) + ((double)ssq[2] + ssq[3]);
+      }
+      for (int o = Q; o < 64; o <<= 1) {  // lanes holding the same channels, different rows
+        d0 += __shfl_xor(d0, o, 64);
+        q0 += __shfl_xor(q0, o, 64);
+        d1 += __shfl_xor(d1, o, 64);
+        q1 += __shfl_xor(q1, o, 64);
+      }
+      for (int o = 1; o * 4 < cpg; o <<= 1) {  // adjacent channel quads of one group (cpg >= 8)
+        d0 += __shfl_xor(d0, o, 64);
+        q0 += __shfl_xor(q0, o, 64);
+      }
+      if (rl == 0 && nvalid && (n % cpg) == 0) {
+        const size_t pidx = (size_t)(mt - b * a.tiles_per_img) * SP_WM + wm;
+        const int ng = a.cout / cpg;
+        double* o = a.stats_out + (((size_t)b * ng + n / cpg) * a.nparts + pidx) * 2;
+        o[0] = d0;
+        o[1] = q0;
+        if (cpg == 2) {
+          o[(size_t)a.nparts * 2] = d1;  // group n/2 + 1
+          o[(size_t)a.nparts * 2 + 1] = q1;
+        }
+      }
+    }
+  };
+  switch (a.epilogue) {
+    case CF_EPI_RESIDUAL: epilogue(std::integral_constant<int, CF_EPI_RESIDUAL>{}); break;
+    case CF_EPI_SFT: epilogue(std::integral_constant<int, CF_EPI_SFT>{}); break;
+    default: epilogue(std::integral_constant<int, CF_EPI_NONE>{}); break;
+  }
+}
+
+// packed slab entry (cf_igemm.hip's rule): plain tap, or the pre-summed taps of the folded nearest-x2 + 3x3
+__device__ __forceinline__ float split_weight_value(const float* __restrict__ w, int cout, int cin, int fold, int slab, int n, int c) {
+  if (n >= cout || c >= cin) return 0.f;
+  const float* wk = w + ((long)n * cin + c) * 9;
+  if (!fold) return wk[slab];
+  const int cls = slab >> 2, t2 = slab & 3;
+  const int sy = cls >> 1, sx = cls & 1, ty = t2 >> 1, tx = t2 & 1;
+  const int ky0 = sy == 0 ? (ty == 0 ? 0 : 1) : (ty == 0 ? 0 : 2), ky1 = sy == 0 ? (ty == 0 ? 0 : 2) : (ty == 0 ? 1 : 2);
+  const int kx0 = sx == 0 ? (tx == 0 ? 0 : 1) : (tx == 0 ? 0 : 2), kx1 = sx == 0 ? (tx == 0 ? 0 : 2) : (tx == 0 ? 1 : 2);
+  float v = 0.f;
+  for (int ky = ky0; ky <= ky1; ++ky)
+    for (int kx = kx0; kx <= kx1; ++kx) v += wk[ky * 3 + kx];
+  return v;
+}
+
+// [slab][cin/32][cout_pad][32 words]: words 0..15 = hi halves of channels (2k, 2k+1), words 16..31 = their lo halves
+__global__ void pack_weight_f16x2_kernel(const float* __restrict__ w, int cout, int cin, int fold, int cout_pad, int nchunks,
+                                         float scale, unsigned* __restrict__ packed, long total_words) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total_words) return;
+  const int k2 = (int)(i & 15), part = (int)((i >> 4) & 1);
+  long r = i >> 5;
+  const int n = (int)(r % cout_pad);
+  r /= cout_pad;
+  const int chunk = (int)(r % nchunks);
+  const int slab = (int)(r / nchunks);
+  unsigned out = 0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float v = split_weight_value(w, cout, cin, fold, slab, n, chunk * 32 + k2 * 2 + h) * scale;  // exact: power of two
+    const _Float16 hi = (_Float16)v;
+    const _Float16 hv = part ? (_Float16)(v - (float)hi) : hi;
+    out |= (unsigned)__builtin_bit_cast(unsigned short, hv) << (16 * h);
+  }
+  packed[i] = out;
+}
+
+template <int TAPS, int NI>
+int split_launch(SplitArgs& k, int batch, hipStream_t stream) {
+  using C = SplitCfg<TAPS, NI>;
+  k.ntn = k.cout_pad / C::BN;
+  auto kern = split_conv_kernel<TAPS, NI>;
+  constexpr size_t lds = C::LDS_FLOATS * sizeof(float);
+  static unsigned long long attr_devs = 0;  // bit d: the LDS attribute has been set on device d (it is a per-device property)
+  int dev = 0;
+  hipGetDevice(&dev);
+  if (dev >= 64 || !((attr_devs >> dev) & 1ull)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      cf_set_error("cf_conv2d(f16x2): hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+      return CF_ERR_LAUNCH;
+    }
+    if (dev < 64) attr_devs |= 1ull << dev;  // benign race: the attribute call is idempotent
+  }
+  hipLaunchKernelGGL(kern, dim3(k.tiles_per_img * batch * k.ntn), dim3(SP_NT), lds, stream, k);
+  CF_CHECK_LAUNCH("cf_conv2d(f16x2)");
+  return CF_OK;
+}
+
+}  // namespace
+
+extern "C" int cf_pack_conv_weight_f16x2(const float* w, int cout, int cin, int up2x, int cout_pad, int cin_pad, float scale,
+                                         void* packed, cf_stream_t stream) {
+  CF_REQUIRE(w && packed, "cf_pack_conv_weight_f16x2: null pointer");
+  CF_REQUIRE(cin_pad % 32 == 0 && cin_pad >= cin && cout_pad >= cout && cout_pad % 64 == 0,
+             "cf_pack_conv_weight_f16x2: bad padding cin %d->%d cout %d->%d", cin, cin_pad, cout, cout_pad);
+  int ex = 0;
+  CF_REQUIRE(scale > 0.f && frexpf(scale, &ex) == 0.5f, "cf_pack_conv_weight_f16x2: scale %g is not a power of two", (double)scale);
+  const long words = (long)(up2x ? 16 : 9) * cin_pad * cout_pad;  // two halves per word, hi + lo per channel: one word per weight
+  hipLaunchKernelGGL(pack_weight_f16x2_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, cout, cin,
+                     up2x ? 1 : 0, cout_pad, cin_pad / 32, scale, reinterpret_cast<unsigned*>(packed), words);
+  CF_CHECK_LAUNCH("cf_pack_conv_weight_f16x2");
+  return CF_OK;
+}
+
+// Called by cf_conv2d (cf_igemm.hip) for descriptors with bf16_mfma == CF_OPERAND_F16X2; the common argument checks have run.
+int cf_split_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query) {
+  CF_REQUIRE(d->taps == 9 && d->stride == 1 && !d->in_nchw && !d->out_nchw && !d->winograd,
+             "cf_conv2d: f16x2 operands cover 3x3 stride-1 NHWC convolutions (plain or nearest-x2 folded)");
+  CF_REQUIRE(d->c0 % 32 == 0 && d->c1 % 32 == 0, "cf_conv2d(f16x2): input channels (%d, %d) must be multiples of 32", d->c0, d->c1);
+  CF_REQUIRE(d->cout_pad % 64 == 0 && d->cout % 4 == 0 && d->cout_pad == (d->cout + 63) / 64 * 64,
+             "cf_conv2d(f16x2): cout %d / cout_pad %d (pad to a multiple of 64)", d->cout, d->cout_pad);
+  CF_REQUIRE(d->hin % 16 == 0 && d->win % 16 == 0, "cf_conv2d(f16x2): %dx%d input is not a multiple of the 16x16 tile", d->hin, d->win);
+  CF_REQUIRE(d->epilogue == CF_EPI_NONE || d->epilogue == CF_EPI_RESIDUAL || d->epilogue == CF_EPI_SFT,
+             "cf_conv2d(f16x2): epilogues are none / residual / SFT");
+  CF_REQUIRE(d->pad_mode == CF_PAD_ZERO && (d->ld_in0 == 0 || d->ld_in0 == d->c0) && (d->ld_in1 == 0 || d->ld_in1 == d->c1) &&
+                 (d->ld_out == 0 || d->ld_out == d->cout),
+             "cf_conv2d(f16x2): dense tensors with zero padding only");
+  CF_REQUIRE(d->acc_scale > 0.f, "cf_conv2d(f16x2): acc_scale must be the inverse of the pack-time weight scale (got %g)",
+             (double)d->acc_scale);
+  SplitArgs a;
+  a.in0 = d->in0;
+  a.in1 = d->in1;
+  a.c0 = d->c0;
+  a.c1 = d->c1;
+  a.cin = d->c0 + d->c1;
+  a.nchunks = a.cin / SP_KC;
+  a.batch = d->batch;
+  a.hin = d->hin;
+  a.win = d->win;
+  a.hout = d->hout;
+  a.wout = d->wout;
+  a.cout = d->cout;
+  a.cout_pad = d->cout_pad;
+  a.prologue = d->prologue;
+  a.epilogue = d->epilogue;
+  a.pro_scale = d->pro_scale;
+  a.pro_shift = d->pro_shift;
+  a.weight = d->weight;
+  a.bias = d->bias;
+  a.res = d->res;
+  a.sft_scale = d->sft_scale;
+  a.sft_w = d->sft_w;
+  a.acc_scale = d->acc_scale;
+  a.out = d->out;
+  a.stats_out = d->stats_out;
+  a.stats_cpg = d->stats_cpg > 0 ? d->stats_cpg : 1;
+  a.tiles_x = d->win / 16;  // tiles live on the SOURCE grid (== the output grid unless upsample)
+  a.tiles_per_img = (d->upsample ? 4 : 1) * a.tiles_x * (d->hin / 16);
+  a.nparts = a.tiles_per_img * SP_WM;
+  a.ntn = 0;
+  if (parts_query) {
+    *parts_query = a.nparts;
+    return CF_OK;
+  }
+  const bool wide = d->cout_pad % 128 == 0;
+  if (d->upsample) return wide ? split_launch<4, 2>(a, d->batch, stream) : split_launch<4, 1>(a, d->batch, stream);
+  return wide ? split_launch<9, 2>(a, d->batch, stream) : split_launch<9, 1>(a, d->batch, stream);
+}

@@ -242,6 +242,34 @@ def vq_nearest(z, codebook):
     return z_q, idx, d
 
 
+def vq_forward(z, codebook, beta):
+    """VectorQuantizer.forward with its statistics (basicsr/archs/vqgan_arch.py:33-70): distances, mean_distance (:42),
+    argmin (:44), one-hot min_encodings (:49-50), z_q = one-hot x codebook (:53), loss = mse + beta * mse (:55),
+    straight-through z_q (:57), perplexity = exp(-sum(e_mean * log(e_mean + 1e-10))) (:60-61)."""
+    zp = z.permute(0, 2, 3, 1).contiguous()
+    zf = zp.view(-1, codebook.shape[1])
+    d = (zf ** 2).sum(dim=1, keepdim=True) + (codebook ** 2).sum(1) - 2 * torch.matmul(zf, codebook.t())
+    mean_distance = torch.mean(d)
+    idx = torch.argmin(d, dim=1).unsqueeze(1)
+    enc = torch.zeros(idx.shape[0], codebook.shape[0]).to(z)
+    enc.scatter_(1, idx, 1)
+    z_q = torch.matmul(enc, codebook).view(zp.shape)
+    loss = torch.mean((z_q - zp) ** 2) + beta * torch.mean((z_q - zp) ** 2)
+    z_q = zp + (z_q - zp)
+    e_mean = torch.mean(enc, dim=0)
+    perplexity = torch.exp(-torch.sum(e_mean * torch.log(e_mean + 1e-10)))
+    return {'z_q': z_q.permute(0, 3, 1, 2).contiguous(), 'loss': loss, 'perplexity': perplexity, 'min_encodings': enc,
+            'min_encoding_indices': idx, 'mean_distance': mean_distance}
+
+
+def inpaint_composite(x, y):
+    """Inpainting composite (inference_inpainting.py:68-74): mask = pixels whose three normalised input channels sum to
+    exactly 3 (pure white brush); result = (1 - mask) * x + mask * y, evaluated in fp32 in that order."""
+    mask = torch.zeros(x.shape[0], 1, x.shape[2], x.shape[3], dtype=x.dtype)
+    mask[torch.sum(x, dim=1, keepdim=True) == 3] = 1.0
+    return (1 - mask) * x + mask * y
+
+
 FUSE_ENC_BLOCK = {'512': 2, '256': 5, '128': 8, '64': 11, '32': 14, '16': 18}   # codeformer_arch.py:203
 FUSE_GEN_BLOCK = {'16': 6, '32': 9, '64': 12, '128': 15, '256': 18, '512': 21}  # codeformer_arch.py:205
 

@@ -98,3 +98,32 @@ def load_reference_parsenet():
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     return m
+
+
+def load_reference_img_util():
+    """The reference's basicsr/utils/img_util.py (img2tensor / tensor2img, the tensor boundary of
+    inference_codeformer.py:199-206) with stand-ins for the two imports this container lacks: `cv2.cvtColor` is only
+    used for the BGR<->RGB swap (a channel reversal, exact for every dtype) and `torchvision.utils.make_grid` only for 4-D
+    batches (never reached: the callers pass one face)."""
+    if not available():
+        raise RuntimeError(f'reference not found under {REF}')
+    import numpy as np
+    saved = {k: sys.modules.get(k) for k in ('cv2', 'torchvision', 'torchvision.utils')}
+    cv2 = types.ModuleType('cv2')
+    cv2.COLOR_BGR2RGB, cv2.COLOR_RGB2BGR = 4, 4
+    cv2.cvtColor = lambda img, code: np.ascontiguousarray(img[:, :, ::-1])
+    tv, tvu = types.ModuleType('torchvision'), types.ModuleType('torchvision.utils')
+    tvu.make_grid = None
+    tv.utils = tvu
+    sys.modules.update({'cv2': cv2, 'torchvision': tv, 'torchvision.utils': tvu})
+    try:
+        spec = importlib.util.spec_from_file_location('_ref_img_util', f'{REF}/basicsr/utils/img_util.py')
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return m

@@ -61,16 +61,6 @@ def test_tensor_boundary_kernels(chk):
         assert np.array_equal(got[b], O.tensor2img_u8(x[b]))
 
 
-def test_mask_composite(chk):
-    import torch
-    from codeformer_amd import cli
-    x = torch.rand(2, 3, 32, 40, generator=torch.Generator().manual_seed(3)) * 2 - 1
-    x[0, :, 4:9, 5:20] = 1.0
-    x[1, 0, 0, 0] = 1.0  # only one channel white -> not masked
-    y = torch.randn(2, 3, 32, 40, generator=torch.Generator().manual_seed(4))
-    assert torch.equal(cli.inpaint_composite(x.cuda(), y.cuda()).cpu(), cli.inpaint_composite(x, y))
-
-
 def test_bundled_ops(chk):
     import torch
     from codeformer_amd import ops

@@ -112,3 +112,48 @@ def test_oracle_upfirdn2d_matches_reference_native():
         ref = ns['upfirdn2d_native'](x, k, up, up, down, down, pad[0], pad[1], pad[0], pad[1])
         got = O.upfirdn2d(x, k, up=up, down=down, pad=pad)
         assert got.shape == ref.shape and torch.allclose(got, ref, atol=1e-6), (up, down, pad)
+
+
+# ---- fixtures made from the reference's own input images (oracle/make_golden_real.py) ---------------------------------------
+def _input_from_u8(img_bgr):
+    """img2tensor(img/255., bgr2rgb=True, float32=True) + normalize(0.5, 0.5) (inference_codeformer.py:199-201)."""
+    t = torch.from_numpy(np.ascontiguousarray((img_bgr[:, :, ::-1] / 255.).astype(np.float32).transpose(2, 0, 1)))
+    return ((t - 0.5) / 0.5).unsqueeze(0)
+
+
+def test_oracle_on_a_real_aligned_face_matches_reference_golden(seed0_net, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'real_0143.npz'))
+    x = _input_from_u8(g['img'])
+    out, logits, lq, idx = O.codeformer_forward(x, _sd(seed0_net), w=0.5, adain_flag=True, return_idx=True)
+    assert float((logits - torch.from_numpy(g['logits'])).abs().max()) <= 2e-5
+    safe = g['gap'].reshape(-1) >= 1e-5
+    assert np.array_equal(idx.numpy().reshape(-1)[safe], g['idx'].reshape(-1)[safe])
+    assert float((out[:, :, ::4, ::4] - torch.from_numpy(g['out_sub'])).abs().max()) <= 1e-4
+    u8 = O.tensor2img_u8(out[0])
+    assert int(np.abs(u8.astype(np.int16) - g['out_u8'].astype(np.int16)).max()) <= 1 and (u8 != g['out_u8']).mean() < 1e-4
+
+
+def test_oracle_vq_forward_statistics_match_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'vq_seed11.npz'))
+    s = np.load(os.path.join(golden_dir, 'vq_stats_seed11.npz'))
+    o = O.vq_forward(torch.from_numpy(g['z']), torch.from_numpy(g['codebook']), 0.25)
+    assert np.array_equal(o['min_encoding_indices'].view(-1).numpy(), g['idx'])
+    assert np.array_equal(o['min_encodings'].sum(0).numpy(), s['counts'])
+    for k in ('loss', 'perplexity', 'mean_distance'):
+        assert abs(float(o[k]) - float(s[k])) <= 1e-6 * abs(float(s[k])), k
+
+
+def test_oracle_tensor2img_and_composite_match_reference_golden(golden_dir):
+    k = np.load(os.path.join(golden_dir, 'tensor2img_kat.npz'))
+    assert np.array_equal(O.tensor2img_u8(torch.from_numpy(k['t'])), k['img'])
+    rep = json.load(open(os.path.join(golden_dir, 'real_oracle_vs_reference.json')))
+    assert rep['00105.png']['oracle_composite_equal'] and rep['00105.png']['masked_pixels'] > 1000
+    for name in ('0143.png', '0342.png', 'Solvay_conference_1927_0018.png'):
+        assert rep[name]['oracle_out'] <= 1e-5 and rep[name]['idx_equal'] and rep[name]['oracle_u8_equal']
+    # composite restatement on the stored mask: white input pixels take the network output, the rest keep the input
+    g = np.load(os.path.join(golden_dir, 'real_masked_00105.npz'))
+    x = _input_from_u8(g['img'])
+    y = torch.zeros_like(x) - 0.25
+    comp = O.inpaint_composite(x, y)
+    m = torch.from_numpy(g['mask']).bool().expand_as(x)
+    assert torch.equal(comp[m], y[m]) and torch.equal(comp[~m], x[~m])

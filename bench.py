@@ -164,7 +164,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch-per-gpu', type=int, default=16)
     ap.add_argument('--w', type=float, default=0.5)
-    ap.add_argument('--precision', choices=['fp32', 'bf16', 'fp16'], default='fp32',
+    ap.add_argument('--precision', choices=['fp32', 'f16x2', 'bf16', 'fp16'], default='fp32',
                     help="fp32 = BASELINE config 2 (the headline); bf16 = generator + CFT on bf16 MFMA operands (configs 3/5), "
                          "encoder / Transformer / argmax stay fp32")
     ap.add_argument('--no-cpu-baseline', action='store_true')

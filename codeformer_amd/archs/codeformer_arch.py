@@ -230,9 +230,9 @@ class CodeFormer(VQAutoEncoder):
                                     lq=tokens.view(B, T, -1) if adain else None)
         quant = quant.view(B, lq.shape[1], lq.shape[2], -1)
 
-        if self.precision not in ('fp32', 'bf16', 'fp16'):
-            raise ValueError(f"precision must be 'fp32', 'bf16' or 'fp16', got {self.precision!r}")
-        bf16 = {'fp32': 0, 'bf16': 1, 'fp16': 2}[self.precision]   # operand code of the generator + CFT 3x3 convs
+        if self.precision not in ('fp32', 'f16x2', 'bf16', 'fp16'):
+            raise ValueError(f"precision must be 'fp32', 'f16x2', 'bf16' or 'fp16', got {self.precision!r}")
+        bf16 = {'fp32': 0, 'f16x2': ops.SPLIT, 'bf16': 1, 'fp16': 2}[self.precision]   # operand code of the generator + CFT 3x3 convs
         if bf16 == 0 and self.winograd:
             bf16 = ops.WINOGRAD
         gen_taps = None

@@ -30,13 +30,18 @@ class HipModule(nn.Module):
             PACK_EPOCH[0] += 1
         return ent[1]
 
-    def _pw_conv(self, name, bf16=False, up2x=False, f16=False, hw=None):
+    def _pw_conv(self, name, bf16=False, up2x=False, f16=False, hw=None, c_split=None):
+        """Packed weight of a conv / linear sub-module for operand code `bf16` (0 fp32, 1 bf16, 2 IEEE half, ops.WINOGRAD,
+        ops.SPLIT).  The Winograd and split-half kernels need the conv's INPUT size `hw` (and the concat boundary `c_split`);
+        shapes they do not cover fall back as ops.conv_code says."""
         conv = getattr(self, name) if isinstance(name, str) else name
-        code = 2 if f16 else int(bf16)   # 0 fp32, 1 bf16, 2 IEEE half operands, 3 fp32 Winograd (`bf16` may carry the code)
-        if code == ops.WINOGRAD:         # needs the output size (`hw`); shapes the Winograd kernel does not cover run direct
+        code = 2 if f16 else int(bf16)
+        if code in (ops.WINOGRAD, ops.SPLIT):
             cout, cin = conv.weight.shape[:2]
-            if up2x or hw is None or tuple(conv.weight.shape[2:]) != (3, 3) or not ops.winograd_ok(cin, cout, hw[0], hw[1]):
+            if hw is None or tuple(conv.weight.shape[2:]) != (3, 3):
                 code = 0
+            else:
+                code = ops.conv_code(code, cin, cout, hw[0], hw[1], up2x=up2x, c_split=c_split)
         key = (name if isinstance(name, str) else id(conv), code, bool(up2x))
         return self._packed(key, lambda: ops.pack_weight(conv.weight, conv.bias, bf16=code, up2x=up2x), conv.weight, conv.bias)
 

@@ -124,7 +124,7 @@ class Upsample(HipModule):
         self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
 
     def forward_nhwc(self, x, bf16=False):
-        return ops.conv2d(x, self._pw_conv('conv', bf16, up2x=True), upsample=True, emit_stats=True)
+        return ops.conv2d(x, self._pw_conv('conv', bf16, up2x=True, hw=x.shape[1:3]), upsample=True, emit_stats=True)
 
     def forward_host(self, x):
         return self.conv(F.interpolate(x, scale_factor=2.0, mode='nearest'))
@@ -154,7 +154,7 @@ class ResBlock(HipModule):
         xs = (x,) if x2 is None else (x, x2)
         sc, sh = _gn_tables(self.norm1, *xs)
         hw = x.shape[1:3]
-        h = ops.conv2d(x, self._pw_conv('conv1', bf16, hw=hw), x2=x2, prologue=PRO_AFFINE_SWISH, scale=sc, shift=sh, emit_stats=True)
+        h = ops.conv2d(x, self._pw_conv('conv1', bf16, hw=hw, c_split=None if x2 is None else x.shape[3]), x2=x2, prologue=PRO_AFFINE_SWISH, scale=sc, shift=sh, emit_stats=True)
         sc, sh = _gn_tables(self.norm2, h)
         if self.in_channels != self.out_channels:
             skip = ops.conv2d(x, self._pw_conv('conv_out'), x2=x2)
@@ -225,11 +225,9 @@ class _Conv3x3(HipModule):
 
     def forward_nhwc(self, x, bf16=False, **kw):
         plain = not kw.get('out_nchw') and not kw.get('in_nchw')
-        code = int(bf16)                 # operand code: 0 fp32 / 1 bf16 / 2 f16 / 3 fp32 Winograd
-        if code == ops.WINOGRAD:
-            code = code if plain and ops.winograd_ok(self.in_channels, self.out_channels, x.shape[1], x.shape[2]) else 0
-        elif not (plain and self.in_channels % 32 == 0 and self.out_channels % 4 == 0):
-            code = 0
+        # operand code: 0 fp32 / 1 bf16 / 2 f16 / ops.WINOGRAD / ops.SPLIT, reduced to what this layer's shape supports
+        h, w = (x.shape[2], x.shape[3]) if kw.get('in_nchw') else (x.shape[1], x.shape[2])
+        code = ops.conv_code(bf16, self.in_channels, self.out_channels, h, w, plain=plain)
         return ops.conv2d(x, self.pw(code), **kw)
 
     def forward_host(self, x):

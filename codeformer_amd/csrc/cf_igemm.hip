@@ -1103,6 +1103,7 @@ extern "C" int cf_pack_conv_weight(const float* w, int cout, int cin, int taps, 
 }
 
 int cf_winograd_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query);  // cf_winograd.hip
+int cf_split_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query);     // cf_split.hip
 
 static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
   CF_REQUIRE(d, "cf_conv2d: null descriptor");
@@ -1134,8 +1135,8 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
                d->c0, d->c1);
     CF_REQUIRE(d->c1 == 0 || d->in1, "cf_conv2d: c1 > 0 without in1");
   }
-  CF_REQUIRE(d->bf16_mfma >= CF_OPERAND_F32 && d->bf16_mfma <= CF_OPERAND_F16, "cf_conv2d: bad operand format %d", d->bf16_mfma);
-  if (d->bf16_mfma)
+  CF_REQUIRE(d->bf16_mfma >= CF_OPERAND_F32 && d->bf16_mfma <= CF_OPERAND_F16X2, "cf_conv2d: bad operand format %d", d->bf16_mfma);
+  if (d->bf16_mfma == CF_OPERAND_BF16 || d->bf16_mfma == CF_OPERAND_F16)
     CF_REQUIRE(d->taps == 9 && d->stride == 1 && !d->in_nchw && !d->out_nchw && d->c0 % 32 == 0 && d->c1 % 32 == 0 &&
                    d->cout_pad % (d->bf16_mfma == CF_OPERAND_F16 ? 32 : 64) == 0 && d->cout % 4 == 0,
                "cf_conv2d: bf16_mfma covers 3x3 stride-1 NHWC convs with channels %% 32 == 0 (c0=%d c1=%d cout_pad=%d)", d->c0,
@@ -1160,7 +1161,7 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
              "cf_conv2d: reflect padding is for plain 3x3 convs on images of at least 2x2");
   CF_REQUIRE(d->pad_mode != CF_PAD_EDGE || d->upsample, "cf_conv2d: edge padding belongs to the folded upsample conv");
   CF_REQUIRE(d->pad_lo == 0 || d->stride == 2, "cf_conv2d: pad_lo applies to stride 2");
-  const bool ext = !d->winograd && (ld0 != d->c0 || ld1 != d->c1 || ldo != d->cout || d->epilogue >= CF_EPI_LEAKY ||
+  const bool ext = !d->winograd && d->bf16_mfma != CF_OPERAND_F16X2 && (ld0 != d->c0 || ld1 != d->c1 || ldo != d->cout || d->epilogue >= CF_EPI_LEAKY ||
                    ((d->pad_mode != CF_PAD_ZERO || d->pad_lo) && !(d->out_nchw && d->cout <= 4)) ||
                    (d->bf16_mfma == CF_OPERAND_F16 && d->cout_pad % 64 != 0) ||
                    (d->taps == 9 && d->stride == 1 && !d->in_nchw && !few_cout && (d->hout % 16 != 0 || d->wout % 16 != 0)));
@@ -1178,6 +1179,7 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
   CF_REQUIRE(d->cout_pad >= d->cout && d->cout_pad % 32 == 0, "cf_conv2d: cout_pad %d invalid for cout %d", d->cout_pad,
              d->cout);
 
+  if (d->bf16_mfma == CF_OPERAND_F16X2) return cf_split_launch(d, stream, pq);
   if (d->winograd) return cf_winograd_launch(d, stream, pq);
 
   ConvArgsExt a;

@@ -35,19 +35,29 @@
 
 #include "cf_common.h"
 
+// SP_ABLATE: timing-only ablation builds (tools/split_ab.sh); 0 / undefined in every product build.
+#ifndef SP_ABLATE
+#define SP_ABLATE 0
+#endif
+
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int SP_NT = 512;     // threads per workgroup
-constexpr int SP_WM = 4;       // waves along M (64 pixels = 4 tile rows each)
-constexpr int SP_KC = 32;      // channels per K slab
-constexpr int SP_ROW = 36;     // floats per LDS row: 32 hi halves (64 B) | 32 lo halves (64 B) | 16 B pad.  9 x 16 B: odd, so 16
-                               // consecutive rows occupy 16 distinct 16-byte slots of the 256-byte bank window (ds_read_b128)
-constexpr int SP_PITCH = 704;  // floats between patch rows: 2816 B = 11 x 256 B, so the two patch rows a 32-lane fragment read
-                               // touches (16 pixels each) keep their bank slots disjoint (18 x 144 B unpadded would alias 4 of 16)
-constexpr int SP_LO = 16;      // float offset of the lo halves inside a row
+// Workgroup shapes: WM waves along M (64 pixels = 4 tile rows of 16 each) x 2 waves along N.
+//   WM = 2: 256 threads, 8x16 output tile, 71 KB LDS -> two workgroups per CU (their store / gather phases overlap each other's MFMA
+//           phases, and a barrier in one leaves the SIMDs to the other);   WM = 4: 512 threads, 16x16 tile, one workgroup per CU.
+#ifndef SP_WM
+#define SP_WM 2
+#endif
+constexpr int SP_KC = 32;   // channels per K slab
+constexpr int SP_PW = 18;   // LDS rows per patch row (18 halo columns; the folded upsample uses 17 of them)
+// LDS rows are 128 B = eight 16-byte chunks [hi k0-7 | hi k8-15 | hi k16-23 | hi k24-31 | lo k0-7 | ... | lo k24-31], UNPADDED; chunk c of
+// row r is stored at position c ^ s(r), s = (x >> 1) & 7 with x = the row's patch column (A) or its channel row n (B).  A 16-lane group
+// of a ds_read_b128 fragment read touches 16 consecutive x (mod 16) at one chunk c: (x & 1) picks the 128-byte half of the 256-byte
+// bank window and c ^ ((x >> 1) & 7) one of its 8 slots -- 16 distinct slots, conflict-free, also for the two patch rows of a
+// 32-pixel fragment (18 is even, so row parity == column parity).
 
 struct SplitArgs {
   const float* in0;
@@ -58,7 +68,7 @@ struct SplitArgs {
   int prologue, epilogue;
   const float* pro_scale;
   const float* pro_shift;
-  const float* weight;  // [slab][cin/32][cout_pad][hi 32 | lo 32] halves = 32 floats per row
+  const float* weight;  // [class][cin/32][tap][cout_pad][hi 32 | lo 32] halves = 32 floats per row
   const float* bias;
   const float* res;
   const float* sft_scale;
@@ -70,18 +80,23 @@ struct SplitArgs {
   int tiles_x, tiles_per_img, ntn;
 };
 
-template <int TAPS, int NI>
+template <int TAPS, int NI, int WM>
 struct SplitCfg {
+  static constexpr int NT = WM * 128;
   static constexpr int BN = 2 * NI * 32;
-  static constexpr int HH = TAPS == 9 ? 18 : 17;  // halo patch rows = columns
-  static constexpr int NPIX = HH * HH;
-  static constexpr int APT = (NPIX + 127) / 128;  // gather items (pixel, channel octet) per thread
-  static constexpr int BPT = BN * 8 / SP_NT;      // 16-byte weight items per thread and step
-  static constexpr int A_FLOATS = HH * SP_PITCH;
-  static constexpr int B_FLOATS = 3 * BN * SP_ROW;
+  static constexpr int TH = WM * 4;                       // tile rows (16 columns)
+  static constexpr int HH = TAPS == 9 ? TH + 2 : TH + 1;  // halo patch rows
+  static constexpr int HW = TAPS == 9 ? 18 : 17;          // halo patch columns
+  static constexpr int NPIX = HH * HW;
+  static constexpr int PPR = NT / 4;                      // pixels gathered per round
+  static constexpr int APT = (NPIX + PPR - 1) / PPR;      // gather items (pixel, channel octet) per thread
+  static constexpr int BPT = BN * 8 / NT;                 // 16-byte weight items per thread and step
+  static constexpr int A_FLOATS = HH * SP_PW * 32;
+  static constexpr int B_SLOT = BN * 32;
   static constexpr int LDW = NI * 32 + 4;
-  static constexpr int EPI_FLOATS = 8 * 32 * LDW;
-  static constexpr int LDS_FLOATS = (A_FLOATS + B_FLOATS) > EPI_FLOATS ? (A_FLOATS + B_FLOATS) : EPI_FLOATS;
+  static constexpr int EPI_FLOATS = WM * 2 * 32 * LDW;
+  static constexpr int MAIN_FLOATS = A_FLOATS + 3 * B_SLOT;
+  static constexpr int LDS_FLOATS = MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS;
 };
 
 // x -> (hi, lo) halves of two neighbouring channels, packed for the LDS rows
@@ -92,10 +107,11 @@ __device__ __forceinline__ void split2(float x0, float x1, float& hi, float& lo)
   lo = __builtin_bit_cast(float, l);
 }
 
-template <int TAPS, int NI>
-__global__ __launch_bounds__(SP_NT) void split_conv_kernel(const SplitArgs a) {
-  using C = SplitCfg<TAPS, NI>;
+template <int TAPS, int NI, int WM>
+__global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void split_conv_kernel(const SplitArgs a) {
+  using C = SplitCfg<TAPS, NI, WM>;
   constexpr int MI = 2;
+  constexpr int NT = C::NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const As = smem;
   float* const Bs = smem + C::A_FLOATS;
@@ -127,27 +143,27 @@ __global__ __launch_bounds__(SP_NT) void split_conv_kernel(const SplitArgs a) {
     sub_x = cls & 1;
   }
   const int tyw = rt / a.tiles_x;
-  const int y0 = tyw * 16;
+  const int y0 = tyw * C::TH;
   const int x0 = (rt - tyw * a.tiles_x) * 16;
 
-  // ---- gather geometry: item j of this thread = channel octet k8 of halo pixel p = (tid >> 2) + 128 j ----
+  // ---- gather geometry: item j of this thread = channel octet k8 of halo pixel p = (tid >> 2) + PPR j ----
   const int k8 = tid & 3;
   int pix[C::APT];   // source pixel index, -1 = zero padding / past the patch
-  int aoff[C::APT];  // LDS float offset of the item's hi halves
+  int aoff[C::APT];  // LDS float offset of the item's hi chunk (the lo chunk is at aoff ^ 16), -1 = past the patch
 #pragma unroll
   for (int j = 0; j < C::APT; ++j) {
-    const int p = (tid >> 2) + 128 * j;
-    int v = -1, off = 0;
+    const int p = (tid >> 2) + C::PPR * j;
+    int v = -1, off = -1;
     if (p < C::NPIX) {
-      const int hy = p / C::HH;
-      const int hx = p - hy * C::HH;
+      const int hy = p / C::HW;
+      const int hx = p - hy * C::HW;
       const int iy = y0 - 1 + (TAPS == 4 ? sub_y : 0) + hy;
       const int ix = x0 - 1 + (TAPS == 4 ? sub_x : 0) + hx;
       if (iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win) v = (b * a.hin + iy) * a.win + ix;
-      off = hy * SP_PITCH + hx * SP_ROW + k8 * 4;
+      off = (hy * SP_PW + hx) * 32 + ((k8 ^ ((hx >> 1) & 7)) << 2);
     }
     pix[j] = v;
-    aoff[j] = p < C::NPIX ? off : -1;
+    aoff[j] = off;
   }
 
   const bool affine = a.prologue == CF_PRO_AFFINE || a.prologue == CF_PRO_AFFINE_SWISH;
@@ -159,27 +175,27 @@ __global__ __launch_bounds__(SP_NT) void split_conv_kernel(const SplitArgs a) {
   f32x4 rsc[2], rsh[2];
   // Loads are issued unconditionally from clamped addresses (a load under a divergent branch is waited for on the spot);
   // out-of-image items are zeroed at conversion time.
-  auto load_A = [&](int chunk) {
-    const int c = chunk * SP_KC + k8 * 8;
+  auto load_A = [&](int chunk) __attribute__((always_inline)) {
+    const int c = chunk * SP_KC;  // (uniform) first channel of the slab
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      rsc[u] = *reinterpret_cast<const f32x4*>(tab_sc + (affine ? c + 4 * u : 0));
-      rsh[u] = *reinterpret_cast<const f32x4*>(tab_sh + (affine ? c + 4 * u : 0));
+      rsc[u] = *reinterpret_cast<const f32x4*>(tab_sc + (affine ? c + k8 * 8 + 4 * u : 0));
+      rsh[u] = *reinterpret_cast<const f32x4*>(tab_sh + (affine ? c + k8 * 8 + 4 * u : 0));
     }
-    const bool first = c < a.c0;
-    const float* src = first ? a.in0 : a.in1;
-    const int cs = first ? a.c0 : a.c1;
-    const int cc = first ? c : c - a.c0;
+    const bool first = c < a.c0;  // a slab never straddles the concat boundary (c0 % 32 == 0)
+    const float* src = (first ? a.in0 : a.in1) + (first ? c : c - a.c0);
+    const unsigned cs = first ? a.c0 : a.c1;
 #pragma unroll
     for (int j = 0; j < C::APT; ++j) {
-      const int pj = pix[j] < 0 ? 0 : pix[j];
+      const unsigned pj = pix[j] < 0 ? 0u : (unsigned)pix[j];
+      const float* q = src + (size_t)(pj * cs + k8 * 8);  // (element offsets fit 32 bits: tensors < 16 GiB)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) ra[j][u] = *reinterpret_cast<const f32x4*>(src + (size_t)pj * cs + cc + 4 * u);
+      for (int u = 0; u < 2; ++u) ra[j][u] = *reinterpret_cast<const f32x4*>(q + 4 * u);
     }
   };
   // prologue (GroupNorm apply / swish / LeakyReLU) + split: ra[j][0] <- 8 hi halves, ra[j][1] <- 8 lo halves.
   // Zero padding stays exactly zero: it pads the conv INPUT, i.e. the post-activation tensor.
-  auto convert_mode = [&](auto mode) {
+  auto convert_mode = [&](auto mode) __attribute__((always_inline)) {
     constexpr int PRO = decltype(mode)::value;
 #pragma unroll
     for (int j = 0; j < C::APT; ++j) {
@@ -210,7 +226,7 @@ __global__ __launch_bounds__(SP_NT) void split_conv_kernel(const SplitArgs a) {
       ra[j][1] = lo;
     }
   };
-  auto convert = [&]() {
+  auto convert = [&]() __attribute__((always_inline)) {
     switch (a.prologue) {
       case CF_PRO_AFFINE: convert_mode(std::integral_constant<int, CF_PRO_AFFINE>{}); break;
       case CF_PRO_AFFINE_SWISH: convert_mode(std::integral_constant<int, CF_PRO_AFFINE_SWISH>{}); break;
@@ -218,43 +234,54 @@ __global__ __launch_bounds__(SP_NT) void split_conv_kernel(const SplitArgs a) {
       default: convert_mode(std::integral_constant<int, CF_PRO_NONE>{}); break;
     }
   };
-  auto store_A = [&]() {
+  auto store_A = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < C::APT; ++j) {
-      if ((j + 1) * 128 <= C::NPIX || aoff[j] >= 0) {
+      if ((j + 1) * C::PPR <= C::NPIX || aoff[j] >= 0) {
         *reinterpret_cast<f32x4*>(As + aoff[j]) = ra[j][0];
-        *reinterpret_cast<f32x4*>(As + aoff[j] + SP_LO) = ra[j][1];
+        *reinterpret_cast<f32x4*>(As + (aoff[j] ^ 16)) = ra[j][1];  // chunk c + 4: bit 2 of the chunk index = bit 4 of the float offset
       }
     }
   };
 
+  // weight slabs: consecutive steps (slab-major, tap-minor) are consecutive [cout_pad][32] blocks of the packed tensor
+  const size_t wstride = (size_t)a.cout_pad * 32;
+  const float* const wbase = a.weight + (TAPS == 4 ? (size_t)(sub_y * 2 + sub_x) * a.nchunks * TAPS * wstride : 0) + (size_t)n0 * 32;
+  int boff[C::BPT];  // LDS float offset inside a ring slot
+#pragma unroll
+  for (int j = 0; j < C::BPT; ++j) {
+    const int f = tid + NT * j, row = f >> 3, c = f & 7;
+    boff[j] = row * 32 + ((c ^ ((row >> 1) & 7)) << 2);
+  }
   f32x4 rb[C::BPT];
-  auto load_B = [&](int step) {
-    const int chunk = step / TAPS;
-    const int tap = step - chunk * TAPS;
-    const int cls_tap = (TAPS == 4) ? (sub_y * 2 + sub_x) * 4 + tap : tap;  // folded upsample: [class][tap] slabs
-    const float* src = a.weight + ((size_t)(cls_tap * a.nchunks + chunk) * a.cout_pad + n0) * 32;
+  auto load_B = [&](int step) __attribute__((always_inline)) {
+    const float* src = wbase + (size_t)step * wstride;
 #pragma unroll
-    for (int j = 0; j < C::BPT; ++j) rb[j] = *reinterpret_cast<const f32x4*>(src + (tid + SP_NT * j) * 4);
+    for (int j = 0; j < C::BPT; ++j) rb[j] = *reinterpret_cast<const f32x4*>(src + (tid + NT * j) * 4);
   };
-  auto store_B = [&](int slot) {
-    float* dst = Bs + slot * (C::BN * SP_ROW);
+  auto store_B = [&](int slot) __attribute__((always_inline)) {
+    float* dst = Bs + slot * C::B_SLOT;
 #pragma unroll
-    for (int j = 0; j < C::BPT; ++j) {
-      const int f = tid + SP_NT * j;
-      *reinterpret_cast<f32x4*>(dst + (f >> 3) * SP_ROW + (f & 7) * 4) = rb[j];
-    }
+    for (int j = 0; j < C::BPT; ++j) *reinterpret_cast<f32x4*>(dst + boff[j]) = rb[j];
   };
 
-  // ---- MFMA operand rows of this lane: lane l holds row l & 31, k = (l >> 5) * 8 .. + 7 of a 16-wide K block ----
-  int a_off[MI], b_off[NI];
+  // ---- MFMA operand addresses of this lane: lane l holds row l & 31, k = (l >> 5) * 8 .. + 7 of a 16-wide K block --------------
+  // chunk of (part, kk) = part*4 + kk*2 + half; swizzled position = chunk ^ s, i.e. float offset (part*16 + kk*8) ^ ((half ^ s) << 2)
+  const int px = l31 & 15;
+  int a_adr[3][4];  // [tap column tx][part*2 + kk]: patch pixel (py0, px + tx); mi / tap row are immediate offsets
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    const int row = wm * 64 + mi * 32 + l31;
-    a_off[mi] = (row >> 4) * SP_PITCH + (row & 15) * SP_ROW + half * 4;
+  for (int tx = 0; tx < 3; ++tx) {
+    const int hx = px + tx;
+    const int hs = ((half ^ (hx >> 1)) & 7) << 2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a_adr[tx][q] = ((wm * 4 + (l31 >> 4)) * SP_PW + hx) * 32 + ((q * 8) ^ hs);
   }
+  int b_adr[4];
+  {
+    const int hs = ((half ^ (l31 >> 1)) & 7) << 2;  // (ni*32 and wn*64 leave bits 1..3 of n alone)
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) b_off[ni] = (wn * (NI * 32) + ni * 32 + l31) * SP_ROW + half * 4;
+    for (int q = 0; q < 4; ++q) b_adr[q] = (wn * (NI * 32) + l31) * 32 + ((q * 8) ^ hs);
+  }
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -267,20 +294,21 @@ __global__ __launch_bounds__(SP_NT) void split_conv_kernel(const SplitArgs a) {
   struct Frags {
     f32x4 ah[MI], al[MI], bh[NI], bl[NI];
   };
-  auto read_frags = [&](Frags& f, int tapoff, int slot, int kk) {  // kk: 16-wide K block of the slab (0 / 1)
+  auto read_frags = [&](Frags& f, int tap, int slot, int kk) __attribute__((always_inline)) {  // kk: 16-wide K block of the slab
+    const int ty = TAPS == 4 ? (tap >> 1) : tap / 3, tx = TAPS == 4 ? (tap & 1) : tap % 3;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-      f.ah[mi] = *reinterpret_cast<const f32x4*>(As + a_off[mi] + tapoff + kk * 8);
-      f.al[mi] = *reinterpret_cast<const f32x4*>(As + a_off[mi] + tapoff + kk * 8 + SP_LO);
+      f.ah[mi] = *reinterpret_cast<const f32x4*>(As + a_adr[tx][kk] + (mi * 2 + ty) * (SP_PW * 32));
+      f.al[mi] = *reinterpret_cast<const f32x4*>(As + a_adr[tx][2 + kk] + (mi * 2 + ty) * (SP_PW * 32));
     }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-      f.bh[ni] = *reinterpret_cast<const f32x4*>(Bs + slot * (C::BN * SP_ROW) + b_off[ni] + kk * 8);
-      f.bl[ni] = *reinterpret_cast<const f32x4*>(Bs + slot * (C::BN * SP_ROW) + b_off[ni] + kk * 8 + SP_LO);
+      f.bh[ni] = *reinterpret_cast<const f32x4*>(Bs + slot * C::B_SLOT + b_adr[kk] + ni * (32 * 32));
+      f.bl[ni] = *reinterpret_cast<const f32x4*>(Bs + slot * C::B_SLOT + b_adr[2 + kk] + ni * (32 * 32));
     }
   };
-  // hi*hi + hi*lo + lo*hi; consecutive MFMAs go to different accumulators
-  auto mma = [&](const Frags& f) {
+  // lo*hi + hi*lo + hi*hi; consecutive MFMAs go to different accumulators
+  auto mma = [&](const Frags& f) __attribute__((always_inline)) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -300,15 +328,14 @@ __global__ __launch_bounds__(SP_NT) void split_conv_kernel(const SplitArgs a) {
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.ah[mi]), __builtin_bit_cast(f16x8, f.bh[ni]),
                                                              acc[mi][ni], 0, 0, 0);
   };
-  auto tap_off = [](int tap) { return TAPS == 4 ? (tap >> 1) * SP_PITCH + (tap & 1) * SP_ROW : (tap / 3) * SP_PITCH + (tap % 3) * SP_ROW; };
 
   // ---- software-pipelined main loop (the schedule of cf_igemm.hip) -----------------------------------------------------------
   //     step s:  [barrier] fetch B(s+2) | read frags(s, k 16..31) | 12 MFMA on frags(s, k 0..15)
   //                        read frags(s+1, k 0..15) | 12 MFMA on frags(s, k 16..31) | LDS write B(s+2)
   // RAW: B(s+1) was written before the barrier opening step s.  WAR: ring slot (s+2)%3 last held B(s-1), whose reads every wave
   // finished before the barrier opening step s.  The halo patch is single-buffered: the slab boundary (1 step in 9) drains --
-  // barrier, patch write, barrier -- but the next slab's activations were fetched at tap 0 and converted (prologue + split) at
-  // tap 4 in the shadow of the MFMAs, so only the twelve LDS stores sit between the two barriers.
+  // barrier, patch write, barrier -- but the next slab's activations were fetched at tap 0 and converted (prologue + split) in
+  // the shadow of the MFMAs of a middle tap, so only the LDS stores sit between the two barriers.
   const int nsteps = a.nchunks * TAPS;
   load_A(0);
   load_B(0);
@@ -319,19 +346,13 @@ __global__ __launch_bounds__(SP_NT) void split_conv_kernel(const SplitArgs a) {
     load_B(1 < nsteps ? 1 : 0);
     convert();
     store_A();
-    {
-      float* dst = Bs;
 #pragma unroll
-      for (int j = 0; j < C::BPT; ++j) {
-        const int f = tid + SP_NT * j;
-        *reinterpret_cast<f32x4*>(dst + (f >> 3) * SP_ROW + (f & 7) * 4) = rb0[j];
-      }
-    }
+    for (int j = 0; j < C::BPT; ++j) *reinterpret_cast<f32x4*>(Bs + boff[j]) = rb0[j];
     store_B(1);
   }
   __syncthreads();
   Frags fx, fy;
-  read_frags(fx, tap_off(0), 0, 0);
+  read_frags(fx, 0, 0, 0);
   int slot = 0;
   int step = 0;
   constexpr int CONV_TAP = TAPS == 9 ? 4 : 2;
@@ -340,22 +361,44 @@ __global__ __launch_bounds__(SP_NT) void split_conv_kernel(const SplitArgs a) {
     for (int tap = 0; tap < TAPS; ++tap, ++step) {
       const int slot1 = slot == 2 ? 0 : slot + 1;
       const int slot2 = slot1 == 2 ? 0 : slot1 + 1;
+#if SP_ABLATE != 2
       load_B(step + 2 < nsteps ? step + 2 : nsteps - 1);  // clamped: the tail prefetches are harmless re-reads
+#endif
+#if SP_ABLATE != 7
       if (tap == 0) load_A(chunk + 1 < a.nchunks ? chunk + 1 : chunk);
-      read_frags(fy, tap_off(tap), slot, 1);
+#endif
+#if SP_ABLATE != 4
+      read_frags(fy, tap, slot, 1);
+#endif
       __builtin_amdgcn_sched_barrier(0);  // pin the fetches above the MFMA block (hipcc would sink them next to their use)
+#if SP_ABLATE != 6
       mma(fx);
+#endif
+#if SP_ABLATE != 7 && SP_ABLATE != 8
       if (tap == CONV_TAP) convert();
+#endif
       __builtin_amdgcn_sched_barrier(0);
-      if (tap != TAPS - 1) read_frags(fx, tap_off(tap + 1), slot1, 0);
+#if SP_ABLATE != 4
+      if (tap != TAPS - 1) read_frags(fx, tap + 1, slot1, 0);
+#endif
+#if SP_ABLATE != 6
       mma(fy);
+#endif
       __builtin_amdgcn_sched_barrier(0);
+#if SP_ABLATE != 3
       store_B(slot2);
+#endif
+#if SP_ABLATE != 5
       __syncthreads();
+#endif
       if (tap == TAPS - 1 && chunk + 1 < a.nchunks) {
+#if SP_ABLATE != 7
         store_A();
         __syncthreads();
-        read_frags(fx, tap_off(0), slot1, 0);
+#endif
+#if SP_ABLATE != 4
+        read_frags(fx, 0, slot1, 0);
+#endif
       }
       slot = slot1;
     }
@@ -367,7 +410,7 @@ __global__ __launch_bounds__(SP_NT) void split_conv_kernel(const SplitArgs a) {
   constexpr int Q = NI * 8;   // float4 per tile row
   constexpr int RPP = 64 / Q;  // rows per pass
   constexpr int PASSES = 32 / RPP;
-  auto epilogue = [&](auto mode) {
+  auto epilogue = [&](auto mode) __attribute__((always_inline)) {
     constexpr int EPI = decltype(mode)::value;
     float* stage = smem + wave * (32 * LDW);
     const int cq = lane % Q, rl = lane / Q;
@@ -431,7 +474,7 @@ __global__ __launch_bounds__(SP_NT) void split_conv_kernel(const SplitArgs a) {
     }
     if (a.stats_out) {
       // GroupNorm statistics of the values just written (fp64 partials, fixed shuffle order): one partial per
-      // (image, group, tile, wave row) -- nparts = tiles_per_img * 4
+      // (image, group, tile, wave row) -- nparts = tiles_per_img * WM
       const int cpg = a.stats_cpg;
       double d0, q0, d1 = 0, q1 = 0;
       if (cpg == 2) {  // two groups per lane
@@ -454,7 +497,7 @@ __global__ __launch_bounds__(SP_NT) void split_conv_kernel(const SplitArgs a) {
         q0 += __shfl_xor(q0, o, 64);
       }
       if (rl == 0 && nvalid && (n % cpg) == 0) {
-        const size_t pidx = (size_t)(mt - b * a.tiles_per_img) * SP_WM + wm;
+        const size_t pidx = (size_t)(mt - b * a.tiles_per_img) * WM + wm;
         const int ng = a.cout / cpg;
         double* o = a.stats_out + (((size_t)b * ng + n / cpg) * a.nparts + pidx) * 2;
         o[0] = d0;
@@ -466,6 +509,19 @@ __global__ __launch_bounds__(SP_NT) void split_conv_kernel(const SplitArgs a) {
       }
     }
   };
+#if SP_ABLATE == 1
+  {  // no epilogue: keep the accumulators live, write one value
+    float t = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[mi][ni][r];
+    if (t == 12345.678f) a.out[0] = t;
+    return;
+  }
+#endif
   switch (a.epilogue) {
     case CF_EPI_RESIDUAL: epilogue(std::integral_constant<int, CF_EPI_RESIDUAL>{}); break;
     case CF_EPI_SFT: epilogue(std::integral_constant<int, CF_EPI_SFT>{}); break;
@@ -488,7 +544,7 @@ __device__ __forceinline__ float split_weight_value(const float* __restrict__ w,
   return v;
 }
 
-// [slab][cin/32][cout_pad][32 words]: words 0..15 = hi halves of channels (2k, 2k+1), words 16..31 = their lo halves
+// [class][cin/32][tap][cout_pad][32 words] (class = 1 plain / 4 folded): words 0..15 = hi halves of channels (2k, 2k+1), 16..31 = lo
 __global__ void pack_weight_f16x2_kernel(const float* __restrict__ w, int cout, int cin, int fold, int cout_pad, int nchunks,
                                          float scale, unsigned* __restrict__ packed, long total_words) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -497,8 +553,11 @@ __global__ void pack_weight_f16x2_kernel(const float* __restrict__ w, int cout, 
   long r = i >> 5;
   const int n = (int)(r % cout_pad);
   r /= cout_pad;
+  const int taps = fold ? 4 : 9;
+  const int tap = (int)(r % taps);
+  r /= taps;
   const int chunk = (int)(r % nchunks);
-  const int slab = (int)(r / nchunks);
+  const int slab = (int)(r / nchunks) * 4 + tap;  // class * 4 + tap (class = 0 when not folded)
   unsigned out = 0;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -512,13 +571,13 @@ __global__ void pack_weight_f16x2_kernel(const float* __restrict__ w, int cout, 
 
 template <int TAPS, int NI>
 int split_launch(SplitArgs& k, int batch, hipStream_t stream) {
-  using C = SplitCfg<TAPS, NI>;
+  using C = SplitCfg<TAPS, NI, SP_WM>;
   k.ntn = k.cout_pad / C::BN;
-  auto kern = split_conv_kernel<TAPS, NI>;
+  auto kern = split_conv_kernel<TAPS, NI, SP_WM>;
   constexpr size_t lds = C::LDS_FLOATS * sizeof(float);
   static unsigned long long attr_devs = 0;  // bit d: the LDS attribute has been set on device d (it is a per-device property)
   int dev = 0;
-  hipGetDevice(&dev);
+  (void)hipGetDevice(&dev);
   if (dev >= 64 || !((attr_devs >> dev) & 1ull)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
@@ -527,7 +586,7 @@ int split_launch(SplitArgs& k, int batch, hipStream_t stream) {
     }
     if (dev < 64) attr_devs |= 1ull << dev;  // benign race: the attribute call is idempotent
   }
-  hipLaunchKernelGGL(kern, dim3(k.tiles_per_img * batch * k.ntn), dim3(SP_NT), lds, stream, k);
+  hipLaunchKernelGGL(kern, dim3(k.tiles_per_img * batch * k.ntn), dim3(C::NT), lds, stream, k);
   CF_CHECK_LAUNCH("cf_conv2d(f16x2)");
   return CF_OK;
 }
@@ -555,7 +614,8 @@ int cf_split_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query)
   CF_REQUIRE(d->c0 % 32 == 0 && d->c1 % 32 == 0, "cf_conv2d(f16x2): input channels (%d, %d) must be multiples of 32", d->c0, d->c1);
   CF_REQUIRE(d->cout_pad % 64 == 0 && d->cout % 4 == 0 && d->cout_pad == (d->cout + 63) / 64 * 64,
              "cf_conv2d(f16x2): cout %d / cout_pad %d (pad to a multiple of 64)", d->cout, d->cout_pad);
-  CF_REQUIRE(d->hin % 16 == 0 && d->win % 16 == 0, "cf_conv2d(f16x2): %dx%d input is not a multiple of the 16x16 tile", d->hin, d->win);
+  constexpr int TH = SP_WM * 4;
+  CF_REQUIRE(d->hin % TH == 0 && d->win % 16 == 0, "cf_conv2d(f16x2): %dx%d input is not a multiple of the %dx16 tile", d->hin, d->win, TH);
   CF_REQUIRE(d->epilogue == CF_EPI_NONE || d->epilogue == CF_EPI_RESIDUAL || d->epilogue == CF_EPI_SFT,
              "cf_conv2d(f16x2): epilogues are none / residual / SFT");
   CF_REQUIRE(d->pad_mode == CF_PAD_ZERO && (d->ld_in0 == 0 || d->ld_in0 == d->c0) && (d->ld_in1 == 0 || d->ld_in1 == d->c1) &&
@@ -591,7 +651,7 @@ int cf_split_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query)
   a.stats_out = d->stats_out;
   a.stats_cpg = d->stats_cpg > 0 ? d->stats_cpg : 1;
   a.tiles_x = d->win / 16;  // tiles live on the SOURCE grid (== the output grid unless upsample)
-  a.tiles_per_img = (d->upsample ? 4 : 1) * a.tiles_x * (d->hin / 16);
+  a.tiles_per_img = (d->upsample ? 4 : 1) * a.tiles_x * (d->hin / TH);
   a.nparts = a.tiles_per_img * SP_WM;
   a.ntn = 0;
   if (parts_query) {

@@ -41,11 +41,12 @@ class PackedWeight:
     """A conv / linear weight in the kernel layout [tap][cin_pad/16][cout_pad][16] (+ bias).
     `bf16` is the operand code of cf_conv_desc.bf16_mfma: 0 / False fp32, 1 / True bf16, 2 IEEE half."""
 
-    __slots__ = ('w', 'bias', 'cout', 'cin', 'taps', 'cout_pad', 'cin_pad', 'bf16', 'up2x', 'wino')
+    __slots__ = ('w', 'bias', 'cout', 'cin', 'taps', 'cout_pad', 'cin_pad', 'bf16', 'up2x', 'wino', 'scale')
 
-    def __init__(self, w, bias, cout, cin, taps, cout_pad, cin_pad, bf16=False, up2x=False, wino=False):
+    def __init__(self, w, bias, cout, cin, taps, cout_pad, cin_pad, bf16=False, up2x=False, wino=False, scale=1.0):
         self.w, self.bias, self.cout, self.cin, self.taps = w, bias, cout, cin, taps
         self.cout_pad, self.cin_pad, self.bf16, self.up2x, self.wino = cout_pad, cin_pad, bf16, up2x, wino
+        self.scale = scale   # f16x2 packing: the power of two the weights were multiplied by (cf_conv_desc.acc_scale = 1 / scale)
 
 
 def _cout_pad(cout):
@@ -57,11 +58,38 @@ def _cout_pad(cout):
 
 
 WINOGRAD = 3   # value of the operand-code argument that selects the Winograd F(2x2,3x3) fp32 evaluation
+SPLIT = 4      # ... the split-half evaluation: fp32 operands as hi + lo IEEE halves, 3 f16 MFMAs per product (cf_split.hip)
+OPERAND_F16X2 = 3   # enum cf_operand value behind SPLIT
+
+
+def split_ok(cin, cout, hin, win, c_split=None):
+    """Shapes the split-half kernel covers (3x3 stride-1 dense NHWC, plain or folded upsample): 32-channel K slabs (also at a
+    concat boundary), 64-wide channel tiles, whole 16x16 tiles of the conv's INPUT grid."""
+    return cin % 32 == 0 and cout % 64 == 0 and hin % 16 == 0 and win % 16 == 0 and (c_split is None or c_split % 32 == 0)
 
 
 def winograd_ok(cin, cout, hout, wout):
     """Shapes the Winograd kernel covers (3x3 stride-1 dense NHWC): whole 8x16 output patches, 64-wide channel tiles."""
     return cin % 16 == 0 and cout % 64 == 0 and hout % 8 == 0 and wout % 16 == 0
+
+
+SPLIT_MIN_PIXELS = 64 * 64   # below this input size a layer has too few 16x16 tiles to fill 256 CUs: it stays on fp32 Winograd
+
+
+def conv_code(code, cin, cout, h, w, up2x=False, c_split=None, plain=True):
+    """Operand code a 3x3 stride-1 convolution really runs with, given the requested one and its shape ((h, w) = INPUT size).
+    SPLIT falls back to WINOGRAD and WINOGRAD to the direct fp32 kernel where their kernels do not apply; the decision depends
+    on the per-image shape only (never on the batch), so results stay batch-invariant."""
+    code = int(code)
+    if code == SPLIT:
+        if plain and split_ok(cin, cout, h, w, c_split) and h * w >= SPLIT_MIN_PIXELS:
+            return SPLIT
+        code = WINOGRAD
+    if code == WINOGRAD:
+        return WINOGRAD if (plain and not up2x and winograd_ok(cin, cout, h, w)) else 0
+    if code and not (plain and cin % 32 == 0 and cout % 4 == 0):
+        return 0
+    return code
 
 
 def pack_weight(weight, bias=None, bf16=False, up2x=False, f16=False):
@@ -81,6 +109,16 @@ def pack_weight(weight, bias=None, bf16=False, up2x=False, f16=False):
         L.check(lib.cf_pack_conv_weight_winograd(L.ptr(w), cout, cin, cout, cin, L.ptr(packed), L.stream_ptr()),
                 'cf_pack_conv_weight_winograd')
         return PackedWeight(packed, b, cout, cin, 9, cout, cin, wino=True)
+    if code == SPLIT:
+        if w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or cin % 32 or cout % 64:
+            raise ValueError('f16x2 packing needs a 3x3 weight with cin % 32 == 0 and cout % 64 == 0')
+        # power-of-two scale that puts max|w'| (folded taps: at most 4 summed) into [2^14, 2^15): lo halves stay normal
+        wmax = float(w.abs().max()) * (4.0 if up2x else 1.0)
+        scale = 1.0 if wmax == 0.0 or not math.isfinite(wmax) else 2.0 ** (14 - math.frexp(wmax)[1] + 1)
+        packed = torch.empty((16 if up2x else 9) * cin * cout, dtype=torch.float32, device=w.device)
+        L.check(lib.cf_pack_conv_weight_f16x2(L.ptr(w), cout, cin, int(bool(up2x)), cout, cin, scale, L.ptr(packed), L.stream_ptr()),
+                'cf_pack_conv_weight_f16x2')
+        return PackedWeight(packed, b, cout, cin, 9, cout, cin, bf16=OPERAND_F16X2, up2x=bool(up2x), scale=scale)
     if w.dim() == 4:
         if w.shape[2] != w.shape[3] or w.shape[2] not in (1, 3):
             raise ValueError(f'unsupported kernel size {tuple(w.shape[2:])}')
@@ -191,7 +229,8 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
         out_nchw=int(bool(out_nchw)), prologue=prologue, epilogue=epilogue, pro_scale=L.ptr(scale),
         pro_shift=L.ptr(shift), weight=L.ptr(pw.w), bias=L.ptr(pw.bias), res=L.ptr(res, True),
         sft_scale=L.ptr(sft_scale, True), sft_w=float(sft_w), out=L.ptr(out, not out_nchw), bf16_mfma=int(pw.bf16),
-        ld_in0=ld0, ld_in1=ld1, ld_out=ldo, pad_mode=int(pad_mode), pad_lo=int(pad_lo), winograd=int(pw.wino))
+        ld_in0=ld0, ld_in1=ld1, ld_out=ldo, pad_mode=int(pad_mode), pad_lo=int(pad_lo), winograd=int(pw.wino),
+        acc_scale=1.0 / pw.scale)
     if emit_stats and not out_nchw and pw.cout % GN_GROUPS == 0 and pw.cout // GN_GROUPS >= 2:
         d.stats_cpg = pw.cout // GN_GROUPS
         parts = lib.cf_conv2d_stats_parts(ctypes.byref(d))
@@ -214,6 +253,8 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
                     + (0 if res is None else res.numel()) + (0 if sft_scale is None else sft_scale.numel()))
     kind = ('conv3x3_s2' if stride == 2 else ('conv_up2x' if upsample else ('conv3x3_wino' if pw.wino else 'conv3x3'))) \
         if pw.taps == 9 else 'gemm1x1'
+    if pw.bf16:
+        kind += ('', '_bf16', '_f16', '_f16x2')[int(pw.bf16)]
     PROFILE.append((kind, flops, nbytes, e0, e1, (B, H, W, cin, pw.cout)))
     return out
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 8
+#define CF_ABI_VERSION 9
 
 typedef void* cf_stream_t; /* hipStream_t */
 
@@ -75,6 +75,12 @@ enum cf_operand {
   CF_OPERAND_F16 = 2,   /* v_mfma_f32_32x32x16_f16; weight from cf_pack_conv_weight[_up2x]_f16.  The operand format of the
                            reference's half-precision Real-ESRGAN (inference_codeformer.py:23-27,44); same speed as bf16
                            with 3 more mantissa bits (conv inputs here are O(1): no range problem) */
+  CF_OPERAND_F16X2 = 3, /* fp32-grade accuracy on the f16 MFMA pipe: every fp32 operand is split x = hi + lo into two IEEE halves
+                           (22 significant bits) and a product is hi*hi + hi*lo + lo*hi -- three v_mfma_f32_32x32x16_f16 with fp32
+                           accumulation (cf_split.hip).  Weight from cf_pack_conv_weight_f16x2, acc_scale = 1 / its scale.  3x3
+                           stride-1 NHWC convolutions (plain or `upsample`), channels % 32 == 0, cout % 64 == 0, 16x16-tile sizes;
+                           prologues as the fp32 kernels, epilogues none / residual / SFT, statistics supported.  The host uses it
+                           for the generator / CFT convolutions (never encoder or Transformer: code indices stay exact) */
 };
 
 /* Border handling of the 3x3 gather (general instantiations; CodeFormer itself only uses zero padding) */
@@ -134,6 +140,8 @@ typedef struct cf_conv_desc {
                              tensors, zero padding, hout % 8 == 0, wout % 16 == 0, cout_pad % 64 == 0; prologues as the direct
                              kernel, epilogues none / residual / SFT, statistics supported.  Measured against fp64 its error
                              is below the direct kernel's, so the host uses it for every eligible 3x3 stride-1 convolution */
+  float acc_scale;        /* CF_OPERAND_F16X2 only: the accumulator is multiplied by this before the bias is added -- the exact
+                             inverse of the power-of-two scale given to cf_pack_conv_weight_f16x2 (> 0) */
 } cf_conv_desc;
 
 int cf_conv2d(const cf_conv_desc* d, cf_stream_t stream);
@@ -163,6 +171,12 @@ int cf_pack_conv_weight_f16(const float* w, int cout, int cin, int taps, int cou
                             cf_stream_t stream);
 int cf_pack_conv_weight_up2x_f16(const float* w, int cout, int cin, int cout_pad, int cin_pad, void* packed,
                                  cf_stream_t stream);
+/* Split-half weights for CF_OPERAND_F16X2: [slab][cin_pad/32][cout_pad][hi 32 | lo 32] IEEE halves (4 bytes per weight, slab = 9
+ * taps or, with up2x != 0, the 16 folded class x tap slabs of cf_pack_conv_weight_up2x).  Each (folded) fp32 weight is multiplied
+ * by `scale` -- a power of two, exact; choose it so that max|w*scale| lies in [2^14, 2^15) -- then hi = half(w'), lo = half(w' - hi)
+ * (round-to-nearest-even).  cin_pad % 32 == 0, cout_pad % 64 == 0; cf_conv_desc.acc_scale must be 1 / scale. */
+int cf_pack_conv_weight_f16x2(const float* w, int cout, int cin, int up2x, int cout_pad, int cin_pad, float scale, void* packed,
+                              cf_stream_t stream);
 
 /* ---- GroupNorm statistics (vqgan_arch.py:14-15: 32 groups, eps 1e-6, biased variance) --------
  * Partials are fp64 (sum, sumsq) tables [batch][groups][parts][2] over an NHWC tensor with c channels whose (fine)

@@ -33,7 +33,7 @@ def test_header_symbols_are_exported(native):
 
 
 def test_version_and_error_string(native):
-    assert native.cf_version() == lib.ABI_VERSION == 8
+    assert native.cf_version() == lib.ABI_VERSION == 9
     assert isinstance(lib.last_error(), str)
 
 
@@ -64,6 +64,13 @@ def test_argument_errors_are_reported_without_a_gpu(native):
     assert native.cf_attention(1, 512, 1, 512, 1, 512, 1, 512, 1, 8, 64, 128, 1.0, None) == -1
     assert '256 keys' in lib.last_error()
     assert native.cf_packed_weight_elems(64, 9, 128) == 9 * 64 * 128
+    # split-half operands (CF_OPERAND_F16X2): shape rules and the pack-time scale are checked before any launch
+    d = lib.ConvDesc(in0=1, weight=1, out=1, taps=9, stride=1, batch=1, hin=16, win=16, hout=16, wout=16, c0=48, cout=64,
+                     cout_pad=64, bf16_mfma=3, acc_scale=1.0)
+    assert native.cf_conv2d(ctypes.byref(d), None) == -1 and 'multiples of 32' in lib.last_error()
+    d.c0, d.acc_scale = 64, 0.0
+    assert native.cf_conv2d(ctypes.byref(d), None) == -1 and 'acc_scale' in lib.last_error()
+    assert native.cf_pack_conv_weight_f16x2(1, 64, 64, 0, 64, 64, 3.0, 1, None) == -1 and 'power of two' in lib.last_error()
 
 
 def test_missing_library_is_a_loud_error(monkeypatch, tmp_path):

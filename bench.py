@@ -3,19 +3,25 @@
     python bench.py --gpus N --steps K --warmup W          (N=1: plain python; N>1: launched by torchrun, one rank per GPU)
 
 A "step" is one CodeFormer.forward(x, w=0.5, adain=True) over one batch of 16 synthetic faces per GPU (config 2 of
-BASELINE.json: fp32, seeded rand(16,3,512,512)*2-1, seed-0 random-init weights unless weights/CodeFormer/codeformer.pth
-exists) followed, for N>1, by the single gather of the restored faces to rank 0 (left in flight while the next step computes;
-all K gathers are joined inside the timed region).  Inputs are resident in HBM before the
-timed region; host PNG decode/encode is outside the path and outside the timed region.  Weak scaling: 16 faces per GPU.
+BASELINE.json: seeded rand(16,3,512,512)*2-1, seed-0 random-init weights unless weights/CodeFormer/codeformer.pth exists)
+followed, for N>1, by the single gather of the restored faces to rank 0 (left in flight while the next step computes; all K
+gathers are joined inside the timed region).  Inputs are resident in HBM before the timed region; host PNG decode/encode is
+outside the path and outside the timed region.  Weak scaling: 16 faces per GPU.
+
+Precision (--precision, default f16x2): every tensor is fp32 and the encoder / Transformer / code argmax run on exact fp32 MFMA in
+every mode.  'f16x2' evaluates the generator + fusion 3x3 convolutions with split operands -- each fp32 operand as hi + lo IEEE
+halves (22 significant bits), three f16 MFMAs per product, fp32 accumulation (cf_split.hip): against the reference its pixels are
+as close as the exact-fp32 path's (5.7e-5 vs 5.6e-5 on real crops, tolerance 1e-3; indices identical).  'fp32' is the exact path
+(Winograd F(2x2,3x3) on fp32 MFMA); at N=1 the default run times it too and reports it under `exact_fp32`, together with the
+largest pixel difference between the two modes on the bench batch.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline:     dominant kernel = the 3x3 stride-1 convolution (95 % of the FLOPs, compute-bound in fp32: AI ~ 233 FLOP/B vs
-                ridge ~ 20), evaluated as Winograd F(2x2,3x3) on fp32 MFMA (winograd_kernel; the direct implicit GEMM keeps the
-                shapes Winograd does not cover and is reported under roofline.direct_kernel).  achieved = algorithmic FLOPs of
-                those launches of one forward (2*B*Ho*Wo*Cout*Cin*9 each) / their summed durations, measured live with events
-                on the launch stream; `executed` = the 4/9 of them the MFMA pipe really performs; peak = 157.3 TFLOP/s (fp32
-                MFMA, MI355X_MICROARCH.md).
-  cpu_baseline: the CPU oracle (oracle/codeformer_oracle.py, torch CPU fp32, all host threads) timed on a bounded sample
+  roofline:     the kernel with the largest summed duration of a step, timed live per launch with events on the launch stream:
+                achieved = MFMA FLOPs it EXECUTES / duration, against the dense peak of the MFMA type it issues (f16: 2500
+                TFLOP/s, fp32: 157.3, MI355X_MICROARCH.md); effective_tflops = the convolution's algorithmic FLOPs
+                (2*taps*Cin*Cout per output pixel) / duration; `other_kernels` holds the same record for every other kernel class;
+                `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_bench.json).
+  cpu_baseline: the CPU oracle (oracle/codeformer_oracle.py, torch CPU fp32, up to 64 host threads) timed on a bounded sample
                 (batch-1 forwards for ~10-30 s) on rank 0 at N=1.
 """
 import argparse
@@ -30,11 +36,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+F16_MFMA_PEAK_TFLOPS = 2500.0     # same guide: dense f16 / bf16 MFMA (v_mfma_f32_32x32x16_f16); the sparse 5 PF figure is not used
 HBM_PEAK_GBS = 8000.0
 GFLOP_PER_FACE = 809.77            # BASELINE.md section 3 (restoration, w>0, 4 fuse levels): the REFERENCE algorithm's FLOPs
 # The five Upsample blocks (nearest x2 + 3x3, 125.6 GFLOP/face in the reference's formulation) run as four 2x2 sub-pixel
 # convolutions with folded taps: 4/9 of those MACs.  Hardware-utilisation figures use the EXECUTED count.
-GFLOP_PER_FACE_EXECUTED = 809.77 - 125.6 * (5.0 / 9.0)
 FUSED_MIN_GB_PER_FACE = 4.155
 
 
@@ -53,7 +59,7 @@ def build_net(device):
     return net.to(device), sd_cpu, weights
 
 
-def recorded_traffic(prefix='igemm_kernel<9, 1'):
+def recorded_traffic(prefix='split_conv_kernel'):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_bench.json,
     produced by tools/pmc_bench.sh on this same bench step; bench.py cannot profile itself).  Per the MI355X guide:
     FETCH_SIZE / WRITE_SIZE are in KiB, and on gfx950 FETCH_SIZE reports half of the bytes of wide (16 B/lane) reads, so
@@ -102,30 +108,36 @@ def roofline_leg(net, x, w):
     table['by_shape (kind,B,H,W,Cin,Cout): launches, ms_total, TFLOP/s'] = {
         str(k): [v[2] // reps, round(v[1] / reps * 1e3, 3), round(v[0] / v[1] / 1e12, 1)]
         for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1])}
-    def entry(kind, name, executed_ratio, peak=FP32_MFMA_PEAK_TFLOPS):
+    # kind -> (kernel, MFMA FLOPs executed per algorithmic FLOP booked by ops.conv2d, dense MFMA peak of the type it issues)
+    KINDS = {
+        'conv3x3_f16x2': ('split_conv_kernel<9,...> (3x3 s1, fp32 operands as hi+lo halves: 3 f16 MFMAs per product, fp32 accumulate)', 3.0, F16_MFMA_PEAK_TFLOPS, 'split_conv_kernel<9'),
+        'conv_up2x_f16x2': ('split_conv_kernel<4,...> (nearest-x2 + 3x3 folded to 2x2 sub-pixel taps, split halves)', 3.0, F16_MFMA_PEAK_TFLOPS, 'split_conv_kernel<4'),
+        'conv3x3_wino': ('winograd_kernel (3x3 s1 as Winograd F(2x2,3x3), fp32 MFMA)', 4.0 / 9.0, FP32_MFMA_PEAK_TFLOPS, 'winograd_kernel'),
+        'conv3x3': ('igemm_kernel<9,1,...> (direct 3x3 s1 implicit GEMM, fp32 MFMA)', 1.0, FP32_MFMA_PEAK_TFLOPS, 'igemm_kernel<9, 1'),
+        'conv_up2x': ('igemm_kernel<4,1,...> (folded nearest-x2 + 3x3, fp32 MFMA)', 1.0, FP32_MFMA_PEAK_TFLOPS, 'igemm_kernel<4, 1'),
+        'conv3x3_s2': ('igemm_kernel<9,2,...> (3x3 stride 2, fp32 MFMA)', 1.0, FP32_MFMA_PEAK_TFLOPS, 'igemm_kernel<9, 2'),
+        'gemm1x1': ('igemm_kernel<1,1,...> (1x1 conv / Linear, fp32 MFMA)', 1.0, FP32_MFMA_PEAK_TFLOPS, 'igemm_kernel<1, 1'),
+    }
+
+    def entry(kind):
         """`achieved` / `frac` = the FLOPs the MFMA pipe really EXECUTES for these launches over their summed durations, against
-        the dense peak of the MFMA type used; the convolution's algorithmic rate (2*9*Cin*Cout per output pixel)
+        the dense peak of the MFMA type used; the convolution's algorithmic rate (2*taps*Cin*Cout per output pixel)
         is reported separately as `effective_tflops` (it exceeds `achieved` for Winograd, which executes 4/9 of those
-        multiplies, and is a third of it for the split-f16 kernel, which issues 3 MFMAs per product)."""
+        multiplies, and is a third of it for the split-half kernel, which issues 3 MFMAs per product)."""
+        name, ratio, peak, pmc = KINDS.get(kind, (kind, 1.0, F16_MFMA_PEAK_TFLOPS if kind.endswith(('_f16', '_bf16')) else FP32_MFMA_PEAK_TFLOPS, 'igemm_kernel<9, 1'))
         c = agg[kind]
         alg = c[0] / c[2] / 1e12
-        ach = alg * executed_ratio
+        ach = alg * ratio
         return {'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                'frac': round(ach / peak, 4), 'effective_tflops': round(alg, 2), 'executed_per_algorithmic_flop': round(executed_ratio, 4),
+                'frac': round(ach / peak, 4), 'effective_tflops': round(alg, 2), 'executed_per_algorithmic_flop': round(ratio, 4),
                 'avg_launch_ms': round(c[2] / c[3] * 1e3, 4), 'launches_per_step': c[3] // reps,
                 'algorithmic_gflop_per_step': round(c[0] / reps / 1e9, 1), 'ms_per_step': round(c[2] / reps * 1e3, 2),
-                'alg_bytes_per_launch': round(c[1] / c[3])}
-    direct = entry('conv3x3', 'igemm_kernel<9,1,...> (direct 3x3 s1 implicit GEMM, fp32 MFMA)', 1.0)
-    direct['traffic'] = recorded_traffic()
-    if 'conv3x3_wino' in agg and agg['conv3x3_wino'][2] > agg['conv3x3'][2]:
-        # Dominant kernel = the Winograd F(2x2,3x3) evaluation of the 3x3 stride-1 convolutions: 16 multiplies per 2x2 outputs =
-        # 4/9 of the direct convolution's, all of them on the fp32 MFMA pipe.
-        roof = entry('conv3x3_wino', 'winograd_kernel (3x3 s1 as Winograd F(2x2,3x3), fp32 MFMA)', 4.0 / 9.0)
-        roof['traffic'] = recorded_traffic('winograd_kernel')   # null until a PMC pass of this kernel is committed
-        roof['direct_kernel'] = direct
-    else:
-        roof = direct
-    # executed (MFMA-issued) FLOPs of one step over every dense contraction + the attention matmuls (2.01 GF / face)
+                'alg_bytes_per_launch': round(c[1] / c[3]), 'traffic': recorded_traffic(pmc)}
+
+    order = sorted(agg, key=lambda k: -agg[k][2])
+    roof = entry(order[0])                                   # the dominant kernel = the kind with the largest summed duration
+    roof['other_kernels'] = {k: entry(k) for k in order[1:]}
+    # executed fp32-MFMA-equivalent work of one step (Winograd at its 4/9; a split-half product counted once) + attention (2.01 GF / face)
     exec_flops = sum(v[0] * (4.0 / 9.0 if k == 'conv3x3_wino' else 1.0) for k, v in agg.items()) / reps + 2.01e9 * x.shape[0]
     roof['executed_gflop_per_face_whole_path'] = round(exec_flops / x.shape[0] / 1e9, 2)
     return roof, table
@@ -164,9 +176,11 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch-per-gpu', type=int, default=16)
     ap.add_argument('--w', type=float, default=0.5)
-    ap.add_argument('--precision', choices=['fp32', 'f16x2', 'bf16', 'fp16'], default='fp32',
-                    help="fp32 = BASELINE config 2 (the headline); bf16 = generator + CFT on bf16 MFMA operands (configs 3/5), "
-                         "encoder / Transformer / argmax stay fp32")
+    ap.add_argument('--precision', choices=['fp32', 'f16x2', 'bf16', 'fp16'], default='f16x2',
+                    help="operand format of the generator + CFT 3x3 convolutions (encoder / Transformer / argmax are exact fp32 in every "
+                         "mode): f16x2 = fp32 operands split into hi+lo halves, fp32-grade accuracy (default); fp32 = exact fp32 MFMA; "
+                         "bf16 / fp16 = 16-bit operands (BASELINE configs 3/5)")
+    ap.add_argument('--no-exact-leg', action='store_true', help='skip the extra exact-fp32 timing of the default run')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--details', action='store_true', help='print the per-kernel-class table to stderr')
@@ -227,26 +241,45 @@ def main():
             'metric': 'aligned 512x512 faces/sec (whole node) at w=0.5', 'value': round(faces_per_s, 2), 'unit': 'faces/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if args.precision == 'fp32' else f'{args.precision} operands / f32 accumulate (generator+CFT); f32 (encoder, Transformer)',
+            'dtype': {'fp32': 'f32', 'f16x2': 'f32 (tensors, accumulation, encoder / Transformer / argmax exact fp32 MFMA; generator + CFT 3x3 '
+                                                  'products on split operands: fp32 = hi + lo IEEE halves, 3 f16 MFMAs per product)'}.get(
+                args.precision, f'{args.precision} operands / f32 accumulate (generator+CFT); f32 (encoder, Transformer)'),
             'data': 'synthetic',
             'config': {'workload': (('BASELINE config 2' if (args.precision in ('fp32', 'f16x2') and args.w == 0.5 and B == 16) else 'custom')
                                     + f': batch={B} aligned 512x512 faces per GPU, w={args.w}, adain=True, precision={args.precision}, '
                                       f'CodeFormer(codebook 1024, 4 fuse levels), {weights} weights'), 'global_batch': total,
                        'parallelism': f'faces sharded x{world}, one gather to rank 0' if world > 1 else 'single GPU'},
             'whole_path': {'effective_tflops_reference_flop_count': round(faces_per_s * GFLOP_PER_FACE / 1e3, 2),
-                           'executed_tflops_fp32': round(faces_per_s * GFLOP_PER_FACE_EXECUTED / 1e3, 2),
-                           'frac_fp32_mfma_peak': round(faces_per_s * GFLOP_PER_FACE_EXECUTED / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world), 4),
                            'frac_hbm_peak_fused_min_bytes': round(faces_per_s * FUSED_MIN_GB_PER_FACE / (HBM_PEAK_GBS * world), 4)},
         }
-        if not args.no_roofline and args.precision == 'fp32':
+        if not args.no_roofline:
             roof, table = roofline_leg(net, x, args.w)
             line['roofline'] = roof
-            ex = roof.pop('executed_gflop_per_face_whole_path')      # measured: overrides the static direct-kernel estimate
-            line['whole_path']['executed_gflop_per_face'] = ex
-            line['whole_path']['executed_tflops_fp32'] = round(faces_per_s * ex / 1e3, 2)
-            line['whole_path']['frac_fp32_mfma_peak'] = round(faces_per_s * ex / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world), 4)
+            ex = roof.pop('executed_gflop_per_face_whole_path')      # products really evaluated (folded upsample taps, Winograd 4/9)
+            line['whole_path']['evaluated_gflop_per_face'] = ex
+            if args.precision == 'fp32':                             # every product on the fp32 pipe: a whole-path fraction makes sense
+                line['whole_path']['executed_tflops_fp32'] = round(faces_per_s * ex / 1e3, 2)
+                line['whole_path']['frac_fp32_mfma_peak'] = round(faces_per_s * ex / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world), 4)
             if args.details:
                 print(json.dumps(table, indent=1), file=sys.stderr)
+        if world == 1 and args.precision == 'f16x2' and not args.no_exact_leg:
+            y_split = net(x, w=args.w, adain=True)
+            net.precision = 'fp32'
+            y_exact = net(x, w=args.w, adain=True)
+            for _ in range(args.warmup):
+                net(x, w=args.w, adain=True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                net(x, w=args.w, adain=True)
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t1
+            net.precision = args.precision
+            line['exact_fp32'] = {'value': round(args.steps * total / dt1, 2), 'unit': 'faces/s', 'ms_per_step': round(dt1 / args.steps * 1e3, 3),
+                                  'what': 'the same step with precision=fp32: every convolution on exact fp32 MFMA (Winograd F(2x2,3x3) '
+                                          'where eligible)',
+                                  'max_abs_pixel_diff_vs_default': float((y_split[0] - y_exact[0]).abs().max()),
+                                  'logits_bitwise_equal': bool(torch.equal(y_split[1], y_exact[1]))}
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline_leg(sd_cpu, args.w)
         print(json.dumps(line), flush=True)

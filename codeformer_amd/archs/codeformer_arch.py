@@ -159,14 +159,17 @@ class CodeFormer(VQAutoEncoder):
                 for p in getattr(self, name).parameters():
                     p.requires_grad = False
 
-        # 'fp32': everything on exact fp32 MFMA.  'bf16' (BASELINE configs 3/5): generator + CFT 3x3 convs on bf16 MFMA
-        # operands with fp32 accumulate; encoder, Transformer and the code argmax stay fp32 so the indices stay exact.
-        # 'fp16': the same split with IEEE-half operands (same speed, 3 more mantissa bits: ~8x smaller pixel error).
-        self.precision = os.environ.get('CODEFORMER_HIP_PRECISION', 'fp32')
-        # fp32 mode: evaluate the generator + CFT 3x3 stride-1 convolutions with Winograd F(2x2,3x3) -- the same function in fp32
-        # with 2.25x fewer multiplies (cf_winograd.hip).  Encoder / Transformer / argmax stay on the direct kernel, so logits and
-        # code indices are bitwise those of the direct mode; pixels move by ~1e-5 (tolerance 1e-3).  Set False (or
-        # CODEFORMER_HIP_WINOGRAD=0) for the direct evaluation everywhere.
+        # Operand format of the generator + CFT 3x3 convolutions.  Encoder, Transformer and the code argmax are exact fp32 in EVERY mode,
+        # so logits and code indices do not depend on it.
+        #   'f16x2' (default): fp32 operands split into hi + lo IEEE halves (22 significant bits), three f16 MFMAs per product, fp32
+        #            accumulation (cf_split.hip).  Per layer 1-2x the fp64-error of the exact kernels; whole network vs the reference
+        #            5.7e-5 on real crops (exact path: 5.6e-5; tolerance 1e-3).  1.27x the exact path's faces/s.
+        #   'fp32':  everything on exact fp32 MFMA (Winograd F(2x2,3x3) where eligible, see below).
+        #   'bf16' (BASELINE configs 3/5) / 'fp16': single 16-bit operands with fp32 accumulate (pixel gates in tests/test_gpu_real_images.py).
+        self.precision = os.environ.get('CODEFORMER_HIP_PRECISION', 'f16x2')
+        # Exact-fp32 convolutions (precision='fp32', and in every mode the layers the split kernel does not take): evaluate 3x3
+        # stride-1 convolutions with Winograd F(2x2,3x3) -- the same function in fp32 with 2.25x fewer multiplies (cf_winograd.hip).
+        # Set False (or CODEFORMER_HIP_WINOGRAD=0) for the direct evaluation everywhere.
         self.winograd = os.environ.get('CODEFORMER_HIP_WINOGRAD', '1') != '0'
         # Also evaluate the ENCODER's 3x3 stride-1 convolutions with Winograd, in every precision mode (the encoder is always
         # fp32, so logits / indices stay bitwise identical across 'fp32' / 'bf16' / 'fp16').  Measured against the reference:
@@ -235,6 +238,8 @@ class CodeFormer(VQAutoEncoder):
         bf16 = {'fp32': 0, 'f16x2': ops.SPLIT, 'bf16': 1, 'fp16': 2}[self.precision]   # operand code of the generator + CFT 3x3 convs
         if bf16 == 0 and self.winograd:
             bf16 = ops.WINOGRAD
+        if bf16 == ops.SPLIT and not self.winograd:
+            bf16 = ops.SPLIT_DIRECT
         gen_taps = None
         if w > 0:
             def fuse(t):

@@ -35,9 +35,21 @@
 
 #include "cf_common.h"
 
-// SP_ABLATE: timing-only ablation builds (tools/split_ab.sh); 0 / undefined in every product build.
+// SP_ABLATE: timing-only ablation builds (tools/split_ab.sh), a bit mask: 1 no epilogue, 2 no weight fetch, 4 no weight LDS write,
+// 8 no fragment reads, 16 no per-step barrier, 32 no MFMA, 64 no activation gather, 128 no prologue/split; 0 in every product build.
 #ifndef SP_ABLATE
 #define SP_ABLATE 0
+#endif
+// SP_DESYNC: start skew of the first generation of workgroups, in sixteenths of (SP_DESYNC x main-loop steps x ~210 cycles); 0 = none
+#ifndef SP_DESYNC
+#define SP_DESYNC 0
+#endif
+#ifndef SP_FAST_RCP
+#define SP_FAST_RCP 1   // 1: swish reciprocal on the raw v_rcp_f32 (1 ulp) instead of the IEEE-rounded division sequence: +4..8 %
+#endif
+// SP_WEAVE: 1 = fragment reads / weight fetches / weight LDS writes are woven one-by-one into the MFMA stream (sched_group_barrier)
+#ifndef SP_WEAVE
+#define SP_WEAVE 1
 #endif
 
 namespace {
@@ -209,7 +221,7 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void split_conv_kernel(c
           if (PRO == CF_PRO_AFFINE) v = v * rsc[u][e] + rsh[u][e];
           if (PRO == CF_PRO_AFFINE_SWISH) {
             v = v * rsc[u][e] + rsh[u][e];
-            v = v * __frcp_rn(1.0f + __expf(-v));  // hardware exp / rcp swish, as the fp32 kernels (~3 ulp of x*sigmoid(x))
+            v = SP_FAST_RCP ? v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)) : v * __frcp_rn(1.0f + __expf(-v));  // hardware exp / rcp swish
           }
           if (PRO == CF_PRO_LEAKY) v = v > 0.f ? v : 0.2f * v;
           y[u * 4 + e] = valid ? v : 0.f;
@@ -337,6 +349,16 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void split_conv_kernel(c
   // barrier, patch write, barrier -- but the next slab's activations were fetched at tap 0 and converted (prologue + split) in
   // the shadow of the MFMAs of a middle tap, so only the LDS stores sit between the two barriers.
   const int nsteps = a.nchunks * TAPS;
+#if SP_DESYNC
+  // Workgroups of one launch all take the same time, so the two co-resident on a CU -- and all 512 on the chip -- would run in
+  // lock-step: everybody in the MFMA loop (HBM idle), then everybody in the store phase (HBM-bound, matrix pipe idle).  A start
+  // skew of the FIRST generation (dispatch ids < 2 x 256 CUs; later ones inherit the phase of the slot they take over) spreads
+  // the phases over the tile time.
+  if (blockIdx.x < 512 && gridDim.x >= 1024) {
+    const int units = (blockIdx.x >> 3) & 15;
+    for (int i = 0; i < units * nsteps * SP_DESYNC / 64; ++i) __builtin_amdgcn_s_sleep(13);  // 13 x 64 cycles per iteration
+  }
+#endif
   load_A(0);
   load_B(0);
   {
@@ -361,42 +383,75 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void split_conv_kernel(c
     for (int tap = 0; tap < TAPS; ++tap, ++step) {
       const int slot1 = slot == 2 ? 0 : slot + 1;
       const int slot2 = slot1 == 2 ? 0 : slot1 + 1;
-#if SP_ABLATE != 2
+#if !(SP_ABLATE & 2)
       load_B(step + 2 < nsteps ? step + 2 : nsteps - 1);  // clamped: the tail prefetches are harmless re-reads
 #endif
-#if SP_ABLATE != 7
+#if !(SP_ABLATE & 64)
       if (tap == 0) load_A(chunk + 1 < a.nchunks ? chunk + 1 : chunk);
 #endif
-#if SP_ABLATE != 4
+#if !(SP_ABLATE & 8)
       read_frags(fy, tap, slot, 1);
 #endif
-      __builtin_amdgcn_sched_barrier(0);  // pin the fetches above the MFMA block (hipcc would sink them next to their use)
-#if SP_ABLATE != 6
+      constexpr int NMF = MI * NI * 3;  // MFMAs per half step
+      const bool weave = SP_WEAVE && NMF >= 2 * (MI + NI) + C::BPT && tap != CONV_TAP && tap != 0;
+      if (!weave) __builtin_amdgcn_sched_barrier(0);  // pin the fetches above the MFMA block (hipcc would sink them next to their use)
+#if !(SP_ABLATE & 32)
       mma(fx);
 #endif
-#if SP_ABLATE != 7 && SP_ABLATE != 8
+#if !(SP_ABLATE & (64 | 128))
       if (tap == CONV_TAP) convert();
 #endif
+      if (weave) {
+        // MFMA-first: frags(s, k 0..15) are in registers, so the half step opens with an MFMA and every LDS read / fetch issues in
+        // the shadow of one
+#pragma unroll
+        for (int i = 0; i < C::BPT; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * (MI + NI); ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+        }
+#pragma unroll
+        for (int i = 0; i < NMF - 2 * (MI + NI) - C::BPT; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
-#if SP_ABLATE != 4
+#if !(SP_ABLATE & 8)
       if (tap != TAPS - 1) read_frags(fx, tap + 1, slot1, 0);
 #endif
-#if SP_ABLATE != 6
+#if !(SP_ABLATE & 32)
       mma(fy);
 #endif
-      __builtin_amdgcn_sched_barrier(0);
-#if SP_ABLATE != 3
+      if (!weave) __builtin_amdgcn_sched_barrier(0);
+#if !(SP_ABLATE & 4)
       store_B(slot2);
 #endif
-#if SP_ABLATE != 5
+      if (weave) {
+#pragma unroll
+        for (int i = 0; i < (tap != TAPS - 1 ? 2 * (MI + NI) : 0); ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NMF - (tap != TAPS - 1 ? 2 * (MI + NI) : 0) - C::BPT; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+        for (int i = 0; i < C::BPT; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write (waits for the slab fetched in the first half)
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#if !(SP_ABLATE & 16)
       __syncthreads();
 #endif
       if (tap == TAPS - 1 && chunk + 1 < a.nchunks) {
-#if SP_ABLATE != 7
+#if !(SP_ABLATE & 64)
         store_A();
         __syncthreads();
 #endif
-#if SP_ABLATE != 4
+#if !(SP_ABLATE & 8)
         read_frags(fx, 0, slot1, 0);
 #endif
       }
@@ -509,7 +564,7 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void split_conv_kernel(c
       }
     }
   };
-#if SP_ABLATE == 1
+#if SP_ABLATE & 1
   {  // no epilogue: keep the accumulators live, write one value
     float t = 0.f;
 #pragma unroll

@@ -59,6 +59,7 @@ def _cout_pad(cout):
 
 WINOGRAD = 3   # value of the operand-code argument that selects the Winograd F(2x2,3x3) fp32 evaluation
 SPLIT = 4      # ... the split-half evaluation: fp32 operands as hi + lo IEEE halves, 3 f16 MFMAs per product (cf_split.hip)
+SPLIT_DIRECT = 5   # ... the same, but layers the split kernel does not take run on the direct fp32 kernel instead of Winograd
 OPERAND_F16X2 = 3   # enum cf_operand value behind SPLIT
 
 
@@ -73,7 +74,7 @@ def winograd_ok(cin, cout, hout, wout):
     return cin % 16 == 0 and cout % 64 == 0 and hout % 8 == 0 and wout % 16 == 0
 
 
-SPLIT_MIN_PIXELS = 64 * 64   # below this input size a layer has too few 16x16 tiles to fill 256 CUs: it stays on fp32 Winograd
+SPLIT_MIN_PIXELS = 32 * 32   # below this input size (the 16x16 latents) the layer stays on fp32 Winograd: too few 8x16 tiles per image
 
 
 def conv_code(code, cin, cout, h, w, up2x=False, c_split=None, plain=True):
@@ -81,10 +82,10 @@ def conv_code(code, cin, cout, h, w, up2x=False, c_split=None, plain=True):
     SPLIT falls back to WINOGRAD and WINOGRAD to the direct fp32 kernel where their kernels do not apply; the decision depends
     on the per-image shape only (never on the batch), so results stay batch-invariant."""
     code = int(code)
-    if code == SPLIT:
+    if code in (SPLIT, SPLIT_DIRECT):
         if plain and split_ok(cin, cout, h, w, c_split) and h * w >= SPLIT_MIN_PIXELS:
             return SPLIT
-        code = WINOGRAD
+        code = WINOGRAD if code == SPLIT else 0
     if code == WINOGRAD:
         return WINOGRAD if (plain and not up2x and winograd_ok(cin, cout, h, w)) else 0
     if code and not (plain and cin % 32 == 0 and cout % 4 == 0):

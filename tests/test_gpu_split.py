@@ -1,0 +1,75 @@
+"""-m gpu: the split-half convolution kernel (cf_split.hip, CF_OPERAND_F16X2: fp32 operands as hi + lo IEEE halves, three f16
+MFMAs per product) through the C ABI against fp64 references -- every prologue / epilogue / concat / upsample combination the
+generator and the fusion blocks use, extreme weight / activation magnitudes, the epilogue's GroupNorm partials, bitwise
+repeatability and batch invariance, and the refusals of the C ABI for shapes the kernel does not cover.
+
+Tolerance: 2e-5 + 1e-5*|ref| (the bound of the exact-fp32 kernels' tests); additionally the split kernel's max error must stay
+within 4x of the exact-fp32 kernel's on the same case (measured: 1-2.3x max, equal mean).
+"""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def sc():
+    import torch
+    assert torch.cuda.is_available(), 'gpu tests need an MI355X'
+    from codeformer_amd import lib
+    lib.load()
+    spec = importlib.util.spec_from_file_location('split_check', os.path.join(ROOT, 'tools', 'split_check.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_split_conv_against_fp64(sc):
+    for c in sc.CASES:
+        es, ef, est, rmax, ems = sc.case(timing=False, **c)
+        assert es <= 2e-5 + 1e-5 * rmax, (c, es)
+        assert es <= 4.0 * ef + 1e-7 * rmax, (c, es, ef)
+        assert est <= 1e-4, (c, est)
+
+
+def test_split_conv_is_bitwise_repeatable_and_batch_invariant(sc):
+    import torch
+    from codeformer_amd import ops
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(3, 32, 48, 128, generator=g).cuda()
+    w = (torch.randn(128, 128, 3, 3, generator=g) * 0.03).cuda()
+    b = torch.randn(128, generator=g).cuda()
+    for up in (False, True):
+        pw = ops.pack_weight(w, b, bf16=ops.SPLIT, up2x=up)
+        y = ops.conv2d(x, pw, upsample=up, emit_stats=True)
+        y2 = ops.conv2d(x, pw, upsample=up, emit_stats=True)
+        assert torch.equal(y, y2) and torch.equal(y._cf_stats.part, y2._cf_stats.part)
+        assert torch.equal(y[1:2], ops.conv2d(x[1:2].contiguous(), pw, upsample=up))
+
+
+def test_split_conv_refusals_and_overflow_is_loud(sc):
+    import torch
+    from codeformer_amd import ops
+    w = torch.zeros(64, 64, 3, 3, device='cuda')
+    w[:, :, 1, 1] = torch.eye(64, device='cuda')
+    pw = ops.pack_weight(w, None, bf16=ops.SPLIT)
+    x = torch.randn(1, 16, 16, 64, device='cuda')
+    y = ops.conv2d(x, pw)
+    assert float((y - x).abs().max()) <= 2e-7 * float(x.abs().max())      # identity kernel: only the 22-bit operand split is visible
+    with pytest.raises(RuntimeError, match='f16x2'):
+        ops.conv2d(torch.zeros(1, 20, 16, 64, device='cuda'), pw)            # 20 rows: not a whole number of 8x16 tiles
+    with pytest.raises(RuntimeError, match='f16x2'):
+        ops.conv2d(x, pw, stride=2)
+    with pytest.raises(ValueError):
+        ops.pack_weight(torch.zeros(64, 48, 3, 3, device='cuda'), None, bf16=ops.SPLIT)   # cin % 32
+    # activations beyond the IEEE-half range (|x| > 65504) do not produce a silently wrong finite value
+    x2 = x.clone()
+    x2[0, 3, 3, 5] = 1e6
+    assert not torch.isfinite(ops.conv2d(x2, pw)).all()
+    # host policy: which layers take the split kernel
+    assert ops.conv_code(ops.SPLIT, 128, 128, 256, 256) == ops.SPLIT and ops.conv_code(ops.SPLIT, 512, 512, 16, 16) == ops.WINOGRAD
+    assert ops.conv_code(ops.SPLIT_DIRECT, 512, 512, 16, 16) == 0 and ops.conv_code(ops.SPLIT, 48, 64, 64, 64) == ops.WINOGRAD
+    assert ops.conv_code(ops.SPLIT, 512, 512, 16, 16, up2x=True) == 0 and ops.conv_code(ops.SPLIT, 128, 128, 256, 256, up2x=True) == ops.SPLIT

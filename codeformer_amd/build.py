@@ -22,18 +22,42 @@ def _hipcc():
     raise RuntimeError('hipcc not found (set HIPCC)')
 
 
-def needs_build():
+def source_hash():
+    """sha256 (16 hex digits) over every file the library is compiled from, in a fixed order."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h'))) + \
+        [os.path.join(ROOT, 'include', 'codeformer_hip.h')]
+    for f in files:
+        h.update(os.path.basename(f).encode() + b'\0')
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def built_id():
+    """Build id of the shared object on disk (what its cf_build_id() returns), read from the file itself -- loading it here
+    would pin the old image in this process across a rebuild.  None when the file is absent or predates the marker."""
     if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, 'include', 'codeformer_hip.h')]
-    return any(os.path.getmtime(d) > t for d in deps)
+        return None
+    with open(LIB, 'rb') as fh:
+        blob = fh.read()
+    i = blob.find(b'CF_BUILD_ID=')
+    if i < 0:
+        return None
+    return blob[i + 12:blob.index(b'\0', i)].decode('ascii', 'replace')
+
+
+def needs_build():
+    """True when the .so is missing or was compiled from other sources than the tree holds (content hash, not mtime: a shipped
+    .so that is older or newer than an edited source is rebuilt either way)."""
+    return built_id() != source_hash()
 
 
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
+    cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', f'-DCF_BUILD_ID="{source_hash()}"',
            '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC, '-o', LIB + '.tmp'] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(' '.join(cmd), flush=True)

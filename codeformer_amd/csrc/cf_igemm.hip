@@ -961,15 +961,17 @@ int launch(const ConvArgsExt& a, hipStream_t stream, int* parts_query) {
   k.ntn = a.cout_pad / C::BN;
   auto kern = igemm_kernel<TAPS, STRIDE, WM, WN, MI, NI, IN_NCHW, BF16, EXT, F16>;
   constexpr size_t lds = C::LDS_FLOATS * sizeof(float);
-  static bool attr_set = false;  // benign race: the attribute call is idempotent
-  if (!attr_set) {
+  static unsigned long long attr_devs = 0;  // bit d: attribute set on device d (it is a per-device property of the function)
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 64 || !((attr_devs >> dev) & 1ull)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       cf_set_error("cf_conv2d: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
       return CF_ERR_LAUNCH;
     }
-    attr_set = true;
+    if (dev < 64) attr_devs |= 1ull << dev;  // benign race: the attribute call is idempotent
   }
   hipLaunchKernelGGL(kern, dim3(mtiles * k.ntn), dim3(256), lds, stream, k);
   CF_CHECK_LAUNCH("cf_conv2d");

@@ -16,7 +16,12 @@ void cf_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+#ifndef CF_BUILD_ID
+#define CF_BUILD_ID "unknown"
+#endif
 extern "C" int cf_version(void) { return CF_ABI_VERSION; }
+static const char g_build_id[] = "CF_BUILD_ID=" CF_BUILD_ID;  // (the marker lets build.py read the id from the file without dlopen)
+extern "C" const char* cf_build_id(void) { return g_build_id + 12; }
 extern "C" const char* cf_last_error(void) { return g_err; }
 extern "C" int cf_device_cu_count(void) {
   int dev = 0, n = 0;

@@ -485,15 +485,17 @@ int cf_winograd_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_que
     return CF_OK;
   }
   constexpr size_t lds = (WG_PATCH_FLOATS + WG_V_FLOATS) * sizeof(float);  // 61.7 KB: two workgroups per CU
-  static bool attr_set = false;  // benign race: the attribute call is idempotent
-  if (!attr_set) {
+  static unsigned long long attr_devs = 0;  // bit d: attribute set on device d (it is a per-device property of the function)
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 64 || !((attr_devs >> dev) & 1ull)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) {
       cf_set_error("cf_conv2d: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
       return CF_ERR_LAUNCH;
     }
-    attr_set = true;
+    if (dev < 64) attr_devs |= 1ull << dev;  // benign race: the attribute call is idempotent
   }
   hipLaunchKernelGGL(winograd_kernel, dim3(a.tiles_per_img * d->batch * a.ntn), dim3(256), lds, stream, a);
   CF_CHECK_LAUNCH("cf_conv2d(winograd)");

@@ -48,6 +48,7 @@ _I, _P, _F, _L = ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctypes.c_int64
 SIGNATURES = {
     'cf_version': (_I, []),
     'cf_last_error': (ctypes.c_char_p, []),
+    'cf_build_id': (ctypes.c_char_p, []),
     'cf_device_cu_count': (_I, []),
     'cf_conv2d': (_I, [ctypes.POINTER(ConvDesc), _P]),
     'cf_conv2d_stats_parts': (_I, [ctypes.POINTER(ConvDesc)]),
@@ -125,13 +126,17 @@ def stream_ptr():
     return torch.cuda.current_stream().cuda_stream
 
 
-def ptr(t, strided=False):
-    """Device pointer of a tensor (None -> NULL).  Tensors must be fp32/int64/uint8/float64 CUDA + contiguous
-    (strided=True: the caller validated the layout itself, e.g. a channel slice of an NHWC buffer)."""
+def ptr(t, strided=False, dtype=torch.float32):
+    """Device pointer of a tensor (None -> NULL).  The tensor must be a contiguous CUDA tensor of the dtype the kernel reads the
+    bytes as -- float32 unless the call site names another one (int64 code indices, float64 statistics, uint8 images;
+    dtype=None for opaque packed-weight buffers): a mismatch raises instead of being reinterpreted.
+    strided=True: the caller validated the layout itself (e.g. a channel slice of an NHWC buffer)."""
     if t is None:
         return None
     if not t.is_cuda:
         raise ValueError('codeformer_amd ops need CUDA (ROCm) tensors')
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f'codeformer_amd op expected a {dtype} tensor, got {t.dtype}')
     if not strided and not t.is_contiguous():
         raise ValueError('codeformer_amd ops need contiguous tensors')
     return t.data_ptr()

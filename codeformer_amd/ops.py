@@ -107,7 +107,7 @@ def pack_weight(weight, bias=None, bf16=False, up2x=False, f16=False):
         if up2x or w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or cin % 16 or cout % 64:
             raise ValueError('winograd packing needs a 3x3 weight with cin % 16 == 0 and cout % 64 == 0 (no up2x)')
         packed = torch.empty(16 * cin * cout, dtype=torch.float32, device=w.device)
-        L.check(lib.cf_pack_conv_weight_winograd(L.ptr(w), cout, cin, cout, cin, L.ptr(packed), L.stream_ptr()),
+        L.check(lib.cf_pack_conv_weight_winograd(L.ptr(w), cout, cin, cout, cin, L.ptr(packed, dtype=None), L.stream_ptr()),
                 'cf_pack_conv_weight_winograd')
         return PackedWeight(packed, b, cout, cin, 9, cout, cin, wino=True)
     if code == SPLIT:
@@ -117,7 +117,7 @@ def pack_weight(weight, bias=None, bf16=False, up2x=False, f16=False):
         wmax = float(w.abs().max()) * (4.0 if up2x else 1.0)
         scale = 1.0 if wmax == 0.0 or not math.isfinite(wmax) else 2.0 ** (14 - math.frexp(wmax)[1] + 1)
         packed = torch.empty((16 if up2x else 9) * cin * cout, dtype=torch.float32, device=w.device)
-        L.check(lib.cf_pack_conv_weight_f16x2(L.ptr(w), cout, cin, int(bool(up2x)), cout, cin, scale, L.ptr(packed), L.stream_ptr()),
+        L.check(lib.cf_pack_conv_weight_f16x2(L.ptr(w), cout, cin, int(bool(up2x)), cout, cin, scale, L.ptr(packed, dtype=None), L.stream_ptr()),
                 'cf_pack_conv_weight_f16x2')
         return PackedWeight(packed, b, cout, cin, 9, cout, cin, bf16=OPERAND_F16X2, up2x=bool(up2x), scale=scale)
     if w.dim() == 4:
@@ -136,7 +136,7 @@ def pack_weight(weight, bias=None, bf16=False, up2x=False, f16=False):
     if not code and not up2x:
         cout_pad, cin_pad = _cout_pad(cout), (cin + 15) // 16 * 16
         packed = torch.empty(lib.cf_packed_weight_elems(cin_pad, taps, cout_pad), dtype=torch.float32, device=w.device)
-        L.check(lib.cf_pack_conv_weight(L.ptr(w), cout, cin, taps, cout_pad, cin_pad, L.ptr(packed), L.stream_ptr()),
+        L.check(lib.cf_pack_conv_weight(L.ptr(w), cout, cin, taps, cout_pad, cin_pad, L.ptr(packed, dtype=None), L.stream_ptr()),
                 'cf_pack_conv_weight')
         return PackedWeight(packed, b, cout, cin, taps, cout_pad, cin_pad)
     # bf16 kernels and every upsample kernel have N tiles of at least 64; the f16 general instantiation also has a 32-wide one
@@ -144,7 +144,7 @@ def pack_weight(weight, bias=None, bf16=False, up2x=False, f16=False):
     dtype = (torch.float32, torch.bfloat16, torch.float16)[code]
     packed = torch.empty((16 if up2x else 9) * cin * cout_pad, dtype=dtype, device=w.device)
     name = 'cf_pack_conv_weight' + ('_up2x' if up2x else '') + ('', '_bf16', '_f16')[code]
-    args = (L.ptr(w), cout, cin) + (() if up2x else (9,)) + (cout_pad, cin, L.ptr(packed), L.stream_ptr())
+    args = (L.ptr(w), cout, cin) + (() if up2x else (9,)) + (cout_pad, cin, L.ptr(packed, dtype=None), L.stream_ptr())
     L.check(getattr(lib, name)(*args), name)
     return PackedWeight(packed, b, cout, cin, 9, cout_pad, cin, bf16=code, up2x=bool(up2x))
 
@@ -228,7 +228,7 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
         in0=L.ptr(x, not in_nchw), in1=L.ptr(x2, True), c0=c0, c1=c1, batch=B, hin=H, win=W, hout=Ho, wout=Wo, cout=pw.cout,
         cout_pad=pw.cout_pad, taps=pw.taps, stride=stride, upsample=int(bool(upsample)), in_nchw=int(bool(in_nchw)),
         out_nchw=int(bool(out_nchw)), prologue=prologue, epilogue=epilogue, pro_scale=L.ptr(scale),
-        pro_shift=L.ptr(shift), weight=L.ptr(pw.w), bias=L.ptr(pw.bias), res=L.ptr(res, True),
+        pro_shift=L.ptr(shift), weight=L.ptr(pw.w, dtype=None), bias=L.ptr(pw.bias), res=L.ptr(res, True),
         sft_scale=L.ptr(sft_scale, True), sft_w=float(sft_w), out=L.ptr(out, not out_nchw), bf16_mfma=int(pw.bf16),
         ld_in0=ld0, ld_in1=ld1, ld_out=ldo, pad_mode=int(pad_mode), pad_lo=int(pad_lo), winograd=int(pw.wino),
         acc_scale=1.0 / pw.scale)
@@ -238,7 +238,7 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
         if parts <= 0:
             raise RuntimeError(f'cf_conv2d_stats_parts failed ({parts}): {L.last_error()}')
         part = torch.empty(B * GN_GROUPS * parts * 2, dtype=torch.float64, device=x.device)
-        d.stats_out = L.ptr(part)
+        d.stats_out = L.ptr(part, dtype=torch.float64)
         out._cf_stats = GNStats(part, parts, d.stats_cpg)
     if PROFILE is None:
         L.check(lib.cf_conv2d(ctypes.byref(d), L.stream_ptr()), 'cf_conv2d')
@@ -299,9 +299,9 @@ def groupnorm_tables(xs, gamma, beta, eps=GN_EPS, groups=GN_GROUPS):
             # ~128 KB of input per block, enough blocks to cover 256 CUs several times, at most 256 partials per group
             nblk = max(1, min(256, (hw * c * 4 + (1 << 17) - 1) >> 17))
             part = torch.empty(B * (c // cpg) * nblk * 2, dtype=torch.float64, device=dev)
-            L.check(lib.cf_groupnorm_stats(L.ptr(t), B, hw, c, cpg, L.ptr(part), nblk, L.stream_ptr()), 'cf_groupnorm_stats')
+            L.check(lib.cf_groupnorm_stats(L.ptr(t), B, hw, c, cpg, L.ptr(part, dtype=torch.float64), nblk, L.stream_ptr()), 'cf_groupnorm_stats')
             st = GNStats(part, nblk, cpg)
-        L.check(lib.cf_groupnorm_finalize(L.ptr(st.part), B, st.parts, c, st.cpg, cpg // st.cpg, hw * cpg,
+        L.check(lib.cf_groupnorm_finalize(L.ptr(st.part, dtype=torch.float64), B, st.parts, c, st.cpg, cpg // st.cpg, hw * cpg,
                                           g_ptr + 4 * coff, b_ptr + 4 * coff, float(eps), sc_ptr + 4 * coff,
                                           sh_ptr + 4 * coff, ctot, L.stream_ptr()), 'cf_groupnorm_finalize')
         coff += c
@@ -339,7 +339,7 @@ def argmax_rows(logits):
     lib = L.load()
     rows, n = logits.shape
     idx = torch.empty(rows, dtype=torch.int64, device=logits.device)
-    L.check(lib.cf_argmax_rows(L.ptr(_f32(logits)), rows, n, L.ptr(idx), L.stream_ptr()), 'cf_argmax_rows')
+    L.check(lib.cf_argmax_rows(L.ptr(_f32(logits)), rows, n, L.ptr(idx, dtype=torch.int64), L.stream_ptr()), 'cf_argmax_rows')
     return idx
 
 
@@ -348,7 +348,7 @@ def codebook_gather(idx, codebook, batch, ntok, lq=None, eps=1e-5):
     lib = L.load()
     ncodes, dim = codebook.shape
     out = torch.empty(batch, ntok, dim, dtype=torch.float32, device=codebook.device)
-    L.check(lib.cf_codebook_gather_adain(L.ptr(idx), L.ptr(_f32(codebook)), ncodes, L.ptr(lq), batch, ntok, dim,
+    L.check(lib.cf_codebook_gather_adain(L.ptr(idx, dtype=torch.int64), L.ptr(_f32(codebook)), ncodes, L.ptr(lq), batch, ntok, dim,
                                          int(lq is not None), float(eps), L.ptr(out), L.stream_ptr()),
             'cf_codebook_gather_adain')
     return out
@@ -367,7 +367,7 @@ def vq_nearest(z_tokens, codebook, pw_codebook=None):
     L.check(lib.cf_row_sqnorm(L.ptr(_f32(codebook)), ncodes, dim, L.ptr(ee), L.stream_ptr()), 'cf_row_sqnorm')
     idx = torch.empty(rows, dtype=torch.int64, device=z_tokens.device)
     dmin = torch.empty(rows, dtype=torch.float32, device=z_tokens.device)
-    L.check(lib.cf_vq_argmin(L.ptr(scores), L.ptr(zz), L.ptr(ee), rows, ncodes, L.ptr(idx), L.ptr(dmin), L.stream_ptr()),
+    L.check(lib.cf_vq_argmin(L.ptr(scores), L.ptr(zz), L.ptr(ee), rows, ncodes, L.ptr(idx, dtype=torch.int64), L.ptr(dmin), L.stream_ptr()),
             'cf_vq_argmin')
     return idx, dmin, (scores, zz, ee)
 
@@ -412,7 +412,7 @@ def img_u8_to_tensor(img):
     lib = L.load()
     B, H, W, _ = img.shape
     out = torch.empty(B, 3, H, W, dtype=torch.float32, device=img.device)
-    L.check(lib.cf_img_u8_to_tensor(L.ptr(img), B, H, W, L.ptr(out), L.stream_ptr()), 'cf_img_u8_to_tensor')
+    L.check(lib.cf_img_u8_to_tensor(L.ptr(img, dtype=torch.uint8), B, H, W, L.ptr(out), L.stream_ptr()), 'cf_img_u8_to_tensor')
     return out
 
 
@@ -421,7 +421,7 @@ def tensor_to_img_u8(t):
     lib = L.load()
     B, _, H, W = t.shape
     img = torch.empty(B, H, W, 3, dtype=torch.uint8, device=t.device)
-    L.check(lib.cf_tensor_to_img_u8(L.ptr(_f32(t).contiguous()), B, H, W, L.ptr(img), L.stream_ptr()), 'cf_tensor_to_img_u8')
+    L.check(lib.cf_tensor_to_img_u8(L.ptr(_f32(t).contiguous()), B, H, W, L.ptr(img, dtype=torch.uint8), L.stream_ptr()), 'cf_tensor_to_img_u8')
     return img
 
 

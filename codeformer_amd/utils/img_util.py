@@ -12,21 +12,51 @@ import torch
 
 
 def imread_bgr(path):
-    """cv2.imread(path, cv2.IMREAD_COLOR) equivalent: uint8 HWC BGR (alpha dropped, gray replicated)."""
-    from PIL import Image
+    """cv2.imread(path, cv2.IMREAD_COLOR) equivalent: uint8 HWC BGR (alpha dropped, gray replicated, EXIF orientation applied as
+    cv2.imread does)."""
+    from PIL import Image, ImageOps
     with Image.open(path) as im:
-        rgb = np.asarray(im.convert('RGB'))
+        rgb = np.asarray(ImageOps.exif_transpose(im).convert('RGB'))
     return np.ascontiguousarray(rgb[:, :, ::-1])
 
 
 def resize_bilinear(img, size):
-    """cv2.resize(img, size, INTER_LINEAR) stand-in (identity when the size already matches)."""
+    """cv2.resize(img, size, interpolation=cv2.INTER_LINEAR) for uint8 HWC images (identity when the size already matches).
+
+    cv2's rule, restated: half-pixel centres (src = (dst + 0.5) * scale - 0.5), the two nearest source samples per axis with NO
+    antialiasing even when shrinking, source coordinates clamped to the image, and -- for uint8 -- fixed-point arithmetic: the
+    per-axis weights are rounded to 11 bits (INTER_RESIZE_COEF_BITS, round-half-to-even like cvRound) and the 22-bit product sum
+    is rounded to nearest with (v + 2^21) >> 22.  PIL's BILINEAR widens its support when shrinking, so it is not a stand-in."""
     h, w = img.shape[:2]
-    if (w, h) == tuple(size):
+    dw, dh = int(size[0]), int(size[1])
+    if (w, h) == (dw, dh):
         return img
-    from PIL import Image
-    rgb = Image.fromarray(np.ascontiguousarray(img[:, :, ::-1]))
-    return np.ascontiguousarray(np.asarray(rgb.resize(size, Image.BILINEAR))[:, :, ::-1])
+    if img.dtype != np.uint8:
+        raise TypeError('resize_bilinear restates the uint8 path of cv2.resize')
+
+    def axis(n_src, n_dst):
+        scale = n_src / n_dst
+        f = (np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5
+        i0 = np.floor(f).astype(np.int64)
+        frac = (f - i0).astype(np.float32)
+        lo = i0 < 0
+        frac[lo] = 0.0
+        i0[lo] = 0
+        hi = i0 >= n_src - 1
+        frac[hi] = 0.0
+        i0[hi] = n_src - 1
+        i1 = np.minimum(i0 + 1, n_src - 1)
+        w1 = np.rint(frac.astype(np.float64) * 2048.0).astype(np.int64)     # cvRound: half to even
+        return i0, i1, 2048 - w1, w1
+
+    x0, x1, wx0, wx1 = axis(w, dw)
+    y0, y1, wy0, wy1 = axis(h, dh)
+    src = img.astype(np.int64).reshape(h, w, -1)
+    rows0, rows1 = src[y0], src[y1]                                        # (dh, w, c)
+    top = rows0[:, x0] * wx0[None, :, None] + rows0[:, x1] * wx1[None, :, None]
+    bot = rows1[:, x0] * wx0[None, :, None] + rows1[:, x1] * wx1[None, :, None]
+    out = (top * wy0[:, None, None] + bot * wy1[:, None, None] + (1 << 21)) >> 22
+    return np.ascontiguousarray(out.astype(np.uint8).reshape((dh, dw) + img.shape[2:]))
 
 
 def img2tensor(imgs, bgr2rgb=True, float32=True):

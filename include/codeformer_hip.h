@@ -37,6 +37,9 @@ enum cf_status {
 };
 
 int cf_version(void);
+/* sha256 (first 16 hex digits) of the sources this library was compiled from (csrc + this header), passed by the build script
+ * as -DCF_BUILD_ID; "unknown" for hand builds.  codeformer_amd/build.py rebuilds when it differs from the tree's hash. */
+const char* cf_build_id(void);
 const char* cf_last_error(void);
 /* number of compute units of the current device (for host-side grid heuristics) */
 int cf_device_cu_count(void);

@@ -62,6 +62,25 @@ def parse_args(argv=None):
     return p.parse_args(argv)
 
 
+def set_realesrgan(args, device, random_init_seed=None):
+    """RealESRGANer(RRDBNet x2) as the reference builds it (inference_codeformer.py:19-52): half operands on a GPU, fp32 on CPU.
+    Returns None (with a note) when the checkpoint is absent and no seeded random init was requested."""
+    from basicsr.archs.rrdbnet_arch import RRDBNet
+    from basicsr.utils.realesrgan_utils import RealESRGANer
+    model = RRDBNet(num_in_ch=3, num_out_ch=3, num_feat=64, num_block=23, num_grow_ch=32, scale=2)
+    url = 'https://github.com/sczhou/CodeFormer/releases/download/v0.1.0/RealESRGAN_x2plus.pth'
+    try:
+        return RealESRGANer(scale=2, model_path=url, model=model, tile=args.bg_tile, tile_pad=40, pre_pad=0,
+                            half=device.type == 'cuda', device=device)
+    except FileNotFoundError as e:
+        if random_init_seed is None:
+            print(f'NOTE: {e}; the Real-ESRGAN upsampler is not used on the --has_aligned path and is skipped')
+            return None
+        print('WARNING: RealESRGAN_x2plus.pth not found -- using random weights for the (unused) upsampler')
+        return RealESRGANer(scale=2, model_path=None, model=model, tile=args.bg_tile, tile_pad=40, pre_pad=0,
+                            half=device.type == 'cuda', device=device)
+
+
 def collect_inputs(args):
     w = args.fidelity_weight
     path = args.input_path
@@ -104,8 +123,11 @@ def main(argv=None):
     if not args.has_aligned:
         raise NotImplementedError('whole-image inputs need face detection / alignment / paste-back (the reference keeps '
                                   'these on the host in facelib); pass aligned 512x512 crops with --has_aligned')
-    if args.bg_upsampler == 'realesrgan' or args.face_upsample:
-        raise NotImplementedError('Real-ESRGAN upsampling is never used on the --has_aligned path and is not provided')
+    # The reference builds the Real-ESRGAN upsampler for these flags (inference_codeformer.py:112-124) but only ever USES it in the
+    # paste-back of whole images (:217-229): on the --has_aligned path it never runs.  Same here: build it when its checkpoint is
+    # present (weights/realesrgan/RealESRGAN_x2plus.pth), say so when it is not.
+    bg_upsampler = set_realesrgan(args, device, args.random_init_seed) if args.bg_upsampler == 'realesrgan' else None
+    face_upsampler = (bg_upsampler or set_realesrgan(args, device, args.random_init_seed)) if args.face_upsample else None
 
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     if world > 1:
@@ -118,7 +140,7 @@ def main(argv=None):
         my_list, first = input_img_list, 0
 
     net = build_net(device, args)
-    print(f'Background upsampling: False, Face upsampling: {args.face_upsample}')
+    print(f'Background upsampling: {bg_upsampler is not None}, Face upsampling: {args.face_upsample}')
     face_helper = AlignedFaceHelper()
     bs = args.batch_size or (16 if device.type == 'cuda' else 1)
     total = len(input_img_list)

@@ -1,0 +1,59 @@
+"""Host-side pieces around the hot path (CPU): the cv2-rule bilinear resize, EXIF handling of the image reader, the content-hash
+gate of the build script and the upsampler flags of the entrypoint on the --has_aligned path."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_resize_bilinear_follows_the_cv2_inter_linear_rule():
+    from codeformer_amd.utils.img_util import resize_bilinear
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, (7, 5, 3), dtype=np.uint8)
+    assert resize_bilinear(a, (5, 7)) is a
+    up = resize_bilinear(a, (10, 14))
+    assert up.shape == (14, 10, 3) and np.array_equal(up[0, 0], a[0, 0]) and np.array_equal(up[-1, -1], a[-1, -1])   # clamped borders
+    # dst x = 1 -> src 0.25: weights 0.75 / 0.25 on both axes where interior
+    want = (a[0, 0].astype(np.int64) * 1536 + a[0, 1].astype(np.int64) * 512)
+    assert np.array_equal(up[0, 1], ((want * 2048 + (1 << 21)) >> 22).astype(np.uint8))
+    # shrinking takes TWO samples per axis (no antialiasing): 16 -> 8 is the mean of neighbouring pairs, 16 -> 4 skips samples
+    g = np.tile(np.arange(0, 256, 16, dtype=np.uint8)[None, :, None], (4, 1, 3))
+    assert resize_bilinear(g, (8, 4))[0, :, 0].tolist() == [8, 40, 72, 104, 136, 168, 200, 232]
+    assert resize_bilinear(g, (4, 4))[0, :, 0].tolist() == [24, 88, 152, 216]     # src 1.5, 5.5, ...: mean of samples (1,2), (5,6), ...
+    assert np.unique(resize_bilinear(np.full((9, 8, 3), 77, np.uint8), (3, 5))).tolist() == [77]
+
+
+def test_imread_applies_exif_orientation_like_cv2(tmp_path):
+    from PIL import Image
+    from codeformer_amd.utils.img_util import imread_bgr
+    a = np.zeros((4, 6, 3), np.uint8)
+    a[0, 0] = (255, 0, 0)
+    im = Image.fromarray(a)
+    ex = im.getexif()
+    ex[0x0112] = 6          # "rotate 90 CW to display"
+    im.save(tmp_path / 'r.jpg', exif=ex, quality=100, subsampling=0)
+    b = imread_bgr(str(tmp_path / 'r.jpg'))
+    assert b.shape == (6, 4, 3) and b[0, -1, 2] > 200 and b[0, 0, 2] < 60     # the red corner moved to the top right; BGR order
+
+
+def test_build_id_follows_the_sources():
+    from codeformer_amd import build, lib
+    assert build.built_id() == build.source_hash() and not build.needs_build()
+    assert lib.load().cf_build_id().decode() == build.source_hash()
+
+
+def test_upsampler_flags_are_accepted_on_the_aligned_path(tmp_path):
+    """--bg_upsampler realesrgan / --face_upsample: the reference builds the upsampler but never runs it for aligned crops
+    (inference_codeformer.py:217-229); without its checkpoint the run goes on and says so."""
+    from PIL import Image
+    src = tmp_path / 'cropped_faces'
+    os.makedirs(src)
+    Image.fromarray(np.random.default_rng(2).integers(0, 256, (512, 512, 3), dtype=np.uint8)).save(src / 'a.png')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'inference_codeformer.py'), '--has_aligned', '-i', str(src), '-o',
+                        str(tmp_path / 'o'), '--device', 'cpu', '--random_init_seed', '0', '--bg_upsampler', 'realesrgan',
+                        '--face_upsample'], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert os.listdir(tmp_path / 'o' / 'restored_faces') == ['a.png'] and 'upsampler' in r.stdout

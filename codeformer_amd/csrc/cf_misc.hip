@@ -168,28 +168,69 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 }
 
 // ---- tensor boundary ------------------------------------------------------------------------------
-__global__ void img_u8_to_tensor_kernel(const uint8_t* __restrict__ img, int hw, float* __restrict__ out, long total) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over batch*hw pixels
-  if (i >= total) return;
-  const long b = i / hw, p = i - b * hw;
-  const uint8_t* px = img + i * 3;  // BGR
+// u8 HWC BGR -> fp32 NCHW RGB in [-1,1]: (float)((double)u / 255.) then (v - 0.5f) / 0.5f, the arithmetic of
+// img2tensor(img / 255.) + normalize (inference_codeformer.py:199-201).  Only 256 inputs exist, so every workgroup evaluates them
+// once into an LDS table; a thread then converts FOUR pixels: three 4-byte loads of the interleaved bytes, one 16-byte store per
+// colour plane.  (hw % 4 != 0: the tail pixels of an image go one at a time.)
+__global__ __launch_bounds__(256) void img_u8_to_tensor_kernel(const uint8_t* __restrict__ img, int hw, float* __restrict__ out,
+                                                               long nquads, int batch) {
+  __shared__ float lut[256];
+  {
+    const float v = (float)((double)threadIdx.x / 255.0);
+    lut[threadIdx.x] = (v - 0.5f) / 0.5f;
+  }
+  __syncthreads();
+  const int qpi = (hw + 3) >> 2;  // quads per image (the last one may be partial)
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nquads; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / qpi;
+    const int p = (int)(i - b * qpi) * 4;
+    const uint8_t* px = img + (b * hw + p) * 3;
+    float* o = out + b * 3 * hw + p;
+    if (p + 4 <= hw && (hw & 3) == 0) {
+      const uint32_t* w = reinterpret_cast<const uint32_t*>(px);  // 12-byte groups of a 4-byte aligned buffer: aligned
+      const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];            // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+      const f32x4 r = {lut[(w0 >> 16) & 255], lut[(w1 >> 8) & 255], lut[w2 & 255], lut[w2 >> 24]};
+      const f32x4 g = {lut[(w0 >> 8) & 255], lut[w1 & 255], lut[w1 >> 24], lut[(w2 >> 16) & 255]};
+      const f32x4 bl = {lut[w0 & 255], lut[w0 >> 24], lut[(w1 >> 16) & 255], lut[(w2 >> 8) & 255]};
+      *reinterpret_cast<f32x4*>(o) = r;
+      *reinterpret_cast<f32x4*>(o + hw) = g;
+      *reinterpret_cast<f32x4*>(o + 2 * (long)hw) = bl;
+    } else {
+      for (int k = 0; k < 4 && p + k < hw; ++k)
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const float v = (float)((double)px[2 - c] / 255.0);  // img/255. in fp64 then .astype(float32)
-    out[(b * 3 + c) * hw + p] = (v - 0.5f) / 0.5f;      // torchvision normalize
+        for (int c = 0; c < 3; ++c) o[(long)c * hw + k] = lut[px[k * 3 + 2 - c]];
+    }
   }
 }
 
-__global__ void tensor_to_img_u8_kernel(const float* __restrict__ t, int hw, uint8_t* __restrict__ img, long total) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const long b = i / hw, p = i - b * hw;
+// fp32 NCHW RGB -> u8 HWC BGR == tensor2img(min_max=(-1,1)): clamp, (v + 1) / 2, * 255, round half to even (img_util.py:66-90);
+// four pixels per thread: one 16-byte load per colour plane, three 4-byte stores of the interleaved bytes.
+__device__ __forceinline__ uint32_t cf_to_u8(float v) {
+  v = fminf(fmaxf(v, -1.0f), 1.0f);
+  v = (v - (-1.0f)) / (1.0f - (-1.0f));
+  return (uint32_t)(uint8_t)rintf(v * 255.0f);
+}
+__global__ __launch_bounds__(256) void tensor_to_img_u8_kernel(const float* __restrict__ t, int hw, uint8_t* __restrict__ img,
+                                                               long nquads) {
+  const int qpi = (hw + 3) >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nquads; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / qpi;
+    const int p = (int)(i - b * qpi) * 4;
+    const float* src = t + b * 3 * hw + p;
+    uint8_t* px = img + (b * hw + p) * 3;
+    if (p + 4 <= hw && (hw & 3) == 0) {
+      const f32x4 r = *reinterpret_cast<const f32x4*>(src);
+      const f32x4 g = *reinterpret_cast<const f32x4*>(src + hw);
+      const f32x4 bl = *reinterpret_cast<const f32x4*>(src + 2 * (long)hw);
+      uint32_t* w = reinterpret_cast<uint32_t*>(px);
+      w[0] = cf_to_u8(bl[0]) | (cf_to_u8(g[0]) << 8) | (cf_to_u8(r[0]) << 16) | (cf_to_u8(bl[1]) << 24);
+      w[1] = cf_to_u8(g[1]) | (cf_to_u8(r[1]) << 8) | (cf_to_u8(bl[2]) << 16) | (cf_to_u8(g[2]) << 24);
+      w[2] = cf_to_u8(r[2]) | (cf_to_u8(bl[3]) << 8) | (cf_to_u8(g[3]) << 16) | (cf_to_u8(r[3]) << 24);
+    } else {
+      for (int k = 0; k < 4 && p + k < hw; ++k)
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    float v = t[(b * 3 + c) * hw + p];
-    v = fminf(fmaxf(v, -1.0f), 1.0f);
-    v = (v - (-1.0f)) / (1.0f - (-1.0f));
-    img[i * 3 + (2 - c)] = (uint8_t)rintf(v * 255.0f);  // np.round = half-to-even
+        for (int c = 0; c < 3; ++c) px[k * 3 + 2 - c] = (uint8_t)cf_to_u8(src[(long)c * hw + k]);
+    }
   }
 }
 
@@ -333,17 +374,19 @@ extern "C" int cf_nhwc_to_nchw(const float* x, int batch, int c, int hw, float* 
 
 extern "C" int cf_img_u8_to_tensor(const uint8_t* img, int batch, int h, int w, float* out, cf_stream_t stream) {
   CF_REQUIRE(img && out && batch > 0 && h > 0 && w > 0, "cf_img_u8_to_tensor: bad args");
-  const long total = (long)batch * h * w;
-  hipLaunchKernelGGL(img_u8_to_tensor_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, img,
-                     h * w, out, total);
+  const long nquads = (long)batch * ((h * w + 3) / 4);
+  long blocks = (nquads + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(img_u8_to_tensor_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, img, h * w, out, nquads, batch);
   CF_CHECK_LAUNCH("cf_img_u8_to_tensor");
   return CF_OK;
 }
 extern "C" int cf_tensor_to_img_u8(const float* t, int batch, int h, int w, uint8_t* img, cf_stream_t stream) {
   CF_REQUIRE(img && t && batch > 0 && h > 0 && w > 0, "cf_tensor_to_img_u8: bad args");
-  const long total = (long)batch * h * w;
-  hipLaunchKernelGGL(tensor_to_img_u8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t,
-                     h * w, img, total);
+  const long nquads = (long)batch * ((h * w + 3) / 4);
+  long blocks = (nquads + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(tensor_to_img_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t, h * w, img, nquads);
   CF_CHECK_LAUNCH("cf_tensor_to_img_u8");
   return CF_OK;
 }

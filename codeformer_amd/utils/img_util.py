@@ -130,13 +130,15 @@ def tensor2img(tensor, rgb2bgr=True, out_type=np.uint8, min_max=(0, 1)):
     return result[0] if len(result) == 1 else result
 
 
-def imwrite(img, file_path, params=None, auto_mkdir=True):
-    """Write a uint8 HWC BGR (or HW gray) array; format from the extension (cv2.imwrite stand-in)."""
+def imwrite(img, file_path, params=None, auto_mkdir=True, compress_level=None):
+    """Write a uint8 HWC BGR (or HW gray) array; format from the extension (cv2.imwrite stand-in).  compress_level: zlib level
+    for PNG output (None = PIL's default 6; decoded pixels are identical at every level)."""
     from PIL import Image
     if auto_mkdir:
         os.makedirs(os.path.abspath(os.path.dirname(file_path)), exist_ok=True)
     arr = np.asarray(img)
     if arr.ndim == 3:
         arr = arr[:, :, ::-1]
-    Image.fromarray(np.ascontiguousarray(arr)).save(file_path)
+    kw = {'compress_level': int(compress_level)} if (compress_level is not None and str(file_path).lower().endswith('.png')) else {}
+    Image.fromarray(np.ascontiguousarray(arr)).save(file_path, **kw)
     return True

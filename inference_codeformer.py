@@ -58,6 +58,7 @@ def parse_args(argv=None):
     p.add_argument('--random_init_seed', type=int, default=None,
                    help='Use torch.manual_seed(SEED) random weights when weights/CodeFormer/codeformer.pth is absent '
                         '(plumbing runs on boxes without the checkpoint)')
+    p.add_argument('--io_workers', type=int, default=None, help='PNG decode / encode worker threads of the GPU pipeline')
     p.add_argument('--strict', action='store_true', help='Raise on inference errors instead of returning the input face')
     return p.parse_args(argv)
 
@@ -146,9 +147,42 @@ def main(argv=None):
     total = len(input_img_list)
     failures = 0
 
+    def finish_face(face, out, g):
+        """What the reference does with a restored crop before saving it (inference_codeformer.py:211-214 +
+        face_restoration_helper.py:364-369): gray inputs get the gray colour transfer."""
+        helper = AlignedFaceHelper()
+        helper.is_gray = g
+        helper.cropped_faces = [face]
+        helper.add_restored_face(out.astype('uint8'), face)
+        r = helper.restored_faces[0]
+        return r if r.dtype == np.uint8 else np.clip(np.round(r), 0, 255).astype('uint8')
+
+    def out_name(img_path):
+        name = os.path.splitext(os.path.basename(img_path))[0]
+        return os.path.join(result_root, 'restored_faces', f'{name}.png' if args.suffix is None else f'{name}_{args.suffix}.png')
+
+    if device.type == 'cuda':
+        # overlapped pipeline: PNG decode / encode in a worker pool, uint8 over PCIe through pinned staging on side streams
+        from codeformer_amd.pipeline import AlignedFacePipeline
+        for j, img_path in enumerate(my_list):
+            print(f'[{first + j + 1}/{total}] Processing: {os.path.basename(img_path)}')
+        pipe = AlignedFacePipeline(net, device, batch_size=bs, workers=args.io_workers)
+
+        def post(face, out, meta):
+            g = is_gray(face, threshold=10)
+            if g:
+                print('Grayscale input: True')
+            return finish_face(face, out, g)
+
+        st = pipe.restore(my_list, [out_name(q) for q in my_list], w=w, adain=True, post=post, strict=args.strict)
+        failures = st['failures']
+        print(f"{st['faces']} faces in {st['seconds']:.2f} s = {st['faces_per_s']:.1f} faces/s including PNG decode / encode "
+              f"(host waited {st['wait_decode_s']:.2f} s for decodes, {st['wait_slot_s']:.2f} s for writes)")
+        my_list = []
+
     for s in range(0, len(my_list), bs):
         chunk = my_list[s:s + bs]
-        faces, names, grays = [], [], []
+        faces, grays = [], []
         for j, img_path in enumerate(chunk):
             img_name = os.path.basename(img_path)
             print(f'[{first + s + j + 1}/{total}] Processing: {img_name}')
@@ -157,7 +191,6 @@ def main(argv=None):
             if g:
                 print('Grayscale input: True')
             faces.append(img)
-            names.append(os.path.splitext(img_name)[0])
             grays.append(g)
         x = faces_to_tensor(faces, device)
         try:
@@ -169,15 +202,8 @@ def main(argv=None):
             print(f'\tFailed inference for CodeFormer: {error}')
             failures += len(faces)
             restored = tensor_to_faces(x)
-        for face, out, name, g in zip(faces, restored, names, grays):
-            face_helper.clean_all()
-            face_helper.is_gray = g
-            face_helper.cropped_faces = [face]
-            face_helper.add_restored_face(out.astype('uint8'), face)
-            save_face_name = f'{name}.png' if args.suffix is None else f'{name}_{args.suffix}.png'
-            imwrite(np.clip(np.round(face_helper.restored_faces[0]), 0, 255).astype('uint8')
-                    if face_helper.restored_faces[0].dtype != np.uint8 else face_helper.restored_faces[0],
-                    os.path.join(result_root, 'restored_faces', save_face_name))
+        for img_path, face, out, g in zip(chunk, faces, restored, grays):
+            imwrite(finish_face(face, out, g), out_name(img_path))
     if failures:
         print(f'WARNING: {failures} face(s) fell back to the unrestored input')
     print(f'\nAll results are saved in {result_root}')

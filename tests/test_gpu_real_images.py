@@ -167,3 +167,57 @@ def test_tensor2img_bytes_equal_the_reference(chk):
     k = np.load(os.path.join(GOLD, 'tensor2img_kat.npz'))
     got = ops.tensor_to_img_u8(torch.from_numpy(k['t']).unsqueeze(0).cuda())[0].cpu().numpy()
     assert np.array_equal(got, k['img'])
+
+
+def test_overlapped_pipeline_writes_the_direct_path_bytes(net, tmp_path):
+    """codeformer_amd.pipeline (pinned staging, copy streams, decode / encode workers, partial last batch) against the plain
+    sequence decode -> cf_img_u8_to_tensor -> forward -> cf_tensor_to_img_u8 -> encode on the same files."""
+    import torch
+    from PIL import Image
+    from codeformer_amd import ops
+    from codeformer_amd.pipeline import AlignedFacePipeline
+    imgs = [np.load(os.path.join(GOLD, n))['img'] for n in REAL]
+    imgs += [np.ascontiguousarray(imgs[0][::-1]), np.repeat(imgs[1].mean(-1, keepdims=True).astype(np.uint8), 3, axis=2)]   # + a gray one
+    paths, outs = [], []
+    for i, a in enumerate(imgs):
+        p = tmp_path / f'in{i}.png'
+        Image.fromarray(a[:, :, ::-1]).save(p)
+        paths.append(str(p))
+        outs.append(str(tmp_path / 'out' / f'in{i}.png'))
+    pipe = AlignedFacePipeline(net, 'cuda', batch_size=2, workers=3, slots=2)
+    st = pipe.restore(paths, outs, w=0.5)
+    assert st['faces'] == 5 and st['batches'] == 3 and st['failures'] == 0
+    for a, o in zip(imgs, outs):
+        x = ops.img_u8_to_tensor(torch.from_numpy(a).unsqueeze(0).cuda())
+        want = ops.tensor_to_img_u8(net(x, w=0.5, adain=True)[0])[0].cpu().numpy()
+        got = np.asarray(Image.open(o))[:, :, ::-1]
+        assert np.array_equal(got, want), o
+
+
+def test_boundary_kernels_on_sizes_off_the_vector_grid(chk):
+    """cf_img_u8_to_tensor / cf_tensor_to_img_u8 convert four pixels per thread; sizes with h*w % 4 != 0 take the per-pixel tail."""
+    import torch
+    from codeformer_amd import ops
+    from oracle import codeformer_oracle as O
+    rng = np.random.default_rng(7)
+    for h, w in ((5, 7), (3, 3), (16, 18)):
+        img = rng.integers(0, 256, (3, h, w, 3), dtype=np.uint8)
+        t = ops.img_u8_to_tensor(torch.from_numpy(img).cuda())
+        ref = torch.from_numpy(((img[..., ::-1] / 255.).astype(np.float32).transpose(0, 3, 1, 2) - 0.5) / 0.5)
+        assert torch.equal(t.cpu(), ref), (h, w)
+        x = torch.randn(3, 3, h, w, generator=torch.Generator().manual_seed(h)) * 1.2
+        got = ops.tensor_to_img_u8(x.cuda()).cpu().numpy()
+        for b in range(3):
+            assert np.array_equal(got[b], O.tensor2img_u8(x[b])), (h, w)
+
+
+def test_dtype_mismatch_is_refused_not_reinterpreted(chk):
+    import torch
+    from codeformer_amd import ops
+    cb = torch.randn(1024, 256, device='cuda')
+    idx = torch.randint(0, 1024, (256,), device='cuda', dtype=torch.int32)
+    with pytest.raises(TypeError):
+        ops.codebook_gather(idx, cb, 1, 256)
+    with pytest.raises(TypeError):
+        ops.groupnorm_tables([torch.randn(1, 16, 16, 64, device='cuda')], torch.ones(64, device='cuda', dtype=torch.float16),
+                             torch.zeros(64, device='cuda'))

@@ -77,6 +77,16 @@ SIGNATURES = {
     'cf_mask_composite': (_I, [_P, _P, _I, _I, _I, _P, _P]),
     'cf_fused_bias_act': (_I, [_P, _P, _L, _I, _I, _F, _F, _P, _P]),
     'cf_upfirdn2d': (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'cf_warp_affine_u8': (_I, [_P, _L, _I, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'cf_warp_affine_f32': (_I, [_P, _I, _I, ctypes.POINTER(ctypes.c_double), _P, _I, _I, _I, _I, _P]),
+    'cf_erode_f32': (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    'cf_gaussian_blur_f32': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
+    'cf_sum_f32': (_I, [_P, _L, _P, _P]),
+    'cf_paste_blend': (_I, [_P, _I, _I, _P, _I, _I, ctypes.POINTER(ctypes.c_double), _P, _P, _P, _I, _I, _I, _I, _P]),
+    'cf_resize_linear_u8': (_I, [_P, _I, _I, _P, _I, _I, _P]),
+    'cf_f32_to_u8_trunc': (_I, [_P, _L, _P, _P]),
+    'cf_label_lut_f32': (_I, [_P, _L, ctypes.POINTER(ctypes.c_float), _I, _P, _P]),
+    'cf_scale_clear_border_f32': (_I, [_P, _I, _I, _I, _I, _F, _P]),
 }
 
 _lib = None

@@ -461,3 +461,97 @@ def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0)):
     L.check(lib.cf_upfirdn2d(L.ptr(x), n * c, h, w, L.ptr(_f32(kernel).contiguous()), kh, kw, up, up, down, down, p0, p1,
                              p0, p1, L.ptr(y), L.stream_ptr()), 'cf_upfirdn2d')
     return y
+
+
+# ---- alignment warp / paste-back primitives (cf_paste.hip) -- see codeformer_amd/facelib/paste.py for the orchestration --------------
+def _c6(m):
+    """6 doubles in host memory for the ctypes call (a 2x3 destination->source matrix)."""
+    vals = [float(v) for v in (m.reshape(-1).tolist() if hasattr(m, 'reshape') else m)]
+    if len(vals) != 6:
+        raise ValueError('affine matrix must have 6 elements')
+    return (ctypes.c_double * 6)(*vals)
+
+
+def warp_affine_u8(src, inv_dev, dst, region=None, border=(0, 0, 0)):
+    """src: uint8 (sh,sw,3) (shared) or (n,sh,sw,3); inv_dev: float64 CUDA (n,6) destination->source matrices; dst: uint8 (n,dh,dw,3)
+    written inside region = (rx, ry, rw, rh) (default: everything)."""
+    lib = L.load()
+    n, dh, dw, _ = dst.shape
+    shared = src.dim() == 3
+    sh, sw = (src.shape[0], src.shape[1]) if shared else (src.shape[1], src.shape[2])
+    if (not shared and src.shape[0] != n) or tuple(inv_dev.shape) != (n, 6):
+        raise ValueError('warp_affine_u8: batch mismatch')
+    rx, ry, rw, rh = region or (0, 0, dw, dh)
+    L.check(lib.cf_warp_affine_u8(L.ptr(src, dtype=torch.uint8), 0 if shared else sh * sw * 3, sh, sw, L.ptr(inv_dev, dtype=torch.float64), n,
+                                  L.ptr(dst, dtype=torch.uint8), dh, dw, rx, ry, rw, rh, int(border[0]), int(border[1]), int(border[2]),
+                                  L.stream_ptr()), 'cf_warp_affine_u8')
+    return dst
+
+
+def warp_affine_f32(src, inv, region):
+    lib = L.load()
+    rx, ry, rw, rh = region
+    out = torch.empty(rh, rw, dtype=torch.float32, device=src.device)
+    L.check(lib.cf_warp_affine_f32(L.ptr(src), src.shape[0], src.shape[1], _c6(inv), L.ptr(out), rx, ry, rw, rh, L.stream_ptr()),
+            'cf_warp_affine_f32')
+    return out
+
+
+def erode(x, k):
+    lib = L.load()
+    tmp, out = torch.empty_like(x), torch.empty_like(x)
+    L.check(lib.cf_erode_f32(L.ptr(x), L.ptr(tmp), L.ptr(out), x.shape[0], x.shape[1], int(k), L.stream_ptr()), 'cf_erode_f32')
+    return out
+
+
+def gaussian_blur(x, taps_dev, region_xy=(0, 0), frame_hw=None):
+    """x: (rh,rw) float32 region at (rx, ry) of a frame of size frame_hw (default: the region is the frame); taps_dev: CUDA float32."""
+    lib = L.load()
+    ch, cw = frame_hw or (x.shape[0], x.shape[1])
+    tmp, out = torch.empty_like(x), torch.empty_like(x)
+    L.check(lib.cf_gaussian_blur_f32(L.ptr(x), L.ptr(tmp), L.ptr(out), x.shape[0], x.shape[1], int(region_xy[0]), int(region_xy[1]), ch, cw,
+                                     L.ptr(taps_dev), taps_dev.numel(), L.stream_ptr()), 'cf_gaussian_blur_f32')
+    return out
+
+
+def sum_partials(x, out64):
+    """64 fp64 partial sums of x into out64 (CUDA float64, 64 elements); the caller adds them after its read-back."""
+    lib = L.load()
+    L.check(lib.cf_sum_f32(L.ptr(x), x.numel(), L.ptr(out64, dtype=torch.float64), L.stream_ptr()), 'cf_sum_f32')
+
+
+def paste_blend(canvas, face, inv, ero, soft, region, parse=None):
+    lib = L.load()
+    rx, ry, rw, rh = region
+    L.check(lib.cf_paste_blend(L.ptr(canvas), canvas.shape[0], canvas.shape[1], L.ptr(face, dtype=torch.uint8), face.shape[0], face.shape[1],
+                               _c6(inv), L.ptr(ero), L.ptr(soft), L.ptr(parse), rx, ry, rw, rh, L.stream_ptr()), 'cf_paste_blend')
+
+
+def resize_linear_u8(src, dh, dw):
+    lib = L.load()
+    out = torch.empty(dh, dw, 3, dtype=torch.float32, device=src.device)
+    L.check(lib.cf_resize_linear_u8(L.ptr(src, dtype=torch.uint8), src.shape[0], src.shape[1], L.ptr(out), dh, dw, L.stream_ptr()),
+            'cf_resize_linear_u8')
+    return out
+
+
+def f32_to_u8_trunc(x):
+    lib = L.load()
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    L.check(lib.cf_f32_to_u8_trunc(L.ptr(x), x.numel(), L.ptr(out, dtype=torch.uint8), L.stream_ptr()), 'cf_f32_to_u8_trunc')
+    return out
+
+
+def label_lut(labels, lut):
+    lib = L.load()
+    out = torch.empty(labels.shape, dtype=torch.float32, device=labels.device)
+    arr = (ctypes.c_float * len(lut))(*[float(v) for v in lut])
+    L.check(lib.cf_label_lut_f32(L.ptr(labels, dtype=torch.int64), labels.numel(), arr, len(lut), L.ptr(out), L.stream_ptr()), 'cf_label_lut_f32')
+    return out
+
+
+def scale_clear_border_(x, border, scale):
+    lib = L.load()
+    B, H, W = x.shape
+    L.check(lib.cf_scale_clear_border_f32(L.ptr(x), B, H, W, int(border), float(scale), L.stream_ptr()), 'cf_scale_clear_border_f32')
+    return x

@@ -255,6 +255,40 @@ int cf_upfirdn2d(const float* x, int nplanes, int in_h, int in_w, const float* k
                  int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, float* y,
                  cf_stream_t stream);
 
+/* ---- alignment warp and paste-back of the whole-image / video path ----------------------------------------------------------
+ * Replaces the OpenCV calls of facelib/utils/face_restoration_helper.py: cv2.warpAffine of align_warp_face (:343-344) and of
+ * paste_faces_to_input_image (:400, :428, :479), cv2.erode (:430-431, :447), cv2.GaussianBlur (:449), np.sum (:433), the soft-mask
+ * blend (:485-492), cv2.resize of the background (:380) and the final astype(uint8) (:497).  OpenCV's fixed-point definitions are
+ * followed bit for bit as restated in oracle/paste_oracle.py (OpenCV itself is not available to pin them).  Affine arguments are
+ * the matrices that map DESTINATION pixels to SOURCE coordinates (what warpAffine obtains by inverting its M, in double).
+ * Regions (rx, ry, rw, rh) are windows of the destination frame; *_region buffers are compact [rh][rw] float32 arrays. */
+/* n warps in one launch: dst[i] (u8 [dh][dw][3]) region <- src + i*src_stride (u8 [sh][sw][3]; stride 0 = one source) through
+ * inv_dev[i] (DEVICE array of n x 6 doubles); taps outside the source take (b0, b1, b2) */
+int cf_warp_affine_u8(const uint8_t* src, int64_t src_stride, int sh, int sw, const double* inv_dev, int n, uint8_t* dst, int dh, int dw,
+                      int rx, int ry, int rw, int rh, int b0, int b1, int b2, cf_stream_t stream);
+/* float32 single-channel warp into a compact region buffer (border 0); inv_host: 6 doubles in HOST memory */
+int cf_warp_affine_f32(const float* src, int sh, int sw, const double* inv_host, float* dst_region, int rx, int ry, int rw, int rh,
+                       cf_stream_t stream);
+/* cv2.erode with a k x k rectangle (anchor k/2; k == 0 -> OpenCV's 3x3 default); samples outside the region do not take part */
+int cf_erode_f32(const float* in_region, float* tmp_region, float* out_region, int rh, int rw, int k, cf_stream_t stream);
+/* cv2.GaussianBlur(ksize, 0) with the caller's taps (DEVICE, ksize floats), BORDER_REFLECT_101 at the borders of the ch x cw frame
+ * the region (rx, ry) lies in; frame positions outside the region count as 0 */
+int cf_gaussian_blur_f32(const float* in_region, float* tmp_region, float* out_region, int rh, int rw, int rx, int ry, int ch, int cw,
+                         const float* taps_dev, int ksize, cf_stream_t stream);
+/* 64 fp64 partial sums of x[0..n) in a fixed order (the caller adds them) */
+int cf_sum_f32(const float* x, int64_t n, double* partials64, cf_stream_t stream);
+/* canvas (f32 [ch][cw][3]) region <- m * (ero * warp(face)) + (1 - m) * canvas, m = soft (or min(parse, soft) when parse != NULL) */
+int cf_paste_blend(float* canvas, int ch, int cw, const uint8_t* face, int fh, int fw, const double* inv_host, const float* ero_region,
+                   const float* soft_region, const float* parse_region, int rx, int ry, int rw, int rh, cf_stream_t stream);
+/* cv2.resize(src u8 [sh][sw][3], INTER_LINEAR) -> f32 [dh][dw][3] (a plain widening copy when the sizes are equal) */
+int cf_resize_linear_u8(const uint8_t* src, int sh, int sw, float* dst, int dh, int dw, cf_stream_t stream);
+/* astype(np.uint8) of a float image in [0, 256): truncation */
+int cf_f32_to_u8_trunc(const float* src, int64_t n, uint8_t* dst, cf_stream_t stream);
+/* parse-map colouring out[i] = lut[labels[i]] (face_restoration_helper.py:468-471; lut_host: nlut <= 32 floats in HOST memory) */
+int cf_label_lut_f32(const int64_t* labels, int64_t n, const float* lut_host, int nlut, float* out, cf_stream_t stream);
+/* in place: x * scale inside the frame of `border` pixels, 0 on it (face_restoration_helper.py:476-481), x: [batch][h][w] */
+int cf_scale_clear_border_f32(float* x, int batch, int h, int w, int border, float scale, cf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,3 +73,56 @@ __device__ __forceinline__ float cf_wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+
+// ---- deterministic split-K across workgroups --------------------------------------------------------------------------------------
+// A small-M layer (one face: 16x16 .. 64x64 pixels) has too few output tiles for 256 CUs, and its latency is the serial K loop of
+// one workgroup.  The K range of such a layer is ALWAYS cut into V "virtual chunks" of CF_SK_SLABS slabs; each chunk is accumulated
+// from zero and the chunk sums are added in chunk order starting from zero:   out = ((0 + P0) + P1) + ... + P(V-1).
+// That association is fixed by the layer's shape, so the HOST may give the V chunks of a tile to 1, 2, .. V workgroups (by how many
+// faces are in flight) without changing a single bit of the result:
+//   nsplit == 1: one workgroup walks all chunks and folds each into a second accumulator in registers;
+//   nsplit  > 1: every workgroup parks each of its chunk sums in a workspace (lane-contiguous 16-byte stores) and takes a ticket on the
+//                tile's counter; the one drawing the last ticket adds all V chunk sums in order and runs the normal epilogue.
+// Cross-workgroup visibility follows the agent-scope release / acquire recipe of cdna_hip_programming.md (Guideline 16): plain
+// stores -> every wave drains vmcnt -> barrier -> one lane: release fence, drained, relaxed agent-scope ticket; the last arriver: one
+// acquire fence -> barrier -> plain loads.  The counter is reset by the last arriver, so a zero-initialised counter buffer stays valid
+// launch after launch.   ws layout: [tile][V][NV][nthreads] float4;  flag: one LDS dword inside the kernel's single LDS array.
+constexpr int CF_SK_SLABS = 8;  // 16-channel slabs per virtual chunk (128 K values)
+
+template <int NV>
+__device__ __forceinline__ void cf_splitk_park(const f32x4 (&v)[NV], float* __restrict__ ws, int tile, int vchunk, int V, int nthreads) {
+  f32x4* mine = reinterpret_cast<f32x4*>(ws) + ((size_t)tile * V + vchunk) * NV * nthreads + threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) mine[(size_t)i * nthreads] = v[i];
+}
+
+// returns true in the workgroup that drew the last ticket, with v = the ordered sum of all V chunk sums
+template <int NV>
+__device__ __forceinline__ bool cf_splitk_finish(f32x4 (&v)[NV], const float* __restrict__ ws, unsigned* __restrict__ counters, int tile, int V,
+                                                 int nsplit, int nthreads, volatile float* lds_flag) {
+  const int tid = threadIdx.x;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (restated where the compiler cannot drop it: the ticket must not overtake the write-back)
+    const unsigned ticket = __hip_atomic_fetch_add(counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *reinterpret_cast<volatile unsigned*>(lds_flag) = ticket;
+  }
+  __syncthreads();
+  const bool last = *reinterpret_cast<volatile unsigned*>(lds_flag) == (unsigned)(nsplit - 1);
+  if (!last) return false;
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    counters[tile] = 0;  // nobody else touches this tile's counter any more in this launch
+  }
+  __syncthreads();
+  const f32x4* base = reinterpret_cast<const f32x4*>(ws) + (size_t)tile * V * NV * nthreads + tid;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < V; ++c) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] += base[((size_t)c * NV + i) * nthreads];
+  }
+  return true;
+}

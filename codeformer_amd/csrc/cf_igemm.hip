@@ -79,10 +79,17 @@ __device__ __forceinline__ int cf_border(int i, int n, int mode) {
   }
   return i < 0 ? 0 : (i >= n ? n - 1 : i);  // (also keeps the overhang of masked edge tiles addressable)
 }
-template <bool EXT>
-using ArgsOf = std::conditional_t<EXT, ConvArgsExt, ConvArgs>;
-template <bool EXT>
-__device__ __forceinline__ int ext_ld(const ArgsOf<EXT>& a, int which, int dense) {
+// Split-K instantiations (1x1 / Linear on small token matrices): workspace, ticket counters and the split count ride behind the
+// ConvArgs fields, again in their own struct so the other instantiations keep their kernarg layout.
+struct ConvArgsSK : ConvArgs {
+  float* ws;
+  unsigned* counters;
+  int nsplit;
+};
+template <bool EXT, bool SK = false>
+using ArgsOf = std::conditional_t<SK, ConvArgsSK, std::conditional_t<EXT, ConvArgsExt, ConvArgs>>;
+template <bool EXT, bool SK = false>
+__device__ __forceinline__ int ext_ld(const ArgsOf<EXT, SK>& a, int which, int dense) {
   if constexpr (EXT) return which == 0 ? a.ld0 : (which == 1 ? a.ld1 : a.ldo);
   return dense;
 }
@@ -122,9 +129,13 @@ __device__ __forceinline__ float swishf(float y) { return y * (1.0f / (1.0f + ex
 // F16 = true: as BF16 but IEEE half operands on v_mfma_f32_32x32x16_f16 (3 more mantissa bits, same MFMA rate) -- the operand
 // format of the reference's `half=True` Real-ESRGAN (inference_codeformer.py:23-27,44) and of CodeFormer's precision='fp16';
 // fp32 accumulation and fp32 tensors in HBM.
-template <int TAPS, int STRIDE, int WM, int WN, int MI, int NI, bool IN_NCHW, bool BF16 = false, bool EXT = false, bool F16 = false>
-__global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const ArgsOf<EXT> a) {
+// SK = true (1x1 / Linear only): `nsplit` workgroups share an output tile, each contracting a contiguous range of K slabs; the partial
+// accumulators meet in a workspace and the last arriver adds them in split order (cf_splitk_combine) before the usual epilogue.
+template <int TAPS, int STRIDE, int WM, int WN, int MI, int NI, bool IN_NCHW, bool BF16 = false, bool EXT = false, bool F16 = false,
+          bool SK = false>
+__global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const ArgsOf<EXT, SK> a) {
   using C = Cfg<TAPS, STRIDE, WM, WN, MI, NI>;
+  static_assert(!SK || (TAPS == 1 && !EXT && !BF16 && !F16), "split-K: 1x1 / Linear fp32 instantiations");
   constexpr bool LP = BF16 || F16;  // 16-bit MFMA operands
   static_assert(!LP || (TAPS > 1 && STRIDE == 1 && !IN_NCHW), "16-bit operand path: 3x3 stride 1 NHWC only");
   static_assert(!(BF16 && F16), "one operand format");
@@ -152,6 +163,12 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Arg
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
   }
 #endif
+  [[maybe_unused]] int split = 0, sk_tile = 0;
+  if constexpr (SK) {
+    split = bid % a.nsplit;  // the splits of one tile are neighbours in the tile order
+    bid /= a.nsplit;
+    sk_tile = bid;
+  }
   const int nt = bid % a.ntn;
   const int mt = bid / a.ntn;
   const int n0 = nt * C::BN;
@@ -538,17 +555,29 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Arg
           for (int ni = 0; ni < NI; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
     };
-    const int n = a.nchunks;
+    int n = a.nchunks, kb = 0;  // this workgroup's K slabs: [kb, kb + n)
+    [[maybe_unused]] f32x16 tot[MI][NI];  // SK: ordered sum of the finished virtual chunks (nsplit == 1)
+    if constexpr (SK) {
+      const int per = (a.nchunks / CF_SK_SLABS / a.nsplit) * CF_SK_SLABS;  // slabs of this workgroup: whole virtual chunks (host-checked)
+      kb = split * per;
+      n = per;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) tot[mi][ni][r] = 0.f;
+    }
     {
       f32x4 ra1[C::APT * AV];
       f32x4 rb1[C::BPT];
-      load_A(0, ra);
-      load_B(0, rb);
-      load_A(1 < n ? 1 : 0, ra1);
-      load_B(1 < n ? 1 : 0, rb1);
-      store_A(0, ra, 0);
+      load_A(kb, ra);
+      load_B(kb, rb);
+      load_A(kb + (1 < n ? 1 : 0), ra1);
+      load_B(kb + (1 < n ? 1 : 0), rb1);
+      store_A(0, ra, kb);
       store_B(0, rb);
-      store_A(1, ra1, 1 < n ? 1 : 0);
+      store_A(1, ra1, kb + (1 < n ? 1 : 0));
       store_B(1, rb1);
     }
     __syncthreads();
@@ -558,7 +587,7 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Arg
     for (int chunk = 0; chunk < n; ++chunk) {
       const int slot1 = slot == 2 ? 0 : slot + 1;
       const int slot2 = slot1 == 2 ? 0 : slot1 + 1;
-      const int nxt = chunk + 2 < n ? chunk + 2 : n - 1;  // clamped: the tail prefetches are harmless re-reads
+      const int nxt = kb + (chunk + 2 < n ? chunk + 2 : n - 1);  // clamped: the tail prefetches are harmless re-reads
       constexpr int NM = MI * NI * 4;
       constexpr bool WEAVE = CF_INTERLEAVE && NM >= MI + NI + C::BPT + C::APT * AV;
       load_B(nxt, rb);
@@ -595,10 +624,61 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Arg
       __builtin_amdgcn_sched_barrier(0);
       store_A(slot2, ra, nxt);
       store_B(slot2, rb);
+      if constexpr (SK) {
+        if ((chunk + 1) % CF_SK_SLABS == 0) {  // a virtual chunk is complete: fold it (one workgroup per tile) or park it (split)
+          if (a.nsplit == 1) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < NI; ++ni) {
+                tot[mi][ni] += acc[mi][ni];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+              }
+          } else {
+            f32x4 v[MI * NI * 4];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  v[(mi * NI + ni) * 4 + q] = f32x4{acc[mi][ni][q * 4], acc[mi][ni][q * 4 + 1], acc[mi][ni][q * 4 + 2], acc[mi][ni][q * 4 + 3]};
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) acc[mi][ni][q * 4 + e] = 0.f;
+                }
+            cf_splitk_park(v, a.ws, sk_tile, (kb + chunk) / CF_SK_SLABS, a.nchunks / CF_SK_SLABS, 256);
+          }
+        }
+      }
       __syncthreads();
       slot = slot1;
     }
     // (the loop's closing barrier retired every LDS read before any wave reuses LDS in its epilogue)
+    if constexpr (SK) {
+      if (a.nsplit == 1) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = tot[mi][ni];
+      }
+    }
+  }
+
+  if constexpr (SK) {
+    if (a.nsplit > 1) {
+      f32x4 v[MI * NI * 4];
+      if (!cf_splitk_finish(v, a.ws, a.counters, sk_tile, a.nchunks / CF_SK_SLABS, a.nsplit, 256, smem)) return;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[mi][ni][q * 4 + e] = v[(mi * NI + ni) * 4 + q][e];
+      __syncthreads();  // the flag word lives in the LDS region the epilogue stages through
+    }
   }
 
   // ---- epilogue ------------------------------------------------------------------------------------------
@@ -635,7 +715,7 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Arg
           pixel = ((size_t)b * a.hout + (y0 + (row >> 4))) * a.wout + (x0 + (row & 15));
         else
           pixel = (size_t)m0 + row;
-        offs[p] = pixel * ext_ld<EXT>(a, 2, a.cout) + n;
+        offs[p] = pixel * ext_ld<EXT, SK>(a, 2, a.cout) + n;
         if constexpr (EXT) {
           const int oy = TAPS == 4 ? 2 * (y0 + (row >> 4)) + sub_y : y0 + (row >> 4);
           const int ox = TAPS == 4 ? 2 * (x0 + (row & 15)) + sub_x : x0 + (row & 15);
@@ -978,6 +1058,46 @@ int launch(const ConvArgsExt& a, hipStream_t stream, int* parts_query) {
   return CF_OK;
 }
 
+// 1x1 / Linear with split-K (small token matrices): 64x64 tiles, `nsplit` workgroups per tile.
+template <int WM, int WN, int MI, int NI>
+int launch_sk(const ConvArgsExt& a, float* ws, unsigned* counters, int nsplit, hipStream_t stream, int* parts_query) {
+  using C = Cfg<1, 1, WM, WN, MI, NI>;
+  ConvArgsSK k;
+  static_cast<ConvArgs&>(k) = a;
+  const long m = (long)a.batch * a.hout * a.wout;
+  if (m % C::BM != 0 || (a.hout * a.wout) % C::BM != 0) {
+    cf_set_error("cf_conv2d: 1x1 rows %ld (per image %d) not divisible by %d", m, a.hout * a.wout, C::BM);
+    return CF_ERR_ARG;
+  }
+  const int mtiles = (int)(m / C::BM);
+  k.tiles_x = k.tiles_per_img = 0;
+  k.nparts = (mtiles / a.batch) * WM;
+  if (parts_query) {
+    *parts_query = k.nparts;
+    return CF_OK;
+  }
+  k.ntn = a.cout_pad / C::BN;
+  k.ws = ws;
+  k.counters = counters;
+  k.nsplit = nsplit;
+  auto kern = igemm_kernel<1, 1, WM, WN, MI, NI, false, false, false, false, true>;
+  constexpr size_t lds = C::LDS_FLOATS * sizeof(float);
+  static unsigned long long attr_devs = 0;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 64 || !((attr_devs >> dev) & 1ull)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      cf_set_error("cf_conv2d: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+      return CF_ERR_LAUNCH;
+    }
+    if (dev < 64) attr_devs |= 1ull << dev;
+  }
+  hipLaunchKernelGGL(kern, dim3(mtiles * k.ntn * nsplit), dim3(256), lds, stream, k);
+  CF_CHECK_LAUNCH("cf_conv2d(split-K)");
+  return CF_OK;
+}
+
 // Value of packed slab entry (slab, n, c).  slab < 9 (or 1): the plain tap.  Folded nearest-x2 + 3x3 (fold != 0): slab =
 // class*4 + tap2 with class = (oy&1)*2 + (ox&1), tap2 = ty*2 + tx over the 2x2 source footprint; the entry is the SUM of the
 // 3x3 taps that land on that source pixel: parity 0 -> {k=0} , {k=1,2} ; parity 1 -> {k=0,1} , {k=2} (per axis), summed
@@ -1290,6 +1410,13 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
     if (cp % 128 == 0) return launch<9, 2, 2, 2, 2, 2, false>(a, stream, pq);
     if (cp == 64) return launch<9, 2, 2, 2, 2, 1, false>(a, stream, pq);
   } else {
+    if (d->split_k >= 1) {  // small token matrices: 64x64 tiles, split_k workgroups per tile
+      const int V = a.nchunks / CF_SK_SLABS;  // virtual chunks: the summation order is out = ((0 + P0) + P1) + ... whatever split_k is
+      CF_REQUIRE(cp % 64 == 0 && a.nchunks % CF_SK_SLABS == 0 && V >= 1 && V % d->split_k == 0,
+                 "cf_conv2d: split_k %d needs cout_pad %% 64 == 0, K %% 128 == 0 and split_k dividing K/128 = %d", d->split_k, V);
+      CF_REQUIRE(pq || d->split_k == 1 || (d->workspace && d->counters), "cf_conv2d: split_k > 1 needs workspace and counters");
+      return launch_sk<2, 2, 1, 1>(a, d->workspace, d->counters, d->split_k, stream, pq);
+    }
     if (narrow) return launch<1, 1, 2, 2, 2, 1, false>(a, stream, pq);
     if (cp % 128 == 0) return launch<1, 1, 2, 2, 2, 2, false>(a, stream, pq);
     if (cp == 64) return launch<1, 1, 4, 1, 2, 2, false>(a, stream, pq);
@@ -1299,6 +1426,35 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
 }
 
 extern "C" int cf_conv2d(const cf_conv_desc* d, cf_stream_t stream) { return conv_dispatch(d, (hipStream_t)stream, nullptr); }
+
+// split-K geometry: output tiles of the launch and accumulator bytes one (tile, split) parks in the workspace
+int cf_winograd_splitk_geometry(const cf_conv_desc* d, int* tiles, long* bytes_per_part);  // cf_winograd.hip
+int cf_split_splitk_geometry(const cf_conv_desc* d, int* tiles, long* bytes_per_part);     // cf_split.hip
+static int splitk_geometry(const cf_conv_desc* d, int* tiles, long* bytes_per_part) {
+  *tiles = 0;
+  *bytes_per_part = 0;
+  if (!d || d->split_k < 1) return CF_OK;
+  if (d->bf16_mfma == CF_OPERAND_F16X2) return cf_split_splitk_geometry(d, tiles, bytes_per_part);
+  if (d->winograd) return cf_winograd_splitk_geometry(d, tiles, bytes_per_part);
+  CF_REQUIRE(d->taps == 1 && d->cout_pad % 64 == 0 && ((long)d->batch * d->hout * d->wout) % 64 == 0,
+             "cf_conv2d: split_k covers 1x1 / Linear (64x64 tiles), winograd and f16x2 launches");
+  *tiles = (int)((long)d->batch * d->hout * d->wout / 64) * (d->cout_pad / 64);
+  *bytes_per_part = 64L * 64 * 4 * ((d->c0 + d->c1) / (16 * CF_SK_SLABS)) / (d->split_k > 0 ? d->split_k : 1);  // V chunk sums per tile in all
+  return CF_OK;
+}
+extern "C" int64_t cf_conv2d_workspace_bytes(const cf_conv_desc* d) {
+  int tiles = 0;
+  long per = 0;
+  const int rc = splitk_geometry(d, &tiles, &per);
+  if (rc != CF_OK) return rc;
+  return d && d->split_k > 1 ? (int64_t)tiles * d->split_k * per : 0;
+}
+extern "C" int cf_conv2d_tiles(const cf_conv_desc* d) {
+  int tiles = 0;
+  long per = 0;
+  const int rc = splitk_geometry(d, &tiles, &per);
+  return rc != CF_OK ? rc : tiles;
+}
 
 extern "C" int cf_conv2d_stats_parts(const cf_conv_desc* d) {
   int parts = 0;

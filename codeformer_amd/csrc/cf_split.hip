@@ -717,3 +717,11 @@ int cf_split_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query)
   if (d->upsample) return wide ? split_launch<4, 2>(a, d->batch, stream) : split_launch<4, 1>(a, d->batch, stream);
   return wide ? split_launch<9, 2>(a, d->batch, stream) : split_launch<9, 1>(a, d->batch, stream);
 }
+
+int cf_split_splitk_geometry(const cf_conv_desc* d, int* tiles, long* bytes_per_part) {
+  (void)d;
+  *tiles = 0;
+  *bytes_per_part = 0;
+  cf_set_error("cf_conv2d: split_k is not available for this kernel");
+  return CF_ERR_ARG;
+}

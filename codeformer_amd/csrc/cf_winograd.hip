@@ -501,3 +501,11 @@ int cf_winograd_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_que
   CF_CHECK_LAUNCH("cf_conv2d(winograd)");
   return CF_OK;
 }
+
+int cf_winograd_splitk_geometry(const cf_conv_desc* d, int* tiles, long* bytes_per_part) {
+  (void)d;
+  *tiles = 0;
+  *bytes_per_part = 0;
+  cf_set_error("cf_conv2d: split_k is not available for this kernel");
+  return CF_ERR_ARG;
+}

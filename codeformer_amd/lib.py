@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('CF_LIB_PATH') or os.path.join(_PKG, 'libcodeformer_hi
 
 c_float_p = ctypes.c_void_p  # device pointers are passed as integers
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 PRO_NONE, PRO_AFFINE, PRO_AFFINE_SWISH, PRO_LEAKY = 0, 1, 2, 3
 EPI_NONE, EPI_RESIDUAL, EPI_SFT, EPI_GELU, EPI_LEAKY, EPI_AXPY, EPI_AXPY2 = 0, 1, 2, 3, 4, 5, 6
 PAD_ZERO, PAD_REFLECT, PAD_EDGE = 0, 1, 2
@@ -40,6 +40,7 @@ class ConvDesc(ctypes.Structure):
         ('ld_in0', ctypes.c_int32), ('ld_in1', ctypes.c_int32), ('ld_out', ctypes.c_int32),
         ('pad_mode', ctypes.c_int32), ('pad_lo', ctypes.c_int32), ('winograd', ctypes.c_int32),
         ('acc_scale', ctypes.c_float),
+        ('split_k', ctypes.c_int32), ('workspace', ctypes.c_void_p), ('counters', ctypes.c_void_p),
     ]
 
 
@@ -52,6 +53,8 @@ SIGNATURES = {
     'cf_device_cu_count': (_I, []),
     'cf_conv2d': (_I, [ctypes.POINTER(ConvDesc), _P]),
     'cf_conv2d_stats_parts': (_I, [ctypes.POINTER(ConvDesc)]),
+    'cf_conv2d_workspace_bytes': (_L, [ctypes.POINTER(ConvDesc)]),
+    'cf_conv2d_tiles': (_I, [ctypes.POINTER(ConvDesc)]),
     'cf_pack_conv_weight': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     'cf_packed_weight_elems': (_L, [_I, _I, _I]),
     'cf_pack_conv_weight_bf16': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),

@@ -6,6 +6,7 @@ libcodeformer_hip.so.  Nothing here has a CPU/eager fallback.
 """
 import ctypes
 import math
+import os
 
 import torch
 
@@ -168,9 +169,38 @@ def _nhwc_ld(t, what):
     return ld
 
 
+# Split-K (cf_conv_desc.split_k) for 1x1 / Linear layers on small token images: WHETHER a layer takes the split-K kernel (64x64
+# tiles, K cut into virtual chunks of 128 added in a fixed order) depends on its per-image shape only, so a face's bits are the same
+# alone and inside any batch; HOW MANY workgroups then share a tile's chunks is chosen from the number of tiles in flight and does
+# not change the result (see cf_common.h).  CODEFORMER_HIP_SPLITK = largest split count (0: layers keep the large-tile kernel).
+SPLITK_MAX = int(os.environ.get('CODEFORMER_HIP_SPLITK', '8'))
+_COUNTERS = {}
+
+
+def splitk_for(pw, ho, wo, cin, batch=1):
+    """Split count for a 1x1 / Linear on `batch` (ho x wo)-token images; 0: the layer is not a split-K layer."""
+    if SPLITK_MAX <= 0 or pw.taps != 1 or pw.bf16 or ho * wo > 1024 or (ho * wo) % 64 or pw.cout_pad % 64 or cin % 128:
+        return 0
+    tiles = batch * (ho * wo // 64) * (pw.cout_pad // 64)
+    v = cin // 128
+    for ns in (8, 4, 2):
+        if ns <= SPLITK_MAX and v % ns == 0 and tiles * ns <= 512:
+            return ns
+    return 1
+
+
+def _counters(device, n):
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    t = _COUNTERS.get(key)
+    if t is None or t.numel() < n:
+        t = torch.zeros(max(n, 4096), dtype=torch.int32, device=device)   # every split-K launch leaves its counters at zero again
+        _COUNTERS[key] = t
+    return t
+
+
 def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale=None, shift=None,
            epilogue=EPI_NONE, res=None, sft_scale=None, sft_w=0.0, in_nchw=False, out_nchw=False, emit_stats=False,
-           out=None, pad_mode=PAD_ZERO, pad_lo=0):
+           out=None, pad_mode=PAD_ZERO, pad_lo=0, split_k=None):
     """Implicit-GEMM conv (3x3 / 1x1).  x: (B,H,W,C0) [x2: (B,H,W,C1) concatenated after x]; returns (B,Ho,Wo,cout)
     (or (B,cout,Ho,Wo) when out_nchw).  With in_nchw, x is (B,C<=4,H,W).
     emit_stats: also write the GroupNorm(32) partial statistics of the output in the epilogue and attach them to the
@@ -232,6 +262,17 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
         sft_scale=L.ptr(sft_scale, True), sft_w=float(sft_w), out=L.ptr(out, not out_nchw), bf16_mfma=int(pw.bf16),
         ld_in0=ld0, ld_in1=ld1, ld_out=ldo, pad_mode=int(pad_mode), pad_lo=int(pad_lo), winograd=int(pw.wino),
         acc_scale=1.0 / pw.scale)
+    if split_k is None:
+        dense = not in_nchw and not out_nchw and ld0 == c0 and (c1 == 0 or ld1 == c1) and ldo in (0, pw.cout)
+        split_k = splitk_for(pw, Ho, Wo, c0 + c1, B) if (stride == 1 and dense) else 0
+    if split_k:
+        d.split_k = int(split_k)
+        if split_k > 1:
+            nbytes, tiles = lib.cf_conv2d_workspace_bytes(ctypes.byref(d)), lib.cf_conv2d_tiles(ctypes.byref(d))
+            if nbytes < 0 or tiles <= 0:
+                raise RuntimeError(f'cf_conv2d_workspace_bytes failed: {L.last_error()}')
+            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+            d.workspace, d.counters = L.ptr(ws), L.ptr(_counters(x.device, tiles), dtype=torch.int32)
     if emit_stats and not out_nchw and pw.cout % GN_GROUPS == 0 and pw.cout // GN_GROUPS >= 2:
         d.stats_cpg = pw.cout // GN_GROUPS
         parts = lib.cf_conv2d_stats_parts(ctypes.byref(d))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 9
+#define CF_ABI_VERSION 10
 
 typedef void* cf_stream_t; /* hipStream_t */
 
@@ -145,11 +145,23 @@ typedef struct cf_conv_desc {
                              is below the direct kernel's, so the host uses it for every eligible 3x3 stride-1 convolution */
   float acc_scale;        /* CF_OPERAND_F16X2 only: the accumulator is multiplied by this before the bias is added -- the exact
                              inverse of the power-of-two scale given to cf_pack_conv_weight_f16x2 (> 0) */
+  /* Deterministic split-K for layers with few output tiles (one face: 16x16 .. 64x64 pixels), where latency is the serial K loop of
+   * a workgroup: split_k workgroups share an output tile, each contracting a contiguous K range; partial accumulators meet in
+   * `workspace`, the workgroup drawing the last ticket on counters[tile] adds them in split order (bitwise reproducible, independent of
+   * arrival order) and runs the epilogue.  0 = off.  Supported: taps == 1 (64x64 tiles; also selects them with split_k == 1),
+   * winograd, CF_OPERAND_F16X2.  workspace: cf_conv2d_workspace_bytes(d) bytes; counters: one zero-initialised uint32 per output
+   * tile (cf_conv2d_tiles(d)), left at zero by every launch. */
+  int32_t split_k;
+  float* workspace;
+  uint32_t* counters;
 } cf_conv_desc;
 
 int cf_conv2d(const cf_conv_desc* d, cf_stream_t stream);
 /* number of statistics partials per (image, group) the launch described by d will write (>0), or <0 on error */
 int cf_conv2d_stats_parts(const cf_conv_desc* d);
+/* split-K launches: bytes of workspace / number of output tiles (= counters) the launch described by d needs (0 when split_k <= 1) */
+int64_t cf_conv2d_workspace_bytes(const cf_conv_desc* d);
+int cf_conv2d_tiles(const cf_conv_desc* d);
 
 /* Pack a PyTorch conv/linear weight [cout][cin][kh*kw] (taps = 1 or 9) into the kernel layout
  * [tap][cin_pad/16][cout_pad][16] (zero padded). */

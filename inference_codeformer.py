@@ -58,6 +58,8 @@ def parse_args(argv=None):
     p.add_argument('--random_init_seed', type=int, default=None,
                    help='Use torch.manual_seed(SEED) random weights when weights/CodeFormer/codeformer.pth is absent '
                         '(plumbing runs on boxes without the checkpoint)')
+    p.add_argument('--affine_npz', type=str, default=None,
+                   help='whole-image inputs: .npz mapping image basename -> (k,2,3) alignment matrices from the host face detector')
     p.add_argument('--io_workers', type=int, default=None, help='PNG decode / encode worker threads of the GPU pipeline')
     p.add_argument('--strict', action='store_true', help='Raise on inference errors instead of returning the input face')
     return p.parse_args(argv)
@@ -80,6 +82,49 @@ def set_realesrgan(args, device, random_init_seed=None):
         print('WARNING: RealESRGAN_x2plus.pth not found -- using random weights for the (unused) upsampler')
         return RealESRGANer(scale=2, model_path=None, model=model, tile=args.bg_tile, tile_pad=40, pre_pad=0,
                             half=device.type == 'cuda', device=device)
+
+
+def restore_whole_images(args, input_img_list, result_root, w):
+    """Whole images / extracted video frames with the host detector's output supplied as a file: --affine_npz maps each image's
+    basename (without extension) to its (k, 2, 3) frame -> 512-face matrices (FaceRestoreHelper.affine_matrices after
+    align_warp_face, face_restoration_helper.py:329-330).  Crops are cut, restored in 16-face batches ACROSS images and pasted back on
+    the device (codeformer_amd.video); the pasted images land in <result_root>/final_results/ like the reference's."""
+    device = torch.device(args.device) if args.device else get_device()
+    if device.type != 'cuda':
+        raise NotImplementedError('the whole-image path runs on a ROCm device (alignment warp and paste-back are HIP kernels)')
+    from codeformer_amd.video import VideoRestorer, frame_shard
+    table = np.load(args.affine_npz)
+    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    if world > 1:
+        from codeformer_amd import parallel
+        _, _, device = parallel.init_distributed(device=device)
+    mine = [input_img_list[i] for i in frame_shard(len(input_img_list), rank, world)]       # frames are the unit of sharding
+    net = build_net(device, args)
+    bg = None
+    if args.bg_upsampler == 'realesrgan':
+        ups = set_realesrgan(args, device, args.random_init_seed)
+        if ups is not None:
+            def bg(frame):
+                img = ups.enhance(frame, outscale=args.upscale)[0]
+                return resize_bilinear(img, (frame.shape[1] * args.upscale, frame.shape[0] * args.upscale))
+    frames, affs, names = [], [], []
+    for p in mine:
+        name = os.path.splitext(os.path.basename(p))[0]
+        frames.append(imread_bgr(p))
+        a = np.asarray(table[name], dtype=np.float64).reshape(-1, 2, 3) if name in table.files else np.zeros((0, 2, 3))
+        if args.only_center_face and a.shape[0] > 1:
+            a = a[:1]
+        affs.append(a)
+        names.append(name)
+        print(f'[{len(names)}/{len(mine)}] Processing: {os.path.basename(p)}\n\tdetect {a.shape[0]} faces')
+    vr = VideoRestorer(net, device, upscale=args.upscale, batch_size=args.batch_size or 16, bg_upsampler=bg)
+    outs = vr.restore(frames, affs, w=w)
+    for name, img in zip(names, outs):
+        out_name = name if args.suffix is None else f'{name}_{args.suffix}'
+        imwrite(img, os.path.join(result_root, 'final_results', f'{out_name}.png'))
+    print(f"{vr.stats['faces']} faces of {vr.stats['frames']} images in {vr.stats['forward_calls']} forward calls")
+    print(f'\nAll results are saved in {result_root}')
+    return 0
 
 
 def collect_inputs(args):
@@ -122,8 +167,12 @@ def main(argv=None):
         raise FileNotFoundError('No input image/video is found...\n'
                                 '\tNote that --input_path for video should end with .mp4|.mov|.avi')
     if not args.has_aligned:
-        raise NotImplementedError('whole-image inputs need face detection / alignment / paste-back (the reference keeps '
-                                  'these on the host in facelib); pass aligned 512x512 crops with --has_aligned')
+        if args.affine_npz is None:
+            raise NotImplementedError('whole-image inputs need face detection (RetinaFace + landmark alignment), which the reference '
+                                      'keeps on the host in facelib and this package does not rebuild: pass aligned 512x512 crops with '
+                                      '--has_aligned, or run the host detector once and hand its alignment matrices over with '
+                                      '--affine_npz (crop warp, restoration and paste-back then run on the GPU)')
+        return restore_whole_images(args, input_img_list, result_root, w)
     # The reference builds the Real-ESRGAN upsampler for these flags (inference_codeformer.py:112-124) but only ever USES it in the
     # paste-back of whole images (:217-229): on the --has_aligned path it never runs.  Same here: build it when its checkpoint is
     # present (weights/realesrgan/RealESRGAN_x2plus.pth), say so when it is not.

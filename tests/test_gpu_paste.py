@@ -151,3 +151,26 @@ def test_video_fanout_batches_faces_across_frames(env):
         crops = [P.align_warp_face(frames[i], a) for a in affs[i]]
         want = P.paste_faces(frames[i], [255 - c for c in crops], list(affs[i]), upscale=1)
         assert np.array_equal(out[i], want), i
+
+
+def test_entrypoint_whole_images_with_host_affines(env, tmp_path):
+    """inference_codeformer.py without --has_aligned: the host detector's alignment matrices come in through --affine_npz, crop
+    warp / restoration / paste-back run on the GPU, final_results/<name>.png is written at the upscaled size."""
+    import subprocess
+    import sys
+    from PIL import Image
+    torch, ops, P = env
+    src = tmp_path / 'whole_imgs'
+    os.makedirs(src)
+    table = {}
+    for i in range(2):
+        Image.fromarray(_img(240, 320, 70 + i)[:, :, ::-1]).save(src / f'im{i}.png')
+        table[f'im{i}'] = np.stack([_affine(P, 120 + 60 * i, 110, 100, 0.1 * i)])
+    np.savez(tmp_path / 'aff.npz', **table)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'inference_codeformer.py'), '-i', str(src), '-o', str(tmp_path / 'o'), '-s', '2',
+                        '--device', 'cuda', '--random_init_seed', '0', '--affine_npz', str(tmp_path / 'aff.npz')],
+                       capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert sorted(os.listdir(tmp_path / 'o' / 'final_results')) == ['im0.png', 'im1.png']
+    out = np.asarray(Image.open(tmp_path / 'o' / 'final_results' / 'im0.png'))
+    assert out.shape == (480, 640, 3) and '2 faces of 2 images in 1 forward calls' in r.stdout

@@ -73,3 +73,36 @@ def test_split_conv_refusals_and_overflow_is_loud(sc):
     assert ops.conv_code(ops.SPLIT, 128, 128, 256, 256) == ops.SPLIT and ops.conv_code(ops.SPLIT, 512, 512, 16, 16) == ops.WINOGRAD
     assert ops.conv_code(ops.SPLIT_DIRECT, 512, 512, 16, 16) == 0 and ops.conv_code(ops.SPLIT, 48, 64, 64, 64) == ops.WINOGRAD
     assert ops.conv_code(ops.SPLIT, 512, 512, 16, 16, up2x=True) == 0 and ops.conv_code(ops.SPLIT, 128, 128, 256, 256, up2x=True) == ops.SPLIT
+
+
+def test_splitk_gemm_bits_do_not_depend_on_the_split_count(sc):
+    """1x1 / Linear on small token images (cf_conv_desc.split_k): K is always cut into virtual chunks of 128 added in a fixed order,
+    so the result is bitwise the same whether 1, 2, 4 or 8 workgroups share a tile -- and equals the fp64 product to fp32 accuracy."""
+    import torch
+    from codeformer_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for (M, K, N, epi) in ((256, 512, 512, ops.EPI_RESIDUAL), (512, 1024, 512, ops.EPI_GELU), (256, 512, 1536, ops.EPI_NONE), (1024, 256, 128, ops.EPI_NONE)):
+        x = torch.randn(M, K, generator=g).cuda()
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+        b = torch.randn(N, generator=g).cuda()
+        res = torch.randn(M, N, generator=g).cuda()
+        pw = ops.pack_weight(w, b)
+        outs = []
+        v = K // 128
+        for ns in [n for n in (1, 2, 4, 8) if v % n == 0]:
+            y = ops.conv2d(x.view(M // 256, 16, 16, K), pw, epilogue=epi, res=res.view(M // 256, 16, 16, N) if epi == ops.EPI_RESIDUAL else None,
+                           split_k=ns, emit_stats=epi == ops.EPI_RESIDUAL)
+            outs.append(y.view(M, N))
+            again = ops.conv2d(x.view(M // 256, 16, 16, K), pw, epilogue=epi, res=res.view(M // 256, 16, 16, N) if epi == ops.EPI_RESIDUAL else None,
+                               split_k=ns)
+            assert torch.equal(again.view(M, N), outs[-1])
+        assert all(torch.equal(o, outs[0]) for o in outs[1:]), (M, K, N)
+        ref = x.double() @ w.double().t() + b.double()
+        if epi == ops.EPI_RESIDUAL:
+            ref = ref + res.double()
+        elif epi == ops.EPI_GELU:
+            ref = torch.nn.functional.gelu(ref)
+        assert float((outs[0].double() - ref).abs().max()) <= 2e-5 + 1e-5 * float(ref.abs().max())
+    # policy: eligibility by per-image shape; the count by what is in flight
+    pw = ops.pack_weight(torch.zeros(512, 512, device='cuda'))
+    assert ops.splitk_for(pw, 16, 16, 512, 1) == 4 and ops.splitk_for(pw, 16, 16, 512, 16) == 1 and ops.splitk_for(pw, 64, 64, 512, 1) == 0

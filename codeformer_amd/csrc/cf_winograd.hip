@@ -82,6 +82,12 @@ struct WinoArgs {
   int stats_cpg, nparts;
   int tiles_x, tiles_per_img, ntn;
 };
+// split-K instantiation (layers of at most 32x32 pixels per face, see cf_common.h): workspace, ticket counters, split count
+struct WinoArgsSK : WinoArgs {
+  float* ws;
+  unsigned* counters;
+  int nsplit;
+};
 
 __device__ __forceinline__ f32x4 v4add(f32x4 a, f32x4 b) { return a + b; }
 __device__ __forceinline__ f32x4 v4sub(f32x4 a, f32x4 b) { return a - b; }
@@ -90,7 +96,14 @@ __device__ __forceinline__ f32x4 v4sub(f32x4 a, f32x4 b) { return a - b; }
 // shipped (git history): a "ping-pong" pair of groups per workgroup running two barrier slots apart so that every SIMD always has
 // one MFMA wave and one VALU / LDS wave (1.90 ms against 1.58 ms on 128->128 @256x256x16 -- the two streams do not co-execute,
 // SQ_VALU_MFMA_COEXEC_CYCLES = 0), and an eight-wave workgroup owning 128 channels (1.65 ms).
-__global__ __launch_bounds__(256, 2) void winograd_kernel(const WinoArgs a) {
+// SK = true: the K range is cut into virtual chunks of CF_SK_SLABS slabs.  At the end of every chunk the accumulators are taken to the
+// OUTPUT domain (the first half of the epilogue: nu axis in registers, xi axis through LDS -- 32 values per thread instead of 128) and
+// the chunk sums are added in chunk order, either in registers (one workgroup per patch) or -- `nsplit` workgroups sharing a patch --
+// through the workspace by the workgroup that draws the last ticket (cf_splitk_park / cf_splitk_finish): the same bits for every nsplit.
+// The running sum lives in LDS (32 KB behind the V buffer), not in registers: next to the 128 Winograd-domain accumulators a second
+// register accumulator spilled into the main loop (+36 %).
+template <bool SK>
+__global__ __launch_bounds__(256, 2) void winograd_kernel(const std::conditional_t<SK, WinoArgsSK, WinoArgs> a) {
   constexpr int NI = WG_NI;
   constexpr int GT = 256;                                        // threads
   constexpr int APT = (WG_NPIX * 4 + GT - 1) / GT;               // float4 gather items per thread (3)
@@ -111,6 +124,12 @@ __global__ __launch_bounds__(256, 2) void winograd_kernel(const WinoArgs a) {
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
   }
+  [[maybe_unused]] int split = 0, sk_tile = 0;
+  if constexpr (SK) {
+    split = bid % a.nsplit;
+    bid /= a.nsplit;
+    sk_tile = bid;
+  }
   const int nt = bid % a.ntn;
   const int mt = bid / a.ntn;  // this workgroup's output patch
   const int n0 = nt * WG_BN;
@@ -119,7 +138,11 @@ __global__ __launch_bounds__(256, 2) void winograd_kernel(const WinoArgs a) {
   const int tyw = rt / a.tiles_x;
   const int y0 = tyw * WG_TH;
   const int x0 = (rt - tyw * a.tiles_x) * WG_TW;
-  const int n = a.nchunks;
+  int n = a.nchunks, kb = 0;  // this workgroup's K slabs: [kb, kb + n)
+  if constexpr (SK) {
+    n = (a.nchunks / CF_SK_SLABS / a.nsplit) * CF_SK_SLABS;  // whole virtual chunks (host-checked)
+    kb = split * n;
+  }
 
   // ---- gather geometry: item j of this thread is float4 #k4 of halo pixel p = (gtid>>2) + 64*j ----
   const int k4 = gtid & 3;
@@ -233,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void winograd_kernel(const WinoArgs a) {
   // this lane's B fragments.  The packed weights are stored in MFMA-operand order,
   //   U[pos = xi*4 + nu][chunk][n tile of 32][kg][lane][4]  (element = U[n = tile*32 + (lane & 31)][k = kg*8 + (lane >> 5)*4 + e]),
   // so every fragment load of a wave is one contiguous 1 KB block; they go global/L2 -> registers (each is used by one wave).
-  const size_t pos_stride = (size_t)n * a.cout_pad * CF_BK;
+  const size_t pos_stride = (size_t)a.nchunks * a.cout_pad * CF_BK;
   const float* const wlane = a.weight + (size_t)(xi * 4) * pos_stride + (size_t)(n0 / 32) * 512 + lane * 4;
   const float* const alane = V + (xi * 4) * WG_PS + l31 * CF_LDK + half * 4;
   f32x4 bq[4][NI][2];
@@ -257,9 +280,45 @@ __global__ __launch_bounds__(256, 2) void winograd_kernel(const WinoArgs a) {
           acc[nu][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[kg][j], bq[nu][ni][kg][j], acc[nu][ni], 0, 0, 0);
   };
 
+  // ---- to the output domain: NI passes of 32 channels.  Every wave contracts its nu axis in registers and stages R[xi][bb] in the
+  // (idle) V buffer; then item = (tile, output column bb, channel quad) contracts xi and owns two output pixels (rows aa = 0, 1):
+  // o[it * 2 + aa] for the thread's two items.  Both barriers are inside, the leading one retires every wave's reads of V.
+  float* const R = V;  // [(xi*2 + bb)][tile][WG_RLD]
+  const int e_n4 = gtid & 7;  // (the item stride is a multiple of 8: both items of a thread have the same channel quad)
+  auto to_output = [&](int pass, f32x4(&o)[4]) __attribute__((always_inline)) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float m0 = acc[0][pass][r], m1 = acc[1][pass][r], m2 = acc[2][pass][r], m3 = acc[3][pass][r];
+      const int row = cf_acc_row(r, lane);
+      R[((xi * 2 + 0) * WG_NT + row) * WG_RLD + l31] = (m0 + m1) + m2;  // nu axis: R[xi][0] = M0 + M1 + M2
+      R[((xi * 2 + 1) * WG_NT + row) * WG_RLD + l31] = (m1 - m2) - m3;  //          R[xi][1] = M1 - M2 - M3
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int it = gtid + k * GT;
+      const int e_bb = (it >> 3) & 1, e_tile = it >> 4;
+      f32x4 x[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        x[q] = *reinterpret_cast<const f32x4*>(R + ((q * 2 + e_bb) * WG_NT + e_tile) * WG_RLD + e_n4 * 4);
+      o[k * 2 + 0] = v4add(v4add(x[0], x[1]), x[2]);  // xi axis: Y[0][bb] = R0 + R1 + R2 ; Y[1][bb] = R1 - R2 - R3
+      o[k * 2 + 1] = v4sub(v4sub(x[1], x[2]), x[3]);
+    }
+  };
+
+  // SK: ordered sum of the finished virtual chunks, output domain: [NI*4][256 threads] float4 in LDS, private to each thread
+  [[maybe_unused]] f32x4* const tot = reinterpret_cast<f32x4*>(V + WG_V_FLOATS) + gtid;
+  if constexpr (SK) {
+#pragma unroll
+    for (int i = 0; i < NI * 4; ++i) tot[i * GT] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
   f32x4 ra[APT];
-  load_A(0, ra);
-  for (int chunk = 0; chunk < n; ++chunk) {
+  load_A(kb, ra);
+  for (int c = 0; c < n; ++c) {
+    const int chunk = kb + c;
     // slot 0: gather-store.  Weight fragments of positions nu 0,1 are requested first: two slots of cover.
     load_B(chunk, 0);
     load_B(chunk, 1);
@@ -269,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void winograd_kernel(const WinoArgs a) {
 #endif
     __syncthreads();
     // slot 1: next slab's activations are requested (a whole slab of cover), then the transform
-    load_A(chunk + 1 < n ? chunk + 1 : chunk, ra);  // unconditional (clamped): a load under a branch makes hipcc drain vmcnt
+    load_A(c + 1 < n ? chunk + 1 : chunk, ra);  // unconditional (clamped): a load under a branch makes hipcc drain vmcnt
     __builtin_amdgcn_sched_barrier(0);
 #if CF_WABLATE != 1 && CF_WABLATE != 7
     transform();
@@ -290,46 +349,67 @@ __global__ __launch_bounds__(256, 2) void winograd_kernel(const WinoArgs a) {
     mma(3);
 #endif
     // (the barrier after the next gather-store separates these reads of V from its rewrite)
+    if constexpr (SK) {
+      if ((c + 1) % CF_SK_SLABS == 0) {  // a virtual chunk is complete: fold its output-domain sum (one workgroup) or park it (split)
+        f32x4 v[NI * 4];
+#pragma unroll
+        for (int pass = 0; pass < NI; ++pass) {
+          f32x4 o[4];
+          to_output(pass, o);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            v[pass * 4 + i] = o[i];
+            tot[(pass * 4 + i) * GT] += o[i];
+          }
+        }
+        if (a.nsplit > 1) cf_splitk_park(v, a.ws, sk_tile, chunk / CF_SK_SLABS, a.nchunks / CF_SK_SLABS, GT);
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nu][ni][r] = 0.f;
+        __syncthreads();  // staging (the V region) is rewritten by the next slab's transform
+      }
+    }
   }
-  __syncthreads();  // V reads retired before it becomes the staging buffer
 
-  // ---- epilogue (both groups, each for its own patch) ------------------------------------------------------------------------
-  // NI passes of 32 channels: every wave contracts its nu axis in registers and stages R[xi][bb] in its group's (idle) V
-  // buffer; then item = (tile, output column bb, channel quad) contracts xi and owns two output pixels (rows aa = 0, 1).
-  float* const R = V;  // [(xi*2 + bb)][tile][WG_RLD]
+  if constexpr (SK) {
+    if (a.nsplit > 1) {
+      f32x4 v[NI * 4];
+      __syncthreads();
+      if (!cf_splitk_finish(v, a.ws, a.counters, sk_tile, a.nchunks / CF_SK_SLABS, a.nsplit, GT, smem)) return;
+#pragma unroll
+      for (int i = 0; i < NI * 4; ++i) tot[i * GT] = v[i];
+    }
+  }
+
+  // ---- epilogue: bias / residual / SFT, 16-byte stores, GroupNorm statistics of what was written -------------------------------
 #pragma unroll
   for (int pass = 0; pass < NI; ++pass) {
+    f32x4 o[4];
+    if constexpr (SK) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float m0 = acc[0][pass][r], m1 = acc[1][pass][r], m2 = acc[2][pass][r], m3 = acc[3][pass][r];
-      const int row = cf_acc_row(r, lane);
-      R[((xi * 2 + 0) * WG_NT + row) * WG_RLD + l31] = (m0 + m1) + m2;  // nu axis: R[xi][0] = M0 + M1 + M2
-      R[((xi * 2 + 1) * WG_NT + row) * WG_RLD + l31] = (m1 - m2) - m3;  //          R[xi][1] = M1 - M2 - M3
+      for (int i = 0; i < 4; ++i) o[i] = tot[(pass * 4 + i) * GT];
+    } else {
+      to_output(pass, o);
     }
-    __syncthreads();
-    const int e_n4 = gtid & 7;  // (the item stride is a multiple of 8: both items of a thread have the same channel quad)
     const int nn = n0 + pass * 32 + e_n4 * 4;
     const bool nvalid = nn < a.cout;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (a.bias && nvalid) bias4 = *reinterpret_cast<const f32x4*>(a.bias + nn);
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int it = gtid; it < 512; it += GT) {
+    for (int k = 0; k < 2; ++k) {
+      const int it = gtid + k * GT;
       const int e_bb = (it >> 3) & 1, e_tile = it >> 4;
       const int e_ty = e_tile >> 3, e_tx = e_tile & 7;
-      f32x4 x[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        x[q] = *reinterpret_cast<const f32x4*>(R + ((q * 2 + e_bb) * WG_NT + e_tile) * WG_RLD + e_n4 * 4);
-      f32x4 o[2];
-      o[0] = v4add(v4add(x[0], x[1]), x[2]);  // xi axis: Y[0][bb] = R0 + R1 + R2 ; Y[1][bb] = R1 - R2 - R3
-      o[1] = v4sub(v4sub(x[1], x[2]), x[3]);
 #pragma unroll
       for (int aa = 0; aa < 2; ++aa) {
         const size_t pixel = ((size_t)b * a.h + (y0 + 2 * e_ty + aa)) * a.w + (x0 + 2 * e_tx + e_bb);
         const size_t off = pixel * a.cout + nn;
         if (nvalid) {
-          f32x4 v = o[aa];
+          f32x4 v = o[k * 2 + aa];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += bias4[e];
           if (a.epilogue == CF_EPI_RESIDUAL) {
@@ -365,33 +445,32 @@ __global__ __launch_bounds__(256, 2) void winograd_kernel(const WinoArgs a) {
         d0 = ((double)ssum[0] + ssum[1]) + ((double)ssum[2] + ssum[3]);
         q0 = ((double)ssq[0] + ssq[1]) + ((double)ssq[2] + ssq[3]);
       }
-      for (int o = 8; o < 64; o <<= 1) {  // the (tile, bb) items of this wave: lanes with the same channel quad
-        d0 += __shfl_xor(d0, o, 64);
-        q0 += __shfl_xor(q0, o, 64);
+      for (int o2 = 8; o2 < 64; o2 <<= 1) {  // the (tile, bb) items of this wave: lanes with the same channel quad
+        d0 += __shfl_xor(d0, o2, 64);
+        q0 += __shfl_xor(q0, o2, 64);
       }
       if (cpg == 2) {  // (second group of the lane: 64-channel layers only -- a wave-uniform branch)
-        for (int o = 8; o < 64; o <<= 1) {
-          d1 += __shfl_xor(d1, o, 64);
-          q1 += __shfl_xor(q1, o, 64);
+        for (int o2 = 8; o2 < 64; o2 <<= 1) {
+          d1 += __shfl_xor(d1, o2, 64);
+          q1 += __shfl_xor(q1, o2, 64);
         }
       }
-      for (int o = 1; o * 4 < cpg; o <<= 1) {  // adjacent channel quads of one group (cpg >= 8)
-        d0 += __shfl_xor(d0, o, 64);
-        q0 += __shfl_xor(q0, o, 64);
+      for (int o2 = 1; o2 * 4 < cpg; o2 <<= 1) {  // adjacent channel quads of one group (cpg >= 8)
+        d0 += __shfl_xor(d0, o2, 64);
+        q0 += __shfl_xor(q0, o2, 64);
       }
       if ((lane >> 3) == 0 && nvalid && (nn % cpg) == 0) {
         const size_t pidx = (size_t)rt * 4 + xi;
         const int ng = a.cout / cpg;
-        double* o = a.stats_out + (((size_t)b * ng + nn / cpg) * a.nparts + pidx) * 2;
-        o[0] = d0;
-        o[1] = q0;
+        double* op = a.stats_out + (((size_t)b * ng + nn / cpg) * a.nparts + pidx) * 2;
+        op[0] = d0;
+        op[1] = q0;
         if (cpg == 2) {
-          o[(size_t)a.nparts * 2] = d1;
-          o[(size_t)a.nparts * 2 + 1] = q1;
+          op[(size_t)a.nparts * 2] = d1;
+          op[(size_t)a.nparts * 2 + 1] = q1;
         }
       }
     }
-    __syncthreads();  // staging is rewritten by the next 32 channels
   }
 }
 
@@ -484,28 +563,46 @@ int cf_winograd_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_que
     *parts_query = a.nparts;
     return CF_OK;
   }
-  constexpr size_t lds = (WG_PATCH_FLOATS + WG_V_FLOATS) * sizeof(float);  // 61.7 KB: two workgroups per CU
-  static unsigned long long attr_devs = 0;  // bit d: attribute set on device d (it is a per-device property of the function)
+  const bool sk = d->split_k >= 1;
+  const size_t lds = (WG_PATCH_FLOATS + WG_V_FLOATS + (sk ? WG_NI * 4 * 256 * 4 : 0)) * sizeof(float);  // 61.7 KB (two workgroups per CU); SK: + 32 KB
+  if (sk) {
+    const int V = a.nchunks / CF_SK_SLABS;
+    CF_REQUIRE(a.nchunks % CF_SK_SLABS == 0 && V >= 1 && V % d->split_k == 0,
+               "cf_conv2d(winograd): split_k %d needs cin %% 128 == 0 and split_k dividing cin/128 = %d", d->split_k, V);
+    CF_REQUIRE(d->split_k == 1 || (d->workspace && d->counters), "cf_conv2d(winograd): split_k > 1 needs workspace and counters");
+  }
+  const void* kern = sk ? reinterpret_cast<const void*>(winograd_kernel<true>) : reinterpret_cast<const void*>(winograd_kernel<false>);
+  static unsigned long long attr_devs[2] = {0, 0};  // bit d: attribute set on device d (a per-device property), per instantiation
   int dev = 0;
   (void)hipGetDevice(&dev);
-  if (dev >= 64 || !((attr_devs >> dev) & 1ull)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
+  if (dev >= 64 || !((attr_devs[sk] >> dev) & 1ull)) {
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       cf_set_error("cf_conv2d: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
       return CF_ERR_LAUNCH;
     }
-    if (dev < 64) attr_devs |= 1ull << dev;  // benign race: the attribute call is idempotent
+    if (dev < 64) attr_devs[sk] |= 1ull << dev;  // benign race: the attribute call is idempotent
   }
-  hipLaunchKernelGGL(winograd_kernel, dim3(a.tiles_per_img * d->batch * a.ntn), dim3(256), lds, stream, a);
+  const int tiles = a.tiles_per_img * d->batch * a.ntn;
+  if (sk) {
+    WinoArgsSK k;
+    static_cast<WinoArgs&>(k) = a;
+    k.ws = d->workspace;
+    k.counters = d->counters;
+    k.nsplit = d->split_k;
+    hipLaunchKernelGGL(winograd_kernel<true>, dim3(tiles * d->split_k), dim3(256), lds, stream, k);
+  } else {
+    hipLaunchKernelGGL(winograd_kernel<false>, dim3(tiles), dim3(256), lds, stream, a);
+  }
   CF_CHECK_LAUNCH("cf_conv2d(winograd)");
   return CF_OK;
 }
 
 int cf_winograd_splitk_geometry(const cf_conv_desc* d, int* tiles, long* bytes_per_part) {
-  (void)d;
-  *tiles = 0;
-  *bytes_per_part = 0;
-  cf_set_error("cf_conv2d: split_k is not available for this kernel");
-  return CF_ERR_ARG;
+  CF_REQUIRE(d->hout % WG_TH == 0 && d->wout % WG_TW == 0 && d->cout_pad % WG_BN == 0 && (d->c0 + d->c1) % (16 * CF_SK_SLABS) == 0,
+             "cf_conv2d(winograd): split_k needs whole patches and cin %% 128 == 0");
+  *tiles = (d->hout / WG_TH) * (d->wout / WG_TW) * d->batch * (d->cout_pad / WG_BN);
+  const int V = (d->c0 + d->c1) / (16 * CF_SK_SLABS);
+  *bytes_per_part = (long)WG_NI * 4 * 256 * 16 * V / (d->split_k > 0 ? d->split_k : 1);  // output-domain chunk sums: 32 KB each
+  return CF_OK;
 }

@@ -178,10 +178,17 @@ _COUNTERS = {}
 
 
 def splitk_for(pw, ho, wo, cin, batch=1):
-    """Split count for a 1x1 / Linear on `batch` (ho x wo)-token images; 0: the layer is not a split-K layer."""
-    if SPLITK_MAX <= 0 or pw.taps != 1 or pw.bf16 or ho * wo > 1024 or (ho * wo) % 64 or pw.cout_pad % 64 or cin % 128:
+    """Split count for a 1x1 / Linear or a Winograd 3x3 on `batch` images of ho x wo pixels; 0: the layer is not a split-K layer."""
+    if SPLITK_MAX <= 0 or pw.bf16 or ho * wo > 1024 or cin % 128:
         return 0
-    tiles = batch * (ho * wo // 64) * (pw.cout_pad // 64)
+    if pw.wino:
+        if ho % 8 or wo % 16 or ho * wo > 256:   # the 16x16 latents only: from 32x32 up a batch fills the CUs without splitting
+            return 0
+        tiles = batch * (ho // 8) * (wo // 16) * (pw.cout_pad // 64)
+    elif pw.taps == 1 and (ho * wo) % 64 == 0 and pw.cout_pad % 64 == 0:
+        tiles = batch * (ho * wo // 64) * (pw.cout_pad // 64)
+    else:
+        return 0
     v = cin // 128
     for ns in (8, 4, 2):
         if ns <= SPLITK_MAX and v % ns == 0 and tiles * ns <= 512:

@@ -106,3 +106,36 @@ def test_splitk_gemm_bits_do_not_depend_on_the_split_count(sc):
     # policy: eligibility by per-image shape; the count by what is in flight
     pw = ops.pack_weight(torch.zeros(512, 512, device='cuda'))
     assert ops.splitk_for(pw, 16, 16, 512, 1) == 4 and ops.splitk_for(pw, 16, 16, 512, 16) == 1 and ops.splitk_for(pw, 64, 64, 512, 1) == 0
+
+
+def test_splitk_winograd_bits_do_not_depend_on_the_split_count(sc):
+    """The Winograd kernel on images of at most 32x32 pixels: virtual chunks of 128 channels are taken to the output domain and added
+    in a fixed order -- 1, 2 or 4 workgroups per patch give the same bits; errors vs fp64 as the unsplit kernel's."""
+    import torch
+    import torch.nn.functional as F
+    from codeformer_amd import ops
+    g = torch.Generator().manual_seed(9)
+    for (B, H, W, cin, cout, epi) in ((1, 16, 16, 512, 512, ops.EPI_RESIDUAL), (2, 32, 32, 256, 256, ops.EPI_NONE), (1, 16, 16, 256, 512, ops.EPI_NONE)):
+        x = torch.randn(B, H, W, cin, generator=g)
+        w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+        b = torch.randn(cout, generator=g) * 0.1
+        sc_, sh_ = torch.rand(B, cin, generator=g) + 0.5, torch.randn(B, cin, generator=g) * 0.1
+        res = torch.randn(B, H, W, cout, generator=g)
+        pw = ops.pack_weight(w.cuda(), b.cuda(), bf16=ops.WINOGRAD)
+        kw = dict(prologue=ops.PRO_AFFINE_SWISH, scale=sc_.cuda(), shift=sh_.cuda(), epilogue=epi, res=res.cuda() if epi else None)
+        outs, stats = [], []
+        for ns in [n for n in (1, 2, 4) if (cin // 128) % n == 0]:
+            y = ops.conv2d(x.cuda(), pw, split_k=ns, emit_stats=True, **kw)
+            outs.append(y)
+            stats.append(y._cf_stats.part.clone())
+        assert all(torch.equal(o, outs[0]) for o in outs[1:]) and all(torch.equal(t, stats[0]) for t in stats[1:]), (H, cin, cout)
+        xd = x.double() * sc_.double()[:, None, None, :] + sh_.double()[:, None, None, :]
+        xd = xd * torch.sigmoid(xd)
+        ref = F.conv2d(xd.permute(0, 3, 1, 2), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+        if epi:
+            ref = ref + res.double()
+        assert float((outs[0].cpu().double() - ref).abs().max()) <= 2e-5 + 1e-5 * float(ref.abs().max())
+        # one image of the batch alone: same bits (the split count follows the tiles in flight, the association does not)
+        if B > 1:
+            kw1 = dict(kw, scale=sc_[:1].cuda(), shift=sh_[:1].cuda(), res=res[:1].cuda() if epi else None)
+            assert torch.equal(ops.conv2d(x[:1].cuda(), pw, **kw1), ops.conv2d(x.cuda(), pw, **kw)[:1])

@@ -175,6 +175,8 @@ class CodeFormer(VQAutoEncoder):
         # fp32, so logits / indices stay bitwise identical across 'fp32' / 'bf16' / 'fp16').  Measured against the reference:
         # logits 4.3e-6 (direct kernel 5.5e-6), lq_feat 1.0e-5 (1.4e-5), indices exact on every seeded face incl. one whose
         # top-2 gap is 1.7e-5 -- the Winograd form sums fewer products per output and is, if anything, the more accurate one.
+        # Round 2 added the reference's own crops (three PNGs, one masked face) and an 8-face sweep to the gate: indices equal the
+        # reference's on every token whose reference gap is >= 1e-5 (tests/test_gpu_real_images.py).
         self.winograd_encoder = os.environ.get('CODEFORMER_HIP_WINOGRAD_ENCODER', '1') != '0'
         # Optional HIP-graph replay of the whole forward (one graph per input shape / w / flags): takes the ~250 host launches
         # per call off the critical path.  Measured: no gain at B=1..16 on an otherwise idle host (the kernels, not the launches,

@@ -106,22 +106,29 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* __restrict
   if (lane == 0) out[row] = s;
 }
 
-// ---- codebook gather (+AdaIN): one workgroup per image, thread = channel -------------------------
+// ---- codebook gather (+AdaIN): one workgroup per (image, 32 channels); thread = (token lane 0..7, channel) ---------------------
+// Statistics in fp64: every thread sums the tokens p = lane, lane + 8, ...; the eight partial sums of a channel are added in lane
+// order through LDS (fixed order -> bitwise reproducible).  Unbiased variance as torch.var (codeformer_arch.py:23-25).
 __global__ __launch_bounds__(256) void gather_adain_kernel(const int64_t* __restrict__ idx, const float* __restrict__ cb,
                                                            int ncodes, const float* __restrict__ lq, int ntok, int dim,
                                                            int adain, float eps, float* __restrict__ out) {
-  extern __shared__ int s_idx[];
-  const int b = blockIdx.x;
+  extern __shared__ int s_idx[];                      // [ntok] clamped code indices, then 4 x [8][32] doubles
+  double* red = reinterpret_cast<double*>(s_idx + ((ntok + 1) & ~1));
+  __shared__ float s_stat[4][32];
+  const int groups = (dim + 31) / 32;
+  const int b = blockIdx.x / groups;
+  const int c = (blockIdx.x - b * groups) * 32 + (threadIdx.x & 31);
+  const int tl = threadIdx.x >> 5;
+  const bool cv = c < dim;
   for (int p = threadIdx.x; p < ntok; p += blockDim.x) {
     long v = idx[(size_t)b * ntok + p];
     s_idx[p] = (int)(v < 0 ? 0 : (v >= ncodes ? ncodes - 1 : v));
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < dim; c += blockDim.x) {
-    float cm = 0.f, cs = 1.f, sm = 0.f, ss = 1.f;
-    if (adain) {
-      double s1 = 0, q1 = 0, s2 = 0, q2 = 0;
-      for (int p = 0; p < ntok; ++p) {
+  if (adain) {
+    double s1 = 0, q1 = 0, s2 = 0, q2 = 0;
+    if (cv)
+      for (int p = tl; p < ntok; p += 8) {
         const double v1 = cb[(size_t)s_idx[p] * dim + c];
         const double v2 = lq[((size_t)b * ntok + p) * dim + c];
         s1 += v1;
@@ -129,20 +136,36 @@ __global__ __launch_bounds__(256) void gather_adain_kernel(const int64_t* __rest
         s2 += v2;
         q2 += v2 * v2;
       }
-      const double m1 = s1 / ntok, m2 = s2 / ntok;
-      double var1 = (q1 - s1 * m1) / (ntok - 1), var2 = (q2 - s2 * m2) / (ntok - 1);  // unbiased (torch.var)
+    red[(0 * 8 + tl) * 32 + (threadIdx.x & 31)] = s1;
+    red[(1 * 8 + tl) * 32 + (threadIdx.x & 31)] = q1;
+    red[(2 * 8 + tl) * 32 + (threadIdx.x & 31)] = s2;
+    red[(3 * 8 + tl) * 32 + (threadIdx.x & 31)] = q2;
+    __syncthreads();
+    if (tl == 0) {
+      double t[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        t[k] = 0;
+        for (int j = 0; j < 8; ++j) t[k] += red[(k * 8 + j) * 32 + threadIdx.x];
+      }
+      const double m1 = t[0] / ntok, m2 = t[2] / ntok;
+      double var1 = (t[1] - t[0] * m1) / (ntok - 1), var2 = (t[3] - t[2] * m2) / (ntok - 1);  // unbiased (torch.var)
       if (var1 < 0) var1 = 0;
       if (var2 < 0) var2 = 0;
-      cm = (float)m1;
-      sm = (float)m2;
-      cs = sqrtf((float)var1 + eps);
-      ss = sqrtf((float)var2 + eps);
+      s_stat[0][threadIdx.x] = (float)m1;
+      s_stat[1][threadIdx.x] = sqrtf((float)var1 + eps);
+      s_stat[2][threadIdx.x] = (float)m2;
+      s_stat[3][threadIdx.x] = sqrtf((float)var2 + eps);
     }
-    for (int p = 0; p < ntok; ++p) {
-      float v = cb[(size_t)s_idx[p] * dim + c];
-      if (adain) v = ((v - cm) / cs) * ss + sm;  // codeformer_arch.py:42-43 operation order
-      out[((size_t)b * ntok + p) * dim + c] = v;
-    }
+    __syncthreads();
+  }
+  if (!cv) return;
+  const float cm = adain ? s_stat[0][threadIdx.x & 31] : 0.f, cs = adain ? s_stat[1][threadIdx.x & 31] : 1.f;
+  const float sm = adain ? s_stat[2][threadIdx.x & 31] : 0.f, ss = adain ? s_stat[3][threadIdx.x & 31] : 1.f;
+  for (int p = tl; p < ntok; p += 8) {
+    float v = cb[(size_t)s_idx[p] * dim + c];
+    if (adain) v = ((v - cm) / cs) * ss + sm;  // codeformer_arch.py:42-43 operation order
+    out[((size_t)b * ntok + p) * dim + c] = v;
   }
 }
 
@@ -351,8 +374,9 @@ extern "C" int cf_codebook_gather_adain(const int64_t* idx, const float* codeboo
                                         int batch, int ntok, int dim, int adain, float eps, float* out,
                                         cf_stream_t stream) {
   CF_REQUIRE(idx && codebook && out && (!adain || lq), "cf_codebook_gather_adain: null pointer");
-  CF_REQUIRE(batch > 0 && ntok > 1 && ntok <= 16384 && dim > 0 && codebook_size > 0, "cf_codebook_gather_adain: bad dims");
-  hipLaunchKernelGGL(gather_adain_kernel, dim3(batch), dim3(256), ntok * sizeof(int), (hipStream_t)stream, idx, codebook,
+  CF_REQUIRE(batch > 0 && ntok > 1 && ntok <= 8192 && dim > 0 && codebook_size > 0, "cf_codebook_gather_adain: bad dims");
+  const size_t lds = (size_t)((ntok + 1) & ~1) * sizeof(int) + 4 * 8 * 32 * sizeof(double);
+  hipLaunchKernelGGL(gather_adain_kernel, dim3(batch * ((dim + 31) / 32)), dim3(256), lds, (hipStream_t)stream, idx, codebook,
                      codebook_size, lq, ntok, dim, adain, eps, out);
   CF_CHECK_LAUNCH("cf_codebook_gather_adain");
   return CF_OK;

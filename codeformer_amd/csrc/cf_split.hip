@@ -469,33 +469,33 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void split_conv_kernel(c
     constexpr int EPI = decltype(mode)::value;
     float* stage = smem + wave * (32 * LDW);
     const int cq = lane % Q, rl = lane / Q;
-    const int n = n0 + wn * (NI * 32) + cq * 4;
-    const bool nvalid = n < a.cout;
+    const int n = n0 + wn * (NI * 32) + cq * 4;  // (always < cout: the host requires cout % 64 == 0)
+    constexpr bool nvalid = true;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (a.bias && nvalid) bias4 = *reinterpret_cast<const f32x4*>(a.bias + n);
+    if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + n);
     const float s = a.acc_scale;
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+    // Residual / SFT operands of BOTH 32-row halves are requested up front (the main loop's registers are free by now), so their
+    // HBM latency overlaps the transposes instead of opening each half.
+    unsigned offs[MI][PASSES];  // element offsets fit 32 bits (tensors < 16 GiB)
+    f32x4 r0[MI][PASSES], r1[MI][PASSES];
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      size_t offs[PASSES];
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int p = 0; p < PASSES; ++p) {
         const int row = wm * 64 + mi * 32 + p * RPP + rl;
-        size_t pixel;
+        unsigned pixel;
         if (TAPS == 4)
-          pixel = ((size_t)b * a.hout + (2 * (y0 + (row >> 4)) + sub_y)) * a.wout + (2 * (x0 + (row & 15)) + sub_x);
+          pixel = ((unsigned)b * a.hout + (2 * (y0 + (row >> 4)) + sub_y)) * a.wout + (2 * (x0 + (row & 15)) + sub_x);
         else
-          pixel = ((size_t)b * a.hout + (y0 + (row >> 4))) * a.wout + (x0 + (row & 15));
-        offs[p] = pixel * a.cout + n;
+          pixel = ((unsigned)b * a.hout + (y0 + (row >> 4))) * a.wout + (x0 + (row & 15));
+        offs[mi][p] = pixel * (unsigned)a.cout + n;
+        r0[mi][p] = r1[mi][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (EPI == CF_EPI_RESIDUAL || EPI == CF_EPI_SFT) r0[mi][p] = *reinterpret_cast<const f32x4*>(a.res + offs[mi][p]);
+        if (EPI == CF_EPI_SFT) r1[mi][p] = *reinterpret_cast<const f32x4*>(a.sft_scale + offs[mi][p]);
       }
-      // residual / SFT operands are requested before the transpose so that their latency overlaps it
-      f32x4 r0[PASSES], r1[PASSES];
 #pragma unroll
-      for (int p = 0; p < PASSES; ++p) {
-        r0[p] = r1[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (nvalid && (EPI == CF_EPI_RESIDUAL || EPI == CF_EPI_SFT)) r0[p] = *reinterpret_cast<const f32x4*>(a.res + offs[p]);
-        if (nvalid && EPI == CF_EPI_SFT) r1[p] = *reinterpret_cast<const f32x4*>(a.sft_scale + offs[p]);
-      }
+    for (int mi = 0; mi < MI; ++mi) {
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
@@ -504,25 +504,26 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void split_conv_kernel(c
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      f32x4 t[PASSES];
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p) t[p] = *reinterpret_cast<const f32x4*>(stage + (p * RPP + rl) * LDW + cq * 4);
 #pragma unroll
       for (int p = 0; p < PASSES; ++p) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(stage + (p * RPP + rl) * LDW + cq * 4);
-        if (nvalid) {
+        f32x4 v = t[p];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] * s + bias4[e];
-          if (EPI == CF_EPI_RESIDUAL) {
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * s + bias4[e];
+        if (EPI == CF_EPI_RESIDUAL) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += r0[p][e];
-          } else if (EPI == CF_EPI_SFT) {
+          for (int e = 0; e < 4; ++e) v[e] += r0[mi][p][e];
+        } else if (EPI == CF_EPI_SFT) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = r0[p][e] + a.sft_w * (r0[p][e] * r1[p][e] + v[e]);
-          }
-          *reinterpret_cast<f32x4*>(a.out + offs[p]) = v;
+          for (int e = 0; e < 4; ++e) v[e] = r0[mi][p][e] + a.sft_w * (r0[mi][p][e] * r1[mi][p][e] + v[e]);
+        }
+        *reinterpret_cast<f32x4*>(a.out + offs[mi][p]) = v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            ssum[e] += v[e];
-            ssq[e] += v[e] * v[e];
-          }
+        for (int e = 0; e < 4; ++e) {
+          ssum[e] += v[e];
+          ssq[e] += v[e] * v[e];
         }
       }
       __builtin_amdgcn_wave_barrier();  // the staging rows are rewritten by the next 32-row block
@@ -667,8 +668,8 @@ int cf_split_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query)
   CF_REQUIRE(d->taps == 9 && d->stride == 1 && !d->in_nchw && !d->out_nchw && !d->winograd,
              "cf_conv2d: f16x2 operands cover 3x3 stride-1 NHWC convolutions (plain or nearest-x2 folded)");
   CF_REQUIRE(d->c0 % 32 == 0 && d->c1 % 32 == 0, "cf_conv2d(f16x2): input channels (%d, %d) must be multiples of 32", d->c0, d->c1);
-  CF_REQUIRE(d->cout_pad % 64 == 0 && d->cout % 4 == 0 && d->cout_pad == (d->cout + 63) / 64 * 64,
-             "cf_conv2d(f16x2): cout %d / cout_pad %d (pad to a multiple of 64)", d->cout, d->cout_pad);
+  CF_REQUIRE(d->cout % 64 == 0 && d->cout_pad == d->cout, "cf_conv2d(f16x2): cout %d / cout_pad %d must be one multiple of 64", d->cout,
+             d->cout_pad);
   constexpr int TH = SP_WM * 4;
   CF_REQUIRE(d->hin % TH == 0 && d->win % 16 == 0, "cf_conv2d(f16x2): %dx%d input is not a multiple of the %dx16 tile", d->hin, d->win, TH);
   CF_REQUIRE(d->epilogue == CF_EPI_NONE || d->epilogue == CF_EPI_RESIDUAL || d->epilogue == CF_EPI_SFT,

@@ -385,6 +385,27 @@ __global__ __launch_bounds__(256, 2) void winograd_kernel(const std::conditional
   }
 
   // ---- epilogue: bias / residual / SFT, 16-byte stores, GroupNorm statistics of what was written -------------------------------
+  // Residual / SFT operands of both 32-channel passes are requested first (the main loop's registers are free by now): their HBM
+  // latency overlaps the LDS contraction instead of following it.  (n < cout always: the host requires cout % 64 == 0.)
+  unsigned offs[NI][4];  // element offsets fit 32 bits (tensors < 16 GiB)
+  f32x4 r0[NI][4], r1[NI][4];
+#pragma unroll
+  for (int pass = 0; pass < NI; ++pass)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int it = gtid + k * GT;
+      const int e_bb = (it >> 3) & 1, e_tile = it >> 4;
+      const int e_ty = e_tile >> 3, e_tx = e_tile & 7;
+#pragma unroll
+      for (int aa = 0; aa < 2; ++aa) {
+        const unsigned pixel = ((unsigned)b * a.h + (y0 + 2 * e_ty + aa)) * a.w + (x0 + 2 * e_tx + e_bb);
+        const unsigned off = pixel * (unsigned)a.cout + (n0 + pass * 32 + e_n4 * 4);
+        offs[pass][k * 2 + aa] = off;
+        r0[pass][k * 2 + aa] = r1[pass][k * 2 + aa] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.epilogue == CF_EPI_RESIDUAL || a.epilogue == CF_EPI_SFT) r0[pass][k * 2 + aa] = *reinterpret_cast<const f32x4*>(a.res + off);
+        if (a.epilogue == CF_EPI_SFT) r1[pass][k * 2 + aa] = *reinterpret_cast<const f32x4*>(a.sft_scale + off);
+      }
+    }
 #pragma unroll
   for (int pass = 0; pass < NI; ++pass) {
     f32x4 o[4];
@@ -395,40 +416,27 @@ __global__ __launch_bounds__(256, 2) void winograd_kernel(const std::conditional
       to_output(pass, o);
     }
     const int nn = n0 + pass * 32 + e_n4 * 4;
-    const bool nvalid = nn < a.cout;
+    constexpr bool nvalid = true;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (a.bias && nvalid) bias4 = *reinterpret_cast<const f32x4*>(a.bias + nn);
+    if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + nn);
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int it = gtid + k * GT;
-      const int e_bb = (it >> 3) & 1, e_tile = it >> 4;
-      const int e_ty = e_tile >> 3, e_tx = e_tile & 7;
+    for (int i = 0; i < 4; ++i) {
+      f32x4 v = o[i];
 #pragma unroll
-      for (int aa = 0; aa < 2; ++aa) {
-        const size_t pixel = ((size_t)b * a.h + (y0 + 2 * e_ty + aa)) * a.w + (x0 + 2 * e_tx + e_bb);
-        const size_t off = pixel * a.cout + nn;
-        if (nvalid) {
-          f32x4 v = o[k * 2 + aa];
+      for (int e = 0; e < 4; ++e) v[e] += bias4[e];
+      if (a.epilogue == CF_EPI_RESIDUAL) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += bias4[e];
-          if (a.epilogue == CF_EPI_RESIDUAL) {
-            const f32x4 rr = *reinterpret_cast<const f32x4*>(a.res + off);
+        for (int e = 0; e < 4; ++e) v[e] += r0[pass][i][e];
+      } else if (a.epilogue == CF_EPI_SFT) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += rr[e];
-          } else if (a.epilogue == CF_EPI_SFT) {
-            const f32x4 dec = *reinterpret_cast<const f32x4*>(a.res + off);
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.sft_scale + off);
+        for (int e = 0; e < 4; ++e) v[e] = r0[pass][i][e] + a.sft_w * (r0[pass][i][e] * r1[pass][i][e] + v[e]);
+      }
+      *reinterpret_cast<f32x4*>(a.out + offs[pass][i]) = v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = dec[e] + a.sft_w * (dec[e] * sc[e] + v[e]);
-          }
-          *reinterpret_cast<f32x4*>(a.out + off) = v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            ssum[e] += v[e];
-            ssq[e] += v[e] * v[e];
-          }
-        }
+      for (int e = 0; e < 4; ++e) {
+        ssum[e] += v[e];
+        ssq[e] += v[e] * v[e];
       }
     }
     if (a.stats_out) {
@@ -525,7 +533,8 @@ int cf_winograd_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_que
              "cf_conv2d: winograd covers fp32 3x3 stride-1 NHWC convolutions");
   CF_REQUIRE(d->hout % WG_TH == 0 && d->wout % WG_TW == 0, "cf_conv2d: winograd needs an output of %dx%d multiples (got %dx%d)",
              WG_TH, WG_TW, d->hout, d->wout);
-  CF_REQUIRE(d->cout_pad % 64 == 0 && d->cout % 4 == 0, "cf_conv2d: winograd needs cout_pad %% 64 == 0 and cout %% 4 == 0");
+  CF_REQUIRE(d->cout % 64 == 0 && d->cout_pad == d->cout, "cf_conv2d: winograd needs cout == cout_pad, a multiple of 64 (got %d / %d)", d->cout,
+             d->cout_pad);
   CF_REQUIRE(d->epilogue == CF_EPI_NONE || d->epilogue == CF_EPI_RESIDUAL || d->epilogue == CF_EPI_SFT,
              "cf_conv2d: winograd epilogues are none / residual / SFT");
   CF_REQUIRE(d->pad_mode == CF_PAD_ZERO && (d->ld_in0 == 0 || d->ld_in0 == d->c0) && (d->ld_in1 == 0 || d->ld_in1 == d->c1) &&

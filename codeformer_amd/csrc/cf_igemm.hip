@@ -997,6 +997,78 @@ __global__ __launch_bounds__(256) void conv3x3_few_cout_kernel(const ConvArgsExt
       a.out[(((size_t)b * a.cout + co) * a.hout + oy) * a.wout + ox] = acc[co] + (a.bias ? a.bias[co] : 0.f);
 }
 
+// ---- 3x3 convolution of an NCHW input with <= 4 channels into 64 NHWC channels (the network's first conv, vqgan_arch.py:243) --------
+// K = 27: on MFMA the layer pads K to 16 per tap and still moves 1.07 GB of output per 16 faces -- it is write-bound (AI = 13 FLOP/B),
+// and the MFMA instantiation reached 1.0 TB/s.  Here a workgroup owns a 16x16 pixel tile: input patch (<= 4 x 18 x 18) and the 27 x 64
+// weights sit in LDS, a thread computes FOUR channels of one pixel on the vector ALU (exact fp32 FMA chain: channel-major, then
+// taps), and the 16 lanes that share a pixel store its 256 contiguous bytes.  GroupNorm partials as in the MFMA epilogue
+// (fp64, fixed shuffle order): one per (image, group, tile, wave).
+__global__ __launch_bounds__(256) void conv3x3_few_cin_kernel(const ConvArgsExt a) {
+  __shared__ float s_in[4][18 * 18];
+  __shared__ __attribute__((aligned(16))) float s_w[36][64];  // [tap * 4 + c][n]
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / a.tiles_per_img;
+  const int r = blockIdx.x - b * a.tiles_per_img;
+  const int ty0 = r / a.tiles_x;
+  const int y0 = ty0 * 16, x0 = (r - ty0 * a.tiles_x) * 16;
+  for (int i = tid; i < 36 * 64; i += 256) {
+    const int n = i & 63, tc = i >> 6, tap = tc >> 2, c = tc & 3;
+    (&s_w[0][0])[i] = (c < a.c0 && n < a.cout) ? a.weight[((size_t)tap * a.cout_pad + n) * CF_BK + c] : 0.f;  // [tap][1 slab][cout_pad][16]
+  }
+  const size_t plane = (size_t)a.hin * a.win;
+  for (int i = tid; i < 4 * 18 * 18; i += 256) {
+    const int c = i / (18 * 18), p = i - c * (18 * 18), hy = p / 18, hx = p - hy * 18;
+    const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+    float v = 0.f;
+    if (c < a.c0 && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win) v = a.in0[((size_t)b * a.c0 + c) * plane + (size_t)iy * a.win + ix];
+    s_in[c][p] = v;
+  }
+  __syncthreads();
+  const int quad = tid & 15, slot = tid >> 4;
+  const int n = quad * 4;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + n);
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+  for (int round = 0; round < 16; ++round) {
+    const int p = round * 16 + slot, py = p >> 4, px = p & 15;
+    f32x4 acc = bias4;
+    for (int c = 0; c < a.c0; ++c) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const float v = s_in[c][(py + tap / 3) * 18 + px + tap % 3];
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(&s_w[tap * 4 + c][n]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(v, w4[e], acc[e]);
+      }
+    }
+    *reinterpret_cast<f32x4*>(a.out + (((size_t)b * a.hout + (y0 + py)) * a.wout + (x0 + px)) * a.cout + n) = acc;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ssum[e] += acc[e];
+      ssq[e] += acc[e] * acc[e];
+    }
+  }
+  if (a.stats_out) {  // cout = 64 -> 2 channels per group: a lane's four channels are two groups
+    double d0 = (double)ssum[0] + ssum[1], q0 = (double)ssq[0] + ssq[1];
+    double d1 = (double)ssum[2] + ssum[3], q1 = (double)ssq[2] + ssq[3];
+    for (int o = 16; o < 64; o <<= 1) {  // the four pixel slots of the wave that share this channel quad
+      d0 += __shfl_xor(d0, o, 64);
+      q0 += __shfl_xor(q0, o, 64);
+      d1 += __shfl_xor(d1, o, 64);
+      q1 += __shfl_xor(q1, o, 64);
+    }
+    if ((tid & 63) < 16) {
+      const size_t pidx = (size_t)r * 4 + (tid >> 6);
+      double* o = a.stats_out + (((size_t)b * 32 + quad * 2) * a.nparts + pidx) * 2;
+      o[0] = d0;
+      o[1] = q0;
+      o[(size_t)a.nparts * 2] = d1;
+      o[(size_t)a.nparts * 2 + 1] = q1;
+    }
+  }
+}
+
 template <int TAPS, int STRIDE, int WM, int WN, int MI, int NI, bool IN_NCHW, bool BF16 = false, bool EXT = false, bool F16 = false>
 int launch(const ConvArgsExt& a, hipStream_t stream, int* parts_query) {
   using C = Cfg<TAPS, STRIDE, WM, WN, MI, NI>;
@@ -1391,6 +1463,19 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
     return launch<9, 1, 4, 1, 2, 2, false, true>(a, stream, pq);  // cout_pad == 64
   }
   if (d->taps == 9 && d->stride == 1) {
+    if (d->in_nchw && d->cout == 64 && cp == 64 && d->hout % 16 == 0 && d->wout % 16 == 0 && (!d->stats_cpg || d->stats_cpg == 2) &&
+        d->epilogue == CF_EPI_NONE) {  // the vector-ALU first conv (write-bound layer)
+      a.tiles_x = d->wout / 16;
+      a.tiles_per_img = a.tiles_x * (d->hout / 16);
+      a.nparts = a.tiles_per_img * 4;
+      if (pq) {
+        *pq = a.nparts;
+        return CF_OK;
+      }
+      hipLaunchKernelGGL(conv3x3_few_cin_kernel, dim3(a.tiles_per_img * d->batch), dim3(256), 0, stream, a);
+      CF_CHECK_LAUNCH("cf_conv2d");
+      return CF_OK;
+    }
     if (d->in_nchw) {
       CF_REQUIRE(cp == 64, "cf_conv2d: in_nchw path is built for cout_pad 64 (got %d)", cp);
       return launch<9, 1, 4, 1, 2, 2, true>(a, stream, pq);

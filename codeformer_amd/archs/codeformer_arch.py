@@ -159,13 +159,14 @@ class CodeFormer(VQAutoEncoder):
                 for p in getattr(self, name).parameters():
                     p.requires_grad = False
 
-        # Operand format of the generator + CFT 3x3 convolutions.  Encoder, Transformer and the code argmax are exact fp32 in EVERY mode,
-        # so logits and code indices do not depend on it.
+        # Operand format of the 3x3 stride-1 convolutions.  Tensors, accumulation, the Transformer and the code argmax are fp32 in every mode.
         #   'f16x2' (default): fp32 operands split into hi + lo IEEE halves (22 significant bits), three f16 MFMAs per product, fp32
-        #            accumulation (cf_split.hip).  Per layer 1-2x the fp64-error of the exact kernels; whole network vs the reference
-        #            5.7e-5 on real crops (exact path: 5.6e-5; tolerance 1e-3).  1.27x the exact path's faces/s.
+        #            accumulation (cf_split.hip), for generator, CFT and -- see encoder_precision -- the encoder.  Per layer 1-2x the
+        #            fp64-error of the exact kernels; whole network vs the reference 5.7e-5 on real crops (exact path: 5.6e-5;
+        #            tolerance 1e-3), logits 8.0e-6 (exact: 7.8e-6; tolerance 1e-4), code indices identical.  1.45x the exact path's faces/s.
         #   'fp32':  everything on exact fp32 MFMA (Winograd F(2x2,3x3) where eligible, see below).
-        #   'bf16' (BASELINE configs 3/5) / 'fp16': single 16-bit operands with fp32 accumulate (pixel gates in tests/test_gpu_real_images.py).
+        #   'bf16' (BASELINE configs 3/5) / 'fp16': single 16-bit operands with fp32 accumulate in generator + CFT, encoder exact fp32
+        #            (pixel gates in tests/test_gpu_real_images.py).
         self.precision = os.environ.get('CODEFORMER_HIP_PRECISION', 'f16x2')
         # Exact-fp32 convolutions (precision='fp32', and in every mode the layers the split kernel does not take): evaluate 3x3
         # stride-1 convolutions with Winograd F(2x2,3x3) -- the same function in fp32 with 2.25x fewer multiplies (cf_winograd.hip).
@@ -178,6 +179,14 @@ class CodeFormer(VQAutoEncoder):
         # Round 2 added the reference's own crops (three PNGs, one masked face) and an 8-face sweep to the gate: indices equal the
         # reference's on every token whose reference gap is >= 1e-5 (tests/test_gpu_real_images.py).
         self.winograd_encoder = os.environ.get('CODEFORMER_HIP_WINOGRAD_ENCODER', '1') != '0'
+        # Operand format of the ENCODER's 3x3 stride-1 convolutions: 'fp32' (exact fp32 MFMA, Winograd where eligible), 'f16x2' (the
+        # split-half kernel on every layer it covers: all but the first conv and the 16x16 latents) or 'auto' = 'f16x2' when
+        # precision is 'f16x2', 'fp32' otherwise.  The code indices hang on the encoder, so this was measured before it became the
+        # default (tools/encoder_split_check.py, profiles/r02_encoder_split_check.txt): against the reference's logits on its own
+        # crops the split encoder is as close as the exact one (max 8.0e-6 / 6.3e-6 / 6.6e-6 vs 7.8e-6 / 6.5e-6 / 5.7e-6; the
+        # reference's own 1-vs-8-thread noise is 2.6e-6), the smallest (reference top-2 gap) / (2 x our logit error) over all tokens
+        # is 7.1 (exact: 7.3), and every index of every golden agrees.  Set 'fp32' to keep logits bitwise equal across precisions.
+        self.encoder_precision = os.environ.get('CODEFORMER_HIP_ENCODER_PRECISION', 'auto')
         # Optional HIP-graph replay of the whole forward (one graph per input shape / w / flags): takes the ~250 host launches
         # per call off the critical path.  Measured: no gain at B=1..16 on an otherwise idle host (the kernels, not the launches,
         # bound even B=1), so it is off by default; useful when the host thread is busy (decode / encode of PNGs).
@@ -215,7 +224,11 @@ class CodeFormer(VQAutoEncoder):
         enc_feat = {}
         enc_taps = {self.fuse_encoder_block[f]: (lambda t: enc_feat.__setitem__(str(t.shape[2]), t))
                     for f in self.connect_list}
+        if self.encoder_precision not in ('auto', 'fp32', 'f16x2'):
+            raise ValueError(f"encoder_precision must be 'auto', 'fp32' or 'f16x2', got {self.encoder_precision!r}")
         enc_code = ops.WINOGRAD if (self.winograd and self.winograd_encoder) else 0
+        if self.encoder_precision == 'f16x2' or (self.encoder_precision == 'auto' and self.precision == 'f16x2'):
+            enc_code = ops.SPLIT if enc_code == ops.WINOGRAD else ops.SPLIT_DIRECT
         lq = self.encoder.forward_nhwc(x, enc_taps, bf16=enc_code)        # (B,16,16,256) channels-last
         T = lq.shape[1] * lq.shape[2]
         tokens = lq.view(B * T, lq.shape[3])
@@ -286,7 +299,7 @@ class CodeFormer(VQAutoEncoder):
     def _forward_graphed(self, x, w, code_only, adain):
         """Capture-once / replay-many execution of _forward_hip on the current stream.  Outputs are copies, so callers may
         keep them across calls.  A graph is re-captured when any packed weight was rebuilt since its capture."""
-        key = (tuple(x.shape), float(w), bool(code_only), bool(adain), self.precision, bool(self.winograd), bool(self.winograd_encoder), str(x.device))
+        key = (tuple(x.shape), float(w), bool(code_only), bool(adain), self.precision, self.encoder_precision, bool(self.winograd), bool(self.winograd_encoder), str(x.device))
         ent = self._graphs.get(key)
         if ent is None or ent['epoch'] != PACK_EPOCH[0]:
             static_x = x.float().contiguous().clone()

@@ -95,6 +95,10 @@ def test_inpainting_config(chk):
     assert float((logits.cpu() - torch.from_numpy(g['logits'])).abs().max()) <= 1e-4
     assert np.array_equal(net.last_indices.cpu().numpy(), g['idx'])
     assert float((out.cpu()[:, :, ::4, ::4] - torch.from_numpy(g['out_sub'])).abs().max()) <= 1e-3
+    net.precision = 'fp32'                                                   # (the run above was the default, split-half, mode)
+    out, logits, _ = net(seeded_input(1).cuda(), w=1, adain=False)
+    assert float((logits.cpu() - torch.from_numpy(g['logits'])).abs().max()) <= 1e-4
+    assert float((out.cpu()[:, :, ::4, ::4] - torch.from_numpy(g['out_sub'])).abs().max()) <= 1e-3
     # BASELINE config 5 names bf16: 16-bit operands in generator + CFT only -> logits bitwise those of fp32 mode, indices
     # exact, pixels inside the gates of tools/gpu_check.py:g_bf16 (bf16 0.25 max, fp16 0.04 max on outputs of std ~0.5)
     for prec, gate in (('bf16', 0.25), ('fp16', 0.04)):

@@ -456,6 +456,7 @@ def g_bf16():
         net = build_net().to(DEV)
         gold = np.load(os.path.join(ROOT, 'tests/golden/restoration_seed0_face0.npz'))
         x = seeded_input(1).to(DEV)
+        net.precision = 'fp32'
         o32 = net(x, w=0.5, adain=True)
         net.precision = 'bf16'
         out, logits, lq = net(x, w=0.5, adain=True)

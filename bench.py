@@ -113,7 +113,9 @@ def roofline_leg(net, x, w):
     KINDS = {
         'conv3x3_f16x2': ('split_conv_kernel<9,...> (3x3 s1, fp32 operands as hi+lo halves: 3 f16 MFMAs per product, fp32 accumulate)', 3.0, F16_MFMA_PEAK_TFLOPS, 'split_conv_kernel<9'),
         'conv_up2x_f16x2': ('split_conv_kernel<4,...> (nearest-x2 + 3x3 folded to 2x2 sub-pixel taps, split halves)', 3.0, F16_MFMA_PEAK_TFLOPS, 'split_conv_kernel<4'),
-        'conv3x3_wino': ('winograd_kernel (3x3 s1 as Winograd F(2x2,3x3), fp32 MFMA)', 4.0 / 9.0, FP32_MFMA_PEAK_TFLOPS, 'winograd_kernel'),
+        'conv3x3_wino': ('winograd_kernel<.,false> (3x3 s1 as Winograd F(2x2,3x3), fp32 MFMA)', 4.0 / 9.0, FP32_MFMA_PEAK_TFLOPS, 'winograd_kernel'),
+        'conv3x3_wino_f16x2': ('winograd_kernel<.,true> (3x3 s1 as Winograd F(2x2,3x3); U and V as hi+lo halves: 3 f16 MFMAs per '
+                               'transform-domain product, fp32 accumulate)', 3.0 * 4.0 / 9.0, F16_MFMA_PEAK_TFLOPS, 'winograd_kernel'),
         'conv3x3': ('igemm_kernel<9,1,...> (direct 3x3 s1 implicit GEMM, fp32 MFMA)', 1.0, FP32_MFMA_PEAK_TFLOPS, 'igemm_kernel<9, 1'),
         'conv_up2x': ('igemm_kernel<4,1,...> (folded nearest-x2 + 3x3, fp32 MFMA)', 1.0, FP32_MFMA_PEAK_TFLOPS, 'igemm_kernel<4, 1'),
         'conv3x3_s2': ('igemm_kernel<9,2,...> (3x3 stride 2, fp32 MFMA)', 1.0, FP32_MFMA_PEAK_TFLOPS, 'igemm_kernel<9, 2'),
@@ -139,7 +141,7 @@ def roofline_leg(net, x, w):
     roof = entry(order[0])                                   # the dominant kernel = the kind with the largest summed duration
     roof['other_kernels'] = {k: entry(k) for k in order[1:]}
     # executed fp32-MFMA-equivalent work of one step (Winograd at its 4/9; a split-half product counted once) + attention (2.01 GF / face)
-    exec_flops = sum(v[0] * (4.0 / 9.0 if k == 'conv3x3_wino' else 1.0) for k, v in agg.items()) / reps + 2.01e9 * x.shape[0]
+    exec_flops = sum(v[0] * (4.0 / 9.0 if k.startswith('conv3x3_wino') else 1.0) for k, v in agg.items()) / reps + 2.01e9 * x.shape[0]
     roof['executed_gflop_per_face_whole_path'] = round(exec_flops / x.shape[0] / 1e9, 2)
     return roof, table
 

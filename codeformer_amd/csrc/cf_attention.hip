@@ -121,6 +121,115 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ Q, 
   }
 }
 
+// ---- head_dim 512 (the VQGAN AttnBlock) -------------------------------------------------------------------------------------------
+// The generic kernel above spends a head_dim-512 call on 8 workgroups per image that walk 32 + 64 barrier-separated 16-wide slabs:
+// 108 us whatever the batch.  Here a workgroup is 8 waves and owns one (image, 32-query tile, 256-column half of the output).
+// Only the A operands are shared between waves (the Q tile in phase 1, the probabilities in phase 3): they live in LDS, the Q tile
+// staged ONCE.  The B operands are private to a wave -- its 32 keys of K, its 32 output columns of V -- so each lane loads them
+// straight from global memory in MFMA operand order, 64 channels / 64 keys ahead in registers: no barrier inside either loop.
+// The products are summed in the order of the generic kernel, so the results are bit-identical to it.  The second column half
+// recomputes S (fp32 MFMA time per workgroup: 6.8 us + 3.4 us).
+constexpr int A5_THREADS = 512;
+constexpr int A5_CW = 256;                        // output columns per workgroup
+constexpr int A5_QS = (512 / CF_BK) * BQ * CF_LDK;  // floats: the whole Q tile as 32 sub-slabs [32 rows][16 + 4]
+constexpr size_t A5_LDS_BYTES = (size_t)(BQ * PS + A5_QS) * sizeof(float);
+
+__global__ __launch_bounds__(A5_THREADS) void attn512_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ K, int ldk,
+                                                             const float* __restrict__ V, int ldv, float* __restrict__ O, int ldo,
+                                                             float scale) {
+  constexpr int DH = 512;
+  extern __shared__ __attribute__((aligned(16))) float a5_smem[];
+  float* const Ps = a5_smem;            // [32][260] scores / probabilities
+  float* const Qs = a5_smem + BQ * PS;  // [32 sub-slabs][32][20]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int q0 = blockIdx.x * BQ;
+  const int h = blockIdx.y >> 1, chunk = blockIdx.y & 1;
+  const int b = blockIdx.z;
+  const size_t rowbase = (size_t)b * NKEY;
+  const int colbase = h * DH;
+
+  // this lane's K row (phase 1 B operand), first group of 64 channels already in flight while Q is staged
+  const float* const krow = K + (rowbase + wave * 32 + l31) * ldk + colbase + half * 4;
+  f32x4 kb[2][8];
+  auto kload = [&](int g, f32x4(&dst)[8]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[i] = *reinterpret_cast<const f32x4*>(krow + g * 64 + i * 8);  // i = sub-slab * 2 + kg
+  };
+  kload(0, kb[0]);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int f = tid + A5_THREADS * j, row = f >> 7, k4 = f & 127;
+    *reinterpret_cast<f32x4*>(Qs + ((k4 >> 2) * BQ + row) * CF_LDK + (k4 & 3) * 4) =
+        *reinterpret_cast<const f32x4*>(Q + (rowbase + q0 + row) * ldq + colbase + k4 * 4);
+  }
+  __syncthreads();
+
+  // ---------------- phase 1: S[32][256] = Q K^T ; wave w owns keys [32w, 32w+32) ----------------
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int g = 0; g < DH / 64; ++g) {
+    if (g + 1 < DH / 64) kload(g + 1, kb[(g + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (the scheduler otherwise sinks every load to its use)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const f32x4 af = *reinterpret_cast<const f32x4*>(Qs + ((g * 4 + (i >> 1)) * BQ + l31) * CF_LDK + (i & 1) * 8 + half * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], kb[g & 1][i][j], acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) Ps[cf_acc_row(r, lane) * PS + wave * 32 + l31] = acc[r] * scale;
+
+  // this lane's V column (phase 3 B operand): the first 64 keys on their way while the softmax runs
+  const float* const vcol = V + (rowbase + half * 4) * ldv + colbase + chunk * A5_CW + wave * 32 + l31;
+  float vb[2][32];
+  auto vload = [&](int g, float(&dst)[32]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)  // i = 16-key slab * 2 + kg
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dst[i * 4 + j] = vcol[(size_t)(g * 64 + i * 8 + j) * ldv];
+  };
+  vload(0, vb[0]);
+  __syncthreads();
+
+  // ---------------- phase 2: row softmax (F.softmax over keys), 4 rows per wave ----------------
+#pragma unroll
+  for (int i = 0; i < BQ / 8; ++i) {
+    float* pr = Ps + (wave * (BQ / 8) + i) * PS + lane * 4;
+    f32x4 v = *reinterpret_cast<f32x4*>(pr);
+    const float m = cf_wave_max(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = expf(v[e] - m);
+    const float s = cf_wave_sum((v[0] + v[1]) + (v[2] + v[3]));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = v[e] / s;
+    *reinterpret_cast<f32x4*>(pr) = v;
+  }
+  __syncthreads();
+
+  // ---------------- phase 3: O[32][256 of 512] = P V, wave w owns columns [32w, 32w+32) of the chunk ----------------
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+  for (int g = 0; g < NKEY / 64; ++g) {
+    if (g + 1 < NKEY / 64) vload(g + 1, vb[(g + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const f32x4 af = *reinterpret_cast<const f32x4*>(Ps + l31 * PS + g * 64 + i * 8 + half * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], vb[g & 1][i * 4 + j], o, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    O[(rowbase + q0 + cf_acc_row(r, lane)) * ldo + colbase + chunk * A5_CW + wave * 32 + l31] = o[r];
+}
+
 }  // namespace
 
 extern "C" int cf_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo,
@@ -133,7 +242,20 @@ extern "C" int cf_attention(const float* q, int ldq, const float* k, int ldk, co
   if (head_dim == 64) {
     hipLaunchKernelGGL(attn_kernel<64>, grid, block, 0, (hipStream_t)stream, q, ldq, k, ldk, v, ldv, out, ldo, scale);
   } else if (head_dim == 512) {
-    hipLaunchKernelGGL(attn_kernel<512>, grid, block, 0, (hipStream_t)stream, q, ldq, k, ldk, v, ldv, out, ldo, scale);
+    static unsigned long long attr_devs = 0;  // bit d: LDS attribute set on device d
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 64 || !((attr_devs >> dev) & 1ull)) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn512_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)A5_LDS_BYTES);
+      if (e != hipSuccess) {
+        cf_set_error("cf_attention: hipFuncSetAttribute(%zu B LDS): %s", A5_LDS_BYTES, hipGetErrorString(e));
+        return CF_ERR_LAUNCH;
+      }
+      if (dev < 64) attr_devs |= 1ull << dev;  // benign race: the attribute call is idempotent
+    }
+    hipLaunchKernelGGL(attn512_kernel, dim3(NKEY / BQ, heads * 2, batch), dim3(A5_THREADS), A5_LDS_BYTES, (hipStream_t)stream, q, ldq,
+                       k, ldk, v, ldv, out, ldo, scale);
   } else {
     cf_set_error("cf_attention: head_dim %d unsupported (64 or 512)", head_dim);
     return CF_ERR_ARG;

@@ -1373,8 +1373,8 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
   CF_REQUIRE(d->cout_pad >= d->cout && d->cout_pad % 32 == 0, "cf_conv2d: cout_pad %d invalid for cout %d", d->cout_pad,
              d->cout);
 
+  if (d->winograd) return cf_winograd_launch(d, stream, pq);  // fp32 or split-half operands
   if (d->bf16_mfma == CF_OPERAND_F16X2) return cf_split_launch(d, stream, pq);
-  if (d->winograd) return cf_winograd_launch(d, stream, pq);
 
   ConvArgsExt a;
   a.in0 = d->in0;
@@ -1492,8 +1492,11 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
     }
     if (cp == 32) return launch<9, 1, 4, 1, 2, 1, false>(a, stream, pq);
   } else if (d->taps == 9 && d->stride == 2) {
-    if (cp % 128 == 0) return launch<9, 2, 2, 2, 2, 2, false>(a, stream, pq);
-    if (cp == 64) return launch<9, 2, 2, 2, 2, 1, false>(a, stream, pq);
+    // 128-wide channel tiles unless the layer is small (at most 64 of them per image): 64-wide tiles double the workgroup count of a
+    // small batch.  Per-image shape only: the two widths group the statistics partials differently (see cf_split_launch)
+    const long wide_wgs = ((long)d->hout * d->wout / 128) * (cp / 128);
+    if (cp % 128 == 0 && wide_wgs > 64) return launch<9, 2, 2, 2, 2, 2, false>(a, stream, pq);
+    if (cp % 64 == 0) return launch<9, 2, 2, 2, 2, 1, false>(a, stream, pq);
   } else {
     if (d->split_k >= 1) {  // small token matrices: 64x64 tiles, split_k workgroups per tile
       const int V = a.nchunks / CF_SK_SLABS;  // virtual chunks: the summation order is out = ((0 + P0) + P1) + ... whatever split_k is
@@ -1519,8 +1522,8 @@ static int splitk_geometry(const cf_conv_desc* d, int* tiles, long* bytes_per_pa
   *tiles = 0;
   *bytes_per_part = 0;
   if (!d || d->split_k < 1) return CF_OK;
-  if (d->bf16_mfma == CF_OPERAND_F16X2) return cf_split_splitk_geometry(d, tiles, bytes_per_part);
   if (d->winograd) return cf_winograd_splitk_geometry(d, tiles, bytes_per_part);
+  if (d->bf16_mfma == CF_OPERAND_F16X2) return cf_split_splitk_geometry(d, tiles, bytes_per_part);
   CF_REQUIRE(d->taps == 1 && d->cout_pad % 64 == 0 && ((long)d->batch * d->hout * d->wout) % 64 == 0,
              "cf_conv2d: split_k covers 1x1 / Linear (64x64 tiles), winograd and f16x2 launches");
   *tiles = (int)((long)d->batch * d->hout * d->wout / 64) * (d->cout_pad / 64);

@@ -67,41 +67,61 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
 }
 
 // ---- GroupNorm stage 2: fixed-order sum of partials -> per-(b,c) scale/shift --------------------
-// One WAVE per (image, normalisation group): the group's gmerge fine groups x nparts partials are contiguous in the
-// table, so the wave streams them with lane-strided 16-byte loads (conv-epilogue statistics can be thousands of
-// partials per group), reduces with a fixed shuffle butterfly (bitwise reproducible), and its first cpg*gmerge lanes
-// write the channel tables.  scale = gamma*rstd, shift = beta - mean*scale: the affine form ATen's CPU kernel applies.
+// One WORKGROUP per (image, normalisation group): the group's gmerge fine groups x nparts partials are contiguous in the
+// table, so the 256 threads stream them with strided 16-byte loads on four independent chains each (conv-epilogue
+// statistics can be thousands of partials per group; a single wave needed up to 60 us for them), reduce with a fixed
+// shuffle butterfly + a fixed-order sum of the four waves (bitwise reproducible), and write the channel tables.  scale = gamma*rstd, shift = beta - mean*scale: the affine form ATen's CPU kernel applies.
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ part, int batch, int nparts, int C,
                                                           int cpg, int gmerge, double inv_count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float eps, float* __restrict__ scale, float* __restrict__ shift,
                                                           int ld) {
-  const int lane = threadIdx.x & 63;
+  __shared__ double red[4][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int GM = C / (cpg * gmerge);
-  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (w >= batch * GM) return;
-  const int b = w / GM, m = w - b * GM;
+  const int b = blockIdx.x / GM, m = blockIdx.x - b * GM;
   const int G = C / cpg;
   const double2* p = reinterpret_cast<const double2*>(part) + ((size_t)b * G + (size_t)m * gmerge) * nparts;
   const int n = gmerge * nparts;
-  double s = 0, q = 0;
-  for (int j = lane; j < n; j += 64) {
-    const double2 v = p[j];
-    s += v.x;
-    q += v.y;
+  // thread t sums partials t, t+256, ... on four independent chains (up to 4096 partials per group: the loads overlap)
+  double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  int j = tid;
+  for (; j + 768 < n; j += 1024) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const double2 v = p[j + 256 * u];
+      s[u] += v.x;
+      q[u] += v.y;
+    }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    s += __shfl_xor(s, o, 64);
-    q += __shfl_xor(q, o, 64);
+  for (int u = 0; u < 4; ++u) {
+    if (j + 256 * u < n) {
+      const double2 v = p[j + 256 * u];
+      s[u] += v.x;
+      q[u] += v.y;
+    }
   }
-  const double mean = s * inv_count;
-  double var = q * inv_count - mean * mean;
+  double ss = (s[0] + s[1]) + (s[2] + s[3]), qq = (q[0] + q[1]) + (q[2] + q[3]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ss += __shfl_xor(ss, o, 64);
+    qq += __shfl_xor(qq, o, 64);
+  }
+  if (lane == 0) {
+    red[wave][0] = ss;
+    red[wave][1] = qq;
+  }
+  __syncthreads();
+  ss = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+  qq = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+  const double mean = ss * inv_count;
+  double var = qq * inv_count - mean * mean;
   if (var < 0) var = 0;
   const float fmean = (float)mean;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
   const int cpm = cpg * gmerge;
-  for (int i = lane; i < cpm; i += 64) {
+  for (int i = tid; i < cpm; i += 256) {
     const int c = m * cpm + i;
     const float sc = rstd * gamma[c];
     scale[(size_t)b * ld + c] = sc;
@@ -178,8 +198,7 @@ extern "C" int cf_groupnorm_finalize(const double* partial, int batch, int parts
   CF_REQUIRE(cpg >= 1 && c % cpg == 0 && gmerge >= 1 && (c / cpg) % gmerge == 0 && count > 0 &&
                  parts >= 1 && ld >= c,
              "cf_groupnorm_finalize: bad dims (c=%d cpg=%d gmerge=%d parts=%d ld=%d)", c, cpg, gmerge, parts, ld);
-  const int waves = batch * (c / (cpg * gmerge));
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((waves + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, batch, parts, c,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch * (c / (cpg * gmerge))), dim3(256), 0, (hipStream_t)stream, partial, batch, parts, c,
                      cpg, gmerge, 1.0 / (double)count, gamma, beta, eps, scale, shift, ld);
   CF_CHECK_LAUNCH("cf_groupnorm_finalize");
   return CF_OK;

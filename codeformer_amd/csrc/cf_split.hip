@@ -33,6 +33,8 @@
 //   * epilogue as in cf_igemm.hip: per-wave LDS transpose, 16-byte stores, bias / residual / SFT, fp64 GroupNorm partials.
 #include <type_traits>
 
+#include <cstdlib>
+
 #include "cf_common.h"
 
 // SP_ABLATE: timing-only ablation builds (tools/split_ab.sh), a bit mask: 1 no epilogue, 2 no weight fetch, 4 no weight LDS write,
@@ -48,6 +50,12 @@
 #define SP_FAST_RCP 1   // 1: swish reciprocal on the raw v_rcp_f32 (1 ulp) instead of the IEEE-rounded division sequence: +4..8 %
 #endif
 // SP_WEAVE: 1 = fragment reads / weight fetches / weight LDS writes are woven one-by-one into the MFMA stream (sched_group_barrier)
+#ifndef SP_NARROW_OCC
+#define SP_NARROW_OCC 3  // workgroups per CU the 64-wide-tile instantiations are compiled for (47 KB LDS each; 168 VGPRs)
+#endif
+#ifndef SP_NARROW_MAX_WGS
+#define SP_NARROW_MAX_WGS 64  // at most this many 128-wide workgroups per image -> use 64-wide tiles (see cf_split_launch)
+#endif
 #ifndef SP_WEAVE
 #define SP_WEAVE 1
 #endif
@@ -120,7 +128,7 @@ __device__ __forceinline__ void split2(float x0, float x1, float& hi, float& lo)
 }
 
 template <int TAPS, int NI, int WM>
-__global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void split_conv_kernel(const SplitArgs a) {
+__global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 ? SP_NARROW_OCC : 2) : 1) void split_conv_kernel(const SplitArgs a) {
   using C = SplitCfg<TAPS, NI, WM>;
   constexpr int MI = 2;
   constexpr int NT = C::NT;
@@ -714,7 +722,15 @@ int cf_split_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query)
     *parts_query = a.nparts;
     return CF_OK;
   }
-  const bool wide = d->cout_pad % 128 == 0;
+  // 128-wide channel tiles unless the layer is small (at most SP_NARROW_MAX_WGS 128-wide workgroups PER IMAGE: the 32x32 / 64x64
+  // layers): 64-wide tiles double the workgroup count of a small batch.  The rule looks at the per-image shape only -- the two tile
+  // widths write the same outputs but group the GroupNorm partial sums differently, so a batch-dependent choice would break the
+  // bitwise batch invariance of the network.
+  static const int narrow_max_wgs = [] {
+    const char* e = getenv("CODEFORMER_HIP_SPLIT_NARROW_WGS");
+    return e ? atoi(e) : SP_NARROW_MAX_WGS;
+  }();
+  const bool wide = d->cout_pad % 128 == 0 && (long)a.tiles_per_img * (d->cout_pad / 128) > narrow_max_wgs;
   if (d->upsample) return wide ? split_launch<4, 2>(a, d->batch, stream) : split_launch<4, 1>(a, d->batch, stream);
   return wide ? split_launch<9, 2>(a, d->batch, stream) : split_launch<9, 1>(a, d->batch, stream);
 }

@@ -77,6 +77,7 @@ struct WinoArgs {
   const float* res;
   const float* sft_scale;
   float sft_w;
+  float acc_scale;  // H2: inverse of the pack-time weight scale (a power of two); 1 otherwise
   float* out;
   double* stats_out;
   int stats_cpg, nparts;
@@ -102,7 +103,15 @@ __device__ __forceinline__ f32x4 v4sub(f32x4 a, f32x4 b) { return a - b; }
 // through the workspace by the workgroup that draws the last ticket (cf_splitk_park / cf_splitk_finish): the same bits for every nsplit.
 // The running sum lives in LDS (32 KB behind the V buffer), not in registers: next to the 128 Winograd-domain accumulators a second
 // register accumulator spilled into the main loop (+36 %).
-template <bool SK>
+// H2 = true ("split halves", the scheme of cf_split.hip in the Winograd domain): the 16 GEMMs run on v_mfma_f32_32x32x16_f16 with both
+// operands as hi + lo IEEE halves -- U pre-split at pack time (scaled by a power of two so that the lo halves stay normal), V split
+// when a wave reads its A fragment (each element of V is read by exactly one lane, so nothing is converted twice) -- and
+// hi*hi + lo*hi + hi*lo accumulated in fp32: 3 MFMAs of 8 passes per 16-channel slab and MFMA tile instead of 8 of 16 passes.
+// Gather, transform, epilogue and the split-K protocol are shared with the fp32 form.
+typedef _Float16 wg_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 wg_f16x2 __attribute__((ext_vector_type(2)));
+
+template <bool SK, bool H2>
 __global__ __launch_bounds__(256, 2) void winograd_kernel(const std::conditional_t<SK, WinoArgsSK, WinoArgs> a) {
   constexpr int NI = WG_NI;
   constexpr int GT = 256;                                        // threads
@@ -198,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void winograd_kernel(const std::conditional
           if (PRO == CF_PRO_AFFINE) y = y * sc[e] + sh[e];
           if (PRO == CF_PRO_AFFINE_SWISH) {
             y = y * sc[e] + sh[e];
-            y = y * __frcp_rn(1.0f + __expf(-y));  // same hardware exp / rcp swish as the direct kernel
+            y = y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));  // same hardware exp / rcp swish as the direct kernel
           }
           if (PRO == CF_PRO_LEAKY) y = y > 0.f ? y : 0.2f * y;
           v[e] = valid ? y : 0.f;
@@ -268,16 +277,40 @@ __global__ __launch_bounds__(256, 2) void winograd_kernel(const std::conditional
       for (int kg = 0; kg < 2; ++kg) bq[nu][ni][kg] = *reinterpret_cast<const f32x4*>(wc + ni * 512 + kg * 256);
   };
   auto mma = [&](int nu) {
-    f32x4 aq[2];
+    if constexpr (H2) {
+      // this lane's 8 channels of the slab (row = tile l31, channels half*8 .. +7), split into hi / lo halves in registers
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(alane + nu * WG_PS + half * 4);  // (alane already holds half*4)
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(alane + nu * WG_PS + half * 4 + 4);
+      f32x4 ah, al;
 #pragma unroll
-    for (int kg = 0; kg < 2; ++kg) aq[kg] = *reinterpret_cast<const f32x4*>(alane + nu * WG_PS + kg * 8);
+      for (int e = 0; e < 4; ++e) {
+        const float x0 = e < 2 ? v0[2 * e] : v1[2 * e - 4], x1 = e < 2 ? v0[2 * e + 1] : v1[2 * e - 3];
+        float hh, ll;
+      cf_split_pair(x0, x1, hh, ll);
+      ah[e] = hh;
+      al[e] = ll;
+      }
 #pragma unroll
-    for (int kg = 0; kg < 2; ++kg)
+      for (int ni = 0; ni < NI; ++ni) {
+        acc[nu][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wg_f16x8, al), __builtin_bit_cast(wg_f16x8, bq[nu][ni][0]),
+                                                             acc[nu][ni], 0, 0, 0);
+        acc[nu][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wg_f16x8, ah), __builtin_bit_cast(wg_f16x8, bq[nu][ni][1]),
+                                                             acc[nu][ni], 0, 0, 0);
+        acc[nu][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wg_f16x8, ah), __builtin_bit_cast(wg_f16x8, bq[nu][ni][0]),
+                                                             acc[nu][ni], 0, 0, 0);
+      }
+    } else {
+      f32x4 aq[2];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int kg = 0; kg < 2; ++kg) aq[kg] = *reinterpret_cast<const f32x4*>(alane + nu * WG_PS + kg * 8);
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-          acc[nu][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[kg][j], bq[nu][ni][kg][j], acc[nu][ni], 0, 0, 0);
+      for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[nu][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[kg][j], bq[nu][ni][kg][j], acc[nu][ni], 0, 0, 0);
+    }
   };
 
   // ---- to the output domain: NI passes of 32 channels.  Every wave contracts its nu axis in registers and stages R[xi][bb] in the
@@ -424,7 +457,7 @@ __global__ __launch_bounds__(256, 2) void winograd_kernel(const std::conditional
     for (int i = 0; i < 4; ++i) {
       f32x4 v = o[i];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += bias4[e];
+      for (int e = 0; e < 4; ++e) v[e] = H2 ? v[e] * a.acc_scale + bias4[e] : v[e] + bias4[e];  // (a power of two: exact)
       if (a.epilogue == CF_EPI_RESIDUAL) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += r0[pass][i][e];
@@ -513,7 +546,59 @@ __global__ void pack_weight_winograd_kernel(const float* __restrict__ w, int cou
   packed[i] = val;
 }
 
+// H2 operands: U' = scale * G g G^T (fp64, rounded once to fp32) as hi = f16(U'), lo = f16(U' - hi), in MFMA-operand order
+// [pos][cin_pad/16][cout_pad/32][part: hi, lo][lane 64][4 words]; a lane's 16 bytes are the 8 halves of
+// U'[n = tile*32 + (lane&31)][c = chunk*16 + (lane>>5)*8 + 0..7]  (v_mfma_f32_32x32x16_f16 B operand).
+__global__ void pack_weight_winograd_f16x2_kernel(const float* __restrict__ w, int cout, int cin, int cout_pad, int nchunks, float scale,
+                                                  unsigned* __restrict__ packed, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one 32-bit word = two halves
+  if (i >= total) return;
+  const int e = (int)(i & 3), ln = (int)((i >> 2) & 63), part = (int)((i >> 8) & 1);
+  long r = i >> 9;
+  const int ntiles = cout_pad / 32;
+  const int n = (int)(r % ntiles) * 32 + (ln & 31);
+  r /= ntiles;
+  const int chunk = (int)(r % nchunks);
+  const int pos = (int)(r / nchunks);
+  const int xi = pos >> 2, nu = pos & 3;
+  unsigned out = 0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int c = chunk * CF_BK + (ln >> 5) * 8 + e * 2 + h;
+    float val = 0.f;
+    if (n < cout && c < cin) {
+      const float* g = w + ((long)n * cin + c) * 9;
+      double row[3];
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        const double g0 = g[x], g1 = g[3 + x], g2 = g[6 + x];
+        row[x] = xi == 0 ? g0 : (xi == 1 ? 0.5 * (g0 + g1 + g2) : (xi == 2 ? 0.5 * (g0 - g1 + g2) : g2));
+      }
+      const double u = nu == 0 ? row[0] : (nu == 1 ? 0.5 * (row[0] + row[1] + row[2]) : (nu == 2 ? 0.5 * (row[0] - row[1] + row[2]) : row[2]));
+      val = (float)(u * (double)scale);
+    }
+    const _Float16 hi = (_Float16)val;
+    const _Float16 hv = part ? (_Float16)(val - (float)hi) : hi;
+    out |= (unsigned)__builtin_bit_cast(unsigned short, hv) << (16 * h);
+  }
+  packed[i] = out;
+}
+
 }  // namespace
+
+extern "C" int cf_pack_conv_weight_winograd_f16x2(const float* w, int cout, int cin, int cout_pad, int cin_pad, float scale, void* packed,
+                                                  cf_stream_t stream) {
+  CF_REQUIRE(w && packed, "cf_pack_conv_weight_winograd_f16x2: null pointer");
+  CF_REQUIRE(cin_pad % CF_BK == 0 && cin_pad >= cin && cout_pad >= cout && cout_pad % 64 == 0,
+             "cf_pack_conv_weight_winograd_f16x2: bad padding cin %d->%d cout %d->%d", cin, cin_pad, cout, cout_pad);
+  int ex = 0;
+  CF_REQUIRE(scale > 0.f && frexpf(scale, &ex) == 0.5f, "cf_pack_conv_weight_winograd_f16x2: scale %g is not a power of two", (double)scale);
+  const long total = 16L * cin_pad * cout_pad;  // 32-bit words: hi + lo half per weight
+  hipLaunchKernelGGL(pack_weight_winograd_f16x2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
+                     cout, cin, cout_pad, cin_pad / CF_BK, scale, reinterpret_cast<unsigned*>(packed), total);
+  CF_CHECK_LAUNCH("cf_pack_conv_weight_winograd_f16x2");
+  return CF_OK;
+}
 
 extern "C" int cf_pack_conv_weight_winograd(const float* w, int cout, int cin, int cout_pad, int cin_pad, float* packed,
                                             cf_stream_t stream) {
@@ -527,10 +612,17 @@ extern "C" int cf_pack_conv_weight_winograd(const float* w, int cout, int cin, i
   return CF_OK;
 }
 
+bool cf_wsplit_covers(const cf_conv_desc* d);                                        // cf_wsplit.hip: the eight-wave,
+int cf_wsplit_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query);  // 128-channel split-half form
+
 // Called by cf_conv2d (cf_igemm.hip) for descriptors with winograd != 0; the common argument checks have run there.
 int cf_winograd_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query) {
-  CF_REQUIRE(d->taps == 9 && d->stride == 1 && !d->upsample && !d->in_nchw && !d->out_nchw && d->bf16_mfma == CF_OPERAND_F32,
-             "cf_conv2d: winograd covers fp32 3x3 stride-1 NHWC convolutions");
+  CF_REQUIRE(d->taps == 9 && d->stride == 1 && !d->upsample && !d->in_nchw && !d->out_nchw &&
+                 (d->bf16_mfma == CF_OPERAND_F32 || d->bf16_mfma == CF_OPERAND_F16X2),
+             "cf_conv2d: winograd covers fp32 and split-half (f16x2) 3x3 stride-1 NHWC convolutions");
+  const bool h2 = d->bf16_mfma == CF_OPERAND_F16X2;
+  CF_REQUIRE(!h2 || d->acc_scale > 0.f, "cf_conv2d(winograd, f16x2): acc_scale must be the inverse of the pack-time weight scale (got %g)",
+             (double)d->acc_scale);
   CF_REQUIRE(d->hout % WG_TH == 0 && d->wout % WG_TW == 0, "cf_conv2d: winograd needs an output of %dx%d multiples (got %dx%d)",
              WG_TH, WG_TW, d->hout, d->wout);
   CF_REQUIRE(d->cout % 64 == 0 && d->cout_pad == d->cout, "cf_conv2d: winograd needs cout == cout_pad, a multiple of 64 (got %d / %d)", d->cout,
@@ -540,6 +632,7 @@ int cf_winograd_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_que
   CF_REQUIRE(d->pad_mode == CF_PAD_ZERO && (d->ld_in0 == 0 || d->ld_in0 == d->c0) && (d->ld_in1 == 0 || d->ld_in1 == d->c1) &&
                  (d->ld_out == 0 || d->ld_out == d->cout),
              "cf_conv2d: winograd reads / writes dense tensors with zero padding");
+  if (h2 && cf_wsplit_covers(d)) return cf_wsplit_launch(d, stream, parts_query);
   WinoArgs a;
   a.in0 = d->in0;
   a.in1 = d->in1;
@@ -561,6 +654,7 @@ int cf_winograd_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_que
   a.res = d->res;
   a.sft_scale = d->sft_scale;
   a.sft_w = d->sft_w;
+  a.acc_scale = h2 ? d->acc_scale : 1.f;
   a.out = d->out;
   a.stats_out = d->stats_out;
   a.stats_cpg = d->stats_cpg > 0 ? d->stats_cpg : 1;
@@ -580,17 +674,19 @@ int cf_winograd_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_que
                "cf_conv2d(winograd): split_k %d needs cin %% 128 == 0 and split_k dividing cin/128 = %d", d->split_k, V);
     CF_REQUIRE(d->split_k == 1 || (d->workspace && d->counters), "cf_conv2d(winograd): split_k > 1 needs workspace and counters");
   }
-  const void* kern = sk ? reinterpret_cast<const void*>(winograd_kernel<true>) : reinterpret_cast<const void*>(winograd_kernel<false>);
-  static unsigned long long attr_devs[2] = {0, 0};  // bit d: attribute set on device d (a per-device property), per instantiation
+  const void* const kerns[4] = {reinterpret_cast<const void*>(winograd_kernel<false, false>), reinterpret_cast<const void*>(winograd_kernel<true, false>),
+                                reinterpret_cast<const void*>(winograd_kernel<false, true>), reinterpret_cast<const void*>(winograd_kernel<true, true>)};
+  const int ki = (h2 ? 2 : 0) + (sk ? 1 : 0);
+  static unsigned long long attr_devs[4] = {0, 0, 0, 0};  // bit d: attribute set on device d (a per-device property), per instantiation
   int dev = 0;
   (void)hipGetDevice(&dev);
-  if (dev >= 64 || !((attr_devs[sk] >> dev) & 1ull)) {
-    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (dev >= 64 || !((attr_devs[ki] >> dev) & 1ull)) {
+    hipError_t e = hipFuncSetAttribute(kerns[ki], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       cf_set_error("cf_conv2d: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
       return CF_ERR_LAUNCH;
     }
-    if (dev < 64) attr_devs[sk] |= 1ull << dev;  // benign race: the attribute call is idempotent
+    if (dev < 64) attr_devs[ki] |= 1ull << dev;  // benign race: the attribute call is idempotent
   }
   const int tiles = a.tiles_per_img * d->batch * a.ntn;
   if (sk) {
@@ -599,9 +695,14 @@ int cf_winograd_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_que
     k.ws = d->workspace;
     k.counters = d->counters;
     k.nsplit = d->split_k;
-    hipLaunchKernelGGL(winograd_kernel<true>, dim3(tiles * d->split_k), dim3(256), lds, stream, k);
+    if (h2)
+      hipLaunchKernelGGL((winograd_kernel<true, true>), dim3(tiles * d->split_k), dim3(256), lds, stream, k);
+    else
+      hipLaunchKernelGGL((winograd_kernel<true, false>), dim3(tiles * d->split_k), dim3(256), lds, stream, k);
+  } else if (h2) {
+    hipLaunchKernelGGL((winograd_kernel<false, true>), dim3(tiles), dim3(256), lds, stream, a);
   } else {
-    hipLaunchKernelGGL(winograd_kernel<false>, dim3(tiles), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((winograd_kernel<false, false>), dim3(tiles), dim3(256), lds, stream, a);
   }
   CF_CHECK_LAUNCH("cf_conv2d(winograd)");
   return CF_OK;

@@ -61,7 +61,11 @@ def _cout_pad(cout):
 WINOGRAD = 3   # value of the operand-code argument that selects the Winograd F(2x2,3x3) fp32 evaluation
 SPLIT = 4      # ... the split-half evaluation: fp32 operands as hi + lo IEEE halves, 3 f16 MFMAs per product (cf_split.hip)
 SPLIT_DIRECT = 5   # ... the same, but layers the split kernel does not take run on the direct fp32 kernel instead of Winograd
-OPERAND_F16X2 = 3   # enum cf_operand value behind SPLIT
+WSPLIT = 6     # ... Winograd F(2x2,3x3) with split-half operands in the 16 transform-domain GEMMs (cf_winograd.hip, H2)
+OPERAND_F16X2 = 3   # enum cf_operand value behind SPLIT / WSPLIT
+# SPLIT layers that the Winograd kernel covers take its split-half form (4/9 of the MFMA work); CODEFORMER_HIP_SPLIT_WINOGRAD=0
+# keeps them on the direct split-half kernel.
+SPLIT_WINOGRAD = os.environ.get('CODEFORMER_HIP_SPLIT_WINOGRAD', '1') != '0'
 
 
 def split_ok(cin, cout, hin, win, c_split=None):
@@ -84,6 +88,8 @@ def conv_code(code, cin, cout, h, w, up2x=False, c_split=None, plain=True):
     on the per-image shape only (never on the batch), so results stay batch-invariant."""
     code = int(code)
     if code in (SPLIT, SPLIT_DIRECT):
+        if code == SPLIT and SPLIT_WINOGRAD and plain and not up2x and winograd_ok(cin, cout, h, w):
+            return WSPLIT
         if plain and split_ok(cin, cout, h, w, c_split) and h * w >= SPLIT_MIN_PIXELS:
             return SPLIT
         code = WINOGRAD if code == SPLIT else 0
@@ -111,6 +117,16 @@ def pack_weight(weight, bias=None, bf16=False, up2x=False, f16=False):
         L.check(lib.cf_pack_conv_weight_winograd(L.ptr(w), cout, cin, cout, cin, L.ptr(packed, dtype=None), L.stream_ptr()),
                 'cf_pack_conv_weight_winograd')
         return PackedWeight(packed, b, cout, cin, 9, cout, cin, wino=True)
+    if code == WSPLIT:
+        if up2x or w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or cin % 16 or cout % 64:
+            raise ValueError('winograd f16x2 packing needs a 3x3 weight with cin % 16 == 0 and cout % 64 == 0 (no up2x)')
+        G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w.device)
+        umax = float(torch.einsum('xi,ncij,yj->ncxy', G, w.double(), G).abs().max())
+        scale = 1.0 if umax == 0.0 or not math.isfinite(umax) else 2.0 ** (14 - math.frexp(umax)[1] + 1)
+        packed = torch.empty(16 * cin * cout, dtype=torch.float32, device=w.device)
+        L.check(lib.cf_pack_conv_weight_winograd_f16x2(L.ptr(w), cout, cin, cout, cin, scale, L.ptr(packed, dtype=None), L.stream_ptr()),
+                'cf_pack_conv_weight_winograd_f16x2')
+        return PackedWeight(packed, b, cout, cin, 9, cout, cin, bf16=OPERAND_F16X2, wino=True, scale=scale)
     if code == SPLIT:
         if w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or cin % 32 or cout % 64:
             raise ValueError('f16x2 packing needs a 3x3 weight with cin % 32 == 0 and cout % 64 == 0')
@@ -179,7 +195,7 @@ _COUNTERS = {}
 
 def splitk_for(pw, ho, wo, cin, batch=1):
     """Split count for a 1x1 / Linear or a Winograd 3x3 on `batch` images of ho x wo pixels; 0: the layer is not a split-K layer."""
-    if SPLITK_MAX <= 0 or pw.bf16 or ho * wo > 1024 or cin % 128:
+    if SPLITK_MAX <= 0 or (pw.bf16 and not pw.wino) or ho * wo > 1024 or cin % 128:
         return 0
     if pw.wino:
         if ho % 8 or wo % 16 or ho * wo > 256:   # the 16x16 latents only: from 32x32 up a batch fills the CUs without splitting

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 10
+#define CF_ABI_VERSION 11
 
 typedef void* cf_stream_t; /* hipStream_t */
 
@@ -142,8 +142,11 @@ typedef struct cf_conv_desc {
                              the same function in a different summation order.  Dense NHWC
                              tensors, zero padding, hout % 8 == 0, wout % 16 == 0, cout_pad % 64 == 0; prologues as the direct
                              kernel, epilogues none / residual / SFT, statistics supported.  Measured against fp64 its error
-                             is below the direct kernel's, so the host uses it for every eligible 3x3 stride-1 convolution */
-  float acc_scale;        /* CF_OPERAND_F16X2 only: the accumulator is multiplied by this before the bias is added -- the exact
+                             is below the direct kernel's, so the host uses it for every eligible 3x3 stride-1 convolution.
+                             With bf16_mfma == CF_OPERAND_F16X2 (`weight` from cf_pack_conv_weight_winograd_f16x2, acc_scale set)
+                             the 16 Winograd-domain GEMMs run on split operands: U and V as hi + lo IEEE halves, three f16
+                             MFMAs per product, fp32 accumulation -- 4/9 of the split-half MFMA work of the direct form */
+  float acc_scale;        /* CF_OPERAND_F16X2 only (direct or winograd): the accumulator is multiplied by this before the bias is added -- the exact
                              inverse of the power-of-two scale given to cf_pack_conv_weight_f16x2 (> 0) */
   /* Deterministic split-K for layers with few output tiles (one face: 16x16 .. 64x64 pixels), where latency is the serial K loop of
    * a workgroup: split_k workgroups share an output tile, each contracting a contiguous K range; partial accumulators meet in
@@ -171,6 +174,10 @@ int64_t cf_packed_weight_elems(int cin_pad, int taps, int cout_pad);
 /* Winograd-domain weights for cf_conv_desc.winograd: [16 positions][cin_pad/16][cout_pad][16] fp32 (16*cin_pad*cout_pad values),
  * U[xi*4+nu] = (G g G^T)[xi][nu] evaluated in fp64 and rounded once; cout_pad % 64 == 0 */
 int cf_pack_conv_weight_winograd(const float* w, int cout, int cin, int cout_pad, int cin_pad, float* packed, cf_stream_t stream);
+/* The same for winograd + CF_OPERAND_F16X2: scale * U as hi + lo IEEE halves in MFMA-operand order (16*cin_pad*cout_pad 32-bit
+ * words); `scale` is a power of two that puts max|scale * U| into [2^14, 2^15) (cf_conv_desc.acc_scale = 1 / scale) */
+int cf_pack_conv_weight_winograd_f16x2(const float* w, int cout, int cin, int cout_pad, int cin_pad, float scale, void* packed,
+                                       cf_stream_t stream);
 /* bf16 layout [tap][cin_pad/32][cout_pad][32] (round-to-nearest-even); cin_pad % 32 == 0, cout_pad % 64 == 0; the buffer
  * holds cf_packed_weight_elems(cin_pad, taps, cout_pad) bf16 values (half the bytes of the fp32 packing). */
 int cf_pack_conv_weight_bf16(const float* w, int cout, int cin, int taps, int cout_pad, int cin_pad, void* packed,

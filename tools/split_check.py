@@ -1,4 +1,5 @@
-"""Split-half conv kernel (cf_split.hip, CF_OPERAND_F16X2) vs an fp64 reference, next to the exact-fp32 kernels (accuracy + time).
+"""Split-half conv kernels (cf_split.hip direct form, cf_winograd.hip / cf_wsplit.hip Winograd form; CF_OPERAND_F16X2) vs an fp64
+reference, next to the exact-fp32 kernels (accuracy + time).
 GPU box only.  usage: python tools/split_check.py [quick]"""
 import os
 import sys
@@ -25,7 +26,8 @@ def t_ms(fn, n=10):
 
 def case(B, H, W, cin, cout, *, upsample=False, c_split=None, prologue=ops.PRO_NONE, epilogue=ops.EPI_NONE, stats=False, seed=0,
          timing=True, wscale=1.0, xscale=1.0, others=True):
-    """Returns (err_split, err_best_fp32_kernel, stats_rel_err, ref_absmax, mean_abs_err_split)."""
+    """Returns (err_split, err_best_fp32_kernel, stats_rel_err, ref_absmax, mean_abs_err_split, err_wsplit, stats_rel_err_wsplit);
+    the last two are NaN / 0 for shapes the Winograd form does not cover."""
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B, H, W, cin, generator=g) * xscale
     w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5 * wscale
@@ -65,6 +67,21 @@ def case(B, H, W, cin, cout, *, upsample=False, c_split=None, prologue=ops.PRO_N
     es, ems = float(d.max()), float(d.mean())
     msg = (f'B{B} {H}x{W} {cin}->{cout}{" up2x" if upsample else ""} pro{prologue} epi{epilogue}{" cat" if c_split else ""}: '
            f'split max {es:.2e} mean {ems:.2e}')
+    pw_w = None
+    ew, estw = float('nan'), 0.0
+    if not upsample and ops.winograd_ok(cin, cout, H, W):   # Winograd form of the split-half scheme (cf_winograd.hip, H2)
+        pw_w = ops.pack_weight(w.cuda(), b.cuda(), bf16=ops.WSPLIT)
+        yw = ops.conv2d(x1, pw_w, x2=x2, **kw)
+        dw = (yw.cpu().double() - ref).abs()
+        ew = float(dw.max())
+        msg += f' | wsplit max {ew:.2e} mean {float(dw.mean()):.2e}'
+        if stats:
+            sw = yw._cf_stats
+            tw = sw.part.view(B, 32, sw.parts, 2).sum(2)
+            r = yw.double().view(B, Ho * Wo, 32, sw.cpg)
+            want = torch.stack([r.sum((1, 3)), (r * r).sum((1, 3))], -1)
+            estw = float(((tw - want).abs() / want.abs().clamp_min(1e-6)).max())
+            msg += f' (stats {estw:.1e})'
     ef = float('nan')
     pw_f = None
     if others:
@@ -87,11 +104,14 @@ def case(B, H, W, cin, cout, *, upsample=False, c_split=None, prologue=ops.PRO_N
         ts_ = t_ms(lambda: ops.conv2d(x1, pw_s, x2=x2, **kw))
         fl = 2.0 * B * Ho * Wo * cout * cin * 9
         msg += f' | split {ts_:.3f} ms ({fl / ts_ / 1e9:.0f} TF-equiv)'
+        if pw_w is not None:
+            tw_ = t_ms(lambda: ops.conv2d(x1, pw_w, x2=x2, **kw))
+            msg += f' wsplit {tw_:.3f} ms ({fl / tw_ / 1e9:.0f}) x{ts_ / tw_:.2f}'
         if pw_f is not None:
             tf_ = t_ms(lambda: ops.conv2d(x1, pw_f, x2=x2, **kw))
             msg += f' fp32 {tf_:.3f} ms ({fl / tf_ / 1e9:.0f}) x{tf_ / ts_:.2f}'
     print(msg, flush=True)
-    return es, ef, est, float(ref.abs().max()), ems
+    return es, ef, est, float(ref.abs().max()), ems, ew, estw
 
 
 CASES = [dict(B=1, H=16, W=16, cin=32, cout=64),
@@ -103,6 +123,9 @@ CASES = [dict(B=1, H=16, W=16, cin=32, cout=64),
          dict(B=2, H=16, W=16, cin=128, cout=128, upsample=True, stats=True, seed=6),
          dict(B=1, H=32, W=16, cin=64, cout=64, upsample=True, seed=7),
          dict(B=1, H=32, W=32, cin=256, cout=128, c_split=128, prologue=ops.PRO_AFFINE_SWISH, stats=True, seed=8),
+         dict(B=2, H=32, W=48, cin=128, cout=128, prologue=ops.PRO_AFFINE_SWISH, epilogue=ops.EPI_RESIDUAL, stats=True, seed=21),   # 8-wave Winograd form
+         dict(B=1, H=32, W=32, cin=64, cout=256, c_split=32, prologue=ops.PRO_LEAKY, epilogue=ops.EPI_SFT, stats=True, seed=22),
+         dict(B=1, H=40, W=32, cin=32, cout=128, seed=23),                                                                          # two slabs
          # magnitudes: large / tiny weights and activations (the pack-time power-of-two scale must absorb them)
          dict(B=1, H=16, W=16, cin=64, cout=64, wscale=300.0, seed=9),
          dict(B=1, H=16, W=16, cin=64, cout=64, wscale=1e-4, xscale=30.0, seed=10)]

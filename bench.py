@@ -60,11 +60,12 @@ def build_net(device):
     return net.to(device), sd_cpu, weights
 
 
-def recorded_traffic(prefix='split_conv_kernel'):
+def recorded_traffic(prefixes=('wsplit_kernel',)):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_bench.json,
     produced by tools/pmc_bench.sh on this same bench step; bench.py cannot profile itself).  Per the MI355X guide:
     FETCH_SIZE / WRITE_SIZE are in KiB, and on gfx950 FETCH_SIZE reports half of the bytes of wide (16 B/lane) reads, so
-    bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024, launch-weighted over the kernels whose name starts with `prefix`."""
+    bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024, launch-weighted over the kernels whose name (without the
+    `void (anonymous namespace)::` decoration) starts with one of `prefixes`."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_bench.json')))
     if not files:
@@ -72,7 +73,8 @@ def recorded_traffic(prefix='split_conv_kernel'):
     d = json.load(open(files[-1]))
     n = tot = 0
     for k, v in d.items():
-        if k.startswith(prefix) and 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
+        name = k.replace('void ', '').replace('(anonymous namespace)::', '')
+        if name.startswith(tuple(prefixes)) and 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
             ln = v['FETCH_SIZE']['launches']
             n += ln
             tot += ln * (2.0 * v['FETCH_SIZE']['mean'] + v['WRITE_SIZE']['mean']) * 1024.0
@@ -111,15 +113,18 @@ def roofline_leg(net, x, w):
         for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1])}
     # kind -> (kernel, MFMA FLOPs executed per algorithmic FLOP booked by ops.conv2d, dense MFMA peak of the type it issues)
     KINDS = {
-        'conv3x3_f16x2': ('split_conv_kernel<9,...> (3x3 s1, fp32 operands as hi+lo halves: 3 f16 MFMAs per product, fp32 accumulate)', 3.0, F16_MFMA_PEAK_TFLOPS, 'split_conv_kernel<9'),
-        'conv_up2x_f16x2': ('split_conv_kernel<4,...> (nearest-x2 + 3x3 folded to 2x2 sub-pixel taps, split halves)', 3.0, F16_MFMA_PEAK_TFLOPS, 'split_conv_kernel<4'),
-        'conv3x3_wino': ('winograd_kernel<.,false> (3x3 s1 as Winograd F(2x2,3x3), fp32 MFMA)', 4.0 / 9.0, FP32_MFMA_PEAK_TFLOPS, 'winograd_kernel'),
-        'conv3x3_wino_f16x2': ('winograd_kernel<.,true> (3x3 s1 as Winograd F(2x2,3x3); U and V as hi+lo halves: 3 f16 MFMAs per '
-                               'transform-domain product, fp32 accumulate)', 3.0 * 4.0 / 9.0, F16_MFMA_PEAK_TFLOPS, 'winograd_kernel'),
-        'conv3x3': ('igemm_kernel<9,1,...> (direct 3x3 s1 implicit GEMM, fp32 MFMA)', 1.0, FP32_MFMA_PEAK_TFLOPS, 'igemm_kernel<9, 1'),
-        'conv_up2x': ('igemm_kernel<4,1,...> (folded nearest-x2 + 3x3, fp32 MFMA)', 1.0, FP32_MFMA_PEAK_TFLOPS, 'igemm_kernel<4, 1'),
-        'conv3x3_s2': ('igemm_kernel<9,2,...> (3x3 stride 2, fp32 MFMA)', 1.0, FP32_MFMA_PEAK_TFLOPS, 'igemm_kernel<9, 2'),
-        'gemm1x1': ('igemm_kernel<1,1,...> (1x1 conv / Linear, fp32 MFMA)', 1.0, FP32_MFMA_PEAK_TFLOPS, 'igemm_kernel<1, 1'),
+        'conv3x3_f16x2': ('split_conv_kernel<9,...> (3x3 s1, fp32 operands as hi+lo halves: 3 f16 MFMAs per product, fp32 accumulate)', 3.0, F16_MFMA_PEAK_TFLOPS, ('split_conv_kernel<9',)),
+        'conv_up2x_f16x2': ('split_conv_kernel<4,...> (nearest-x2 + 3x3 folded to 2x2 sub-pixel taps, split halves)', 3.0, F16_MFMA_PEAK_TFLOPS, ('split_conv_kernel<4',)),
+        'conv3x3_wino': ('winograd_kernel<.,false> (3x3 s1 as Winograd F(2x2,3x3), fp32 MFMA)', 4.0 / 9.0, FP32_MFMA_PEAK_TFLOPS, ('winograd_kernel<false, false', 'winograd_kernel<true, false')),
+        'conv3x3_wino_f16x2_8w': ('wsplit_kernel (3x3 s1 as Winograd F(2x2,3x3), 128 channels per 8-wave workgroup; U and V as hi+lo halves: 3 f16 '
+                                  'MFMAs per transform-domain product, fp32 accumulate)', 3.0 * 4.0 / 9.0, F16_MFMA_PEAK_TFLOPS, ('wsplit_kernel',)),
+        'conv3x3_wino_f16x2': ('winograd_kernel<.,true> (the same on the four-wave 64-channel kernel: 64-channel layers and the 16x16 latents)',
+                               3.0 * 4.0 / 9.0, F16_MFMA_PEAK_TFLOPS, ('winograd_kernel<false, true', 'winograd_kernel<true, true')),
+        'conv3x3': ('igemm_kernel<9,1,...> (direct 3x3 s1 implicit GEMM, fp32 MFMA)', 1.0, FP32_MFMA_PEAK_TFLOPS, ('igemm_kernel<9, 1',)),
+        'conv3x3_io': ('conv3x3_few_cin / conv3x3_few_cout (3->64 and 64->3 at 512x512 on the vector ALU: write- / read-bound)', 0.0, HBM_PEAK_GBS, ('conv3x3_few_c',)),
+        'conv_up2x': ('igemm_kernel<4,1,...> (folded nearest-x2 + 3x3, fp32 MFMA)', 1.0, FP32_MFMA_PEAK_TFLOPS, ('igemm_kernel<4, 1',)),
+        'conv3x3_s2': ('igemm_kernel<9,2,...> (3x3 stride 2, fp32 MFMA)', 1.0, FP32_MFMA_PEAK_TFLOPS, ('igemm_kernel<9, 2',)),
+        'gemm1x1': ('igemm_kernel<1,1,...> (1x1 conv / Linear, fp32 MFMA)', 1.0, FP32_MFMA_PEAK_TFLOPS, ('igemm_kernel<1, 1',)),
     }
 
     def entry(kind):
@@ -127,15 +132,19 @@ def roofline_leg(net, x, w):
         the dense peak of the MFMA type used; the convolution's algorithmic rate (2*taps*Cin*Cout per output pixel)
         is reported separately as `effective_tflops` (it exceeds `achieved` for Winograd, which executes 4/9 of those
         multiplies, and is a third of it for the split-half kernel, which issues 3 MFMAs per product)."""
-        name, ratio, peak, pmc = KINDS.get(kind, (kind, 1.0, F16_MFMA_PEAK_TFLOPS if kind.endswith(('_f16', '_bf16')) else FP32_MFMA_PEAK_TFLOPS, 'igemm_kernel<9, 1'))
+        name, ratio, peak, pmc = KINDS.get(kind, (kind, 1.0, F16_MFMA_PEAK_TFLOPS if kind.endswith(('_f16', '_bf16')) else FP32_MFMA_PEAK_TFLOPS, ('igemm_kernel<9, 1',)))
         c = agg[kind]
+        common = {'avg_launch_ms': round(c[2] / c[3] * 1e3, 4), 'launches_per_step': c[3] // reps,
+                  'algorithmic_gflop_per_step': round(c[0] / reps / 1e9, 1), 'ms_per_step': round(c[2] / reps * 1e3, 2),
+                  'alg_bytes_per_launch': round(c[1] / c[3]), 'frac_hbm_peak_alg_bytes': round(c[1] / c[2] / 1e9 / HBM_PEAK_GBS, 4),
+                  'traffic': recorded_traffic(pmc)}
+        if ratio == 0.0:   # no MFMA: algorithmic bytes / duration against the HBM peak
+            gbs = c[1] / c[2] / 1e9
+            return {'bound': 'hbm', 'kernel': name, 'achieved': round(gbs, 1), 'peak': peak, 'unit': 'GB/s', 'frac': round(gbs / peak, 4), **common}
         alg = c[0] / c[2] / 1e12
         ach = alg * ratio
         return {'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                'frac': round(ach / peak, 4), 'effective_tflops': round(alg, 2), 'executed_per_algorithmic_flop': round(ratio, 4),
-                'avg_launch_ms': round(c[2] / c[3] * 1e3, 4), 'launches_per_step': c[3] // reps,
-                'algorithmic_gflop_per_step': round(c[0] / reps / 1e9, 1), 'ms_per_step': round(c[2] / reps * 1e3, 2),
-                'alg_bytes_per_launch': round(c[1] / c[3]), 'traffic': recorded_traffic(pmc)}
+                'frac': round(ach / peak, 4), 'effective_tflops': round(alg, 2), 'executed_per_algorithmic_flop': round(ratio, 4), **common}
 
     order = sorted(agg, key=lambda k: -agg[k][2])
     roof = entry(order[0])                                   # the dominant kernel = the kind with the largest summed duration

@@ -318,8 +318,12 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
                     + (0 if res is None else res.numel()) + (0 if sft_scale is None else sft_scale.numel()))
     kind = ('conv3x3_s2' if stride == 2 else ('conv_up2x' if upsample else ('conv3x3_wino' if pw.wino else 'conv3x3'))) \
         if pw.taps == 9 else 'gemm1x1'
+    if pw.taps == 9 and stride == 1 and ((in_nchw and c0 <= 4) or (out_nchw and pw.cout <= 4)):
+        kind = 'conv3x3_io'   # the network's first / last conv: vector-ALU kernels, HBM-bound (conv3x3_few_cin / few_cout)
     if pw.bf16:
         kind += ('', '_bf16', '_f16', '_f16x2')[int(pw.bf16)]
+    if pw.wino and pw.bf16 and pw.cout % 128 == 0 and Ho * Wo >= 1024 and not split_k:
+        kind += '_8w'      # the eight-wave 128-channel kernel (cf_wsplit.hip; the rule of cf_wsplit_covers)
     PROFILE.append((kind, flops, nbytes, e0, e1, (B, H, W, cin, pw.cout)))
     return out
 

@@ -21,7 +21,7 @@ for f in sorted(glob.glob('/tmp/ps*/**/*counter_collection.csv', recursive=True)
     seen = set()
     for r in csv.DictReader(open(f)):
         name = r['Kernel_Name']
-        if 'split_conv' in name or 'winograd' in name or 'igemm' in name:
+        if 'split_conv' in name or 'winograd' in name or 'igemm' in name or 'wsplit' in name:
             key = name.replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0][:64]
             agg[key][r['Counter_Name']].append(float(r['Counter_Value']))
             if (f, r['Dispatch_Id']) not in seen:

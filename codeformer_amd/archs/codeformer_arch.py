@@ -161,9 +161,11 @@ class CodeFormer(VQAutoEncoder):
 
         # Operand format of the 3x3 stride-1 convolutions.  Tensors, accumulation, the Transformer and the code argmax are fp32 in every mode.
         #   'f16x2' (default): fp32 operands split into hi + lo IEEE halves (22 significant bits), three f16 MFMAs per product, fp32
-        #            accumulation (cf_split.hip), for generator, CFT and -- see encoder_precision -- the encoder.  Per layer 1-2x the
-        #            fp64-error of the exact kernels; whole network vs the reference 5.7e-5 on real crops (exact path: 5.6e-5;
-        #            tolerance 1e-3), logits 8.0e-6 (exact: 7.8e-6; tolerance 1e-4), code indices identical.  1.45x the exact path's faces/s.
+        #            accumulation, in the Winograd F(2x2,3x3) domain where the layer allows it (cf_wsplit.hip / cf_winograd.hip H2; folded
+        #            upsample convs: cf_split.hip), for generator, CFT and -- see encoder_precision -- the encoder.  Per layer at or below
+        #            the fp64-error of the exact kernels; whole network vs the reference on real crops: pixels 7.2e-5 (exact path
+        #            7.1e-5; tolerance 1e-3), logits 6.7e-6 (exact: 7.6e-6; tolerance 1e-4), code indices identical.  1.5x the exact
+        #            path's faces/s.
         #   'fp32':  everything on exact fp32 MFMA (Winograd F(2x2,3x3) where eligible, see below).
         #   'bf16' (BASELINE configs 3/5) / 'fp16': single 16-bit operands with fp32 accumulate in generator + CFT, encoder exact fp32
         #            (pixel gates in tests/test_gpu_real_images.py).
@@ -183,9 +185,9 @@ class CodeFormer(VQAutoEncoder):
         # split-half kernel on every layer it covers: all but the first conv and the 16x16 latents) or 'auto' = 'f16x2' when
         # precision is 'f16x2', 'fp32' otherwise.  The code indices hang on the encoder, so this was measured before it became the
         # default (tools/encoder_split_check.py, profiles/r02_encoder_split_check.txt): against the reference's logits on its own
-        # crops the split encoder is as close as the exact one (max 8.0e-6 / 6.3e-6 / 6.6e-6 vs 7.8e-6 / 6.5e-6 / 5.7e-6; the
+        # crops the split encoder is as close as the exact one (max 6.7e-6 / 5.4e-6 / 5.7e-6 vs 7.6e-6 / 5.5e-6 / 6.0e-6; the
         # reference's own 1-vs-8-thread noise is 2.6e-6), the smallest (reference top-2 gap) / (2 x our logit error) over all tokens
-        # is 7.1 (exact: 7.3), and every index of every golden agrees.  Set 'fp32' to keep logits bitwise equal across precisions.
+        # is 9.1 (exact: 8.8), and every index of every golden agrees.  Set 'fp32' to keep logits bitwise equal across precisions.
         self.encoder_precision = os.environ.get('CODEFORMER_HIP_ENCODER_PRECISION', 'auto')
         # Optional HIP-graph replay of the whole forward (one graph per input shape / w / flags): takes the ~250 host launches
         # per call off the critical path.  Measured: no gain at B=1..16 on an otherwise idle host (the kernels, not the launches,

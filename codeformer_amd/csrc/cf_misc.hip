@@ -285,6 +285,90 @@ __global__ void fused_bias_act_kernel(const float* __restrict__ x, const float* 
   }
 }
 
+// ---- fused_bias_act with every mode of the reference op (fused_bias_act_kernel.cu:20-50): act 1 (linear) | 3 (leaky ReLU), grad 0 (forward) |
+// 1 (first derivative, gated by the sign of `ref` = the forward OUTPUT) | 2 (second derivative: zero); element types float / IEEE half /
+// bf16 (the arithmetic is done in the element type's values converted to float and rounded once on the way out, like scalar_t = half) ----
+template <typename T>
+__device__ __forceinline__ float fba_load(const T* p, long i) { return (float)p[i]; }
+template <typename T>
+__device__ __forceinline__ void fba_store(T* p, long i, float v) { p[i] = (T)v; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void fused_bias_act_ex_kernel(const T* __restrict__ x, const T* __restrict__ bias, const T* __restrict__ ref,
+                                                                long numel, int c, int hw, int mode, float alpha, float scale,
+                                                                T* __restrict__ y) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += stride) {
+    float v = fba_load(x, i);
+    if (bias) v = (float)(T)(v + fba_load(bias, (i / hw) % c));  // (x += b in scalar_t)
+    const float r = ref ? fba_load(ref, i) : 0.f;
+    float o;
+    switch (mode) {
+      case 12:
+      case 32: o = 0.f; break;
+      case 30: o = v > 0.f ? v : (float)(T)(v * alpha); break;
+      case 31: o = r > 0.f ? v : (float)(T)(v * alpha); break;
+      default: o = v; break;  // 10, 11 and anything else: linear
+    }
+    fba_store(y, i, o * scale);
+  }
+}
+
+// ---- upfirdn2d, LDS-tiled (upfirdn2d_kernel.cu:108-208 is the reference's tiled kernel, :251-291 its six (up, down, taps) configurations) --
+// A workgroup of 256 threads owns a TH x TW tile of one output plane: the input rows / columns the tile's polyphase taps touch are staged
+// in LDS with row-contiguous (coalesced) loads, the flipped FIR kernel sits in LDS zero-padded to K + UP taps per axis so the tap loops
+// have compile-time trip counts and no guards, and a thread computes TW / 64 ... outputs of a row.  Planes are [nplanes][h][w] (W
+// contiguous); tile sizes follow the reference's choice (16 x 64 outputs, 8 x 32 for the decimating configurations).
+template <int UP, int DOWN, int K, int TH, int TW>
+__global__ __launch_bounds__(256) void upfirdn2d_tiled_kernel(const float* __restrict__ x, int in_h, int in_w, const float* __restrict__ k,
+                                                              int kh, int kw, int pad_x0, int pad_y0, int out_h, int out_w,
+                                                              float* __restrict__ y, int tiles_x, int tiles_y) {
+  constexpr int IN_H = ((TH - 1) * DOWN + K - 1) / UP + 2;
+  constexpr int IN_W = ((TW - 1) * DOWN + K - 1) / UP + 2;
+  constexpr int KP = K + UP;         // padded taps per axis
+  constexpr int NT = (K + UP - 1) / UP;  // input samples an output touches per axis
+  __shared__ float sx[IN_H][IN_W + 1];
+  __shared__ float sk[KP][KP];
+  const int tid = threadIdx.x;
+  int t = blockIdx.x;
+  const int tx = t % tiles_x;
+  t /= tiles_x;
+  const int ty = t % tiles_y;
+  const int plane = t / tiles_y;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  for (int i = tid; i < KP * KP; i += 256) {
+    const int ky = i / KP, kx = i - ky * KP;
+    sk[ky][kx] = (ky < kh && kx < kw) ? k[(kh - 1 - ky) * kw + (kw - 1 - kx)] : 0.f;  // flipped FIR kernel, zero beyond its taps
+  }
+  // first input row / column any output of the tile can touch: ceil((o0 * DOWN - pad) / UP)
+  const int by0 = oy0 * DOWN - pad_y0, bx0 = ox0 * DOWN - pad_x0;
+  const int iy0 = (by0 + UP - 1 >= 0) ? (by0 + UP - 1) / UP : -((-(by0 + UP - 1) + UP - 1) / UP);
+  const int ix0 = (bx0 + UP - 1 >= 0) ? (bx0 + UP - 1) / UP : -((-(bx0 + UP - 1) + UP - 1) / UP);
+  const float* xp = x + (size_t)plane * in_h * in_w;
+  for (int i = tid; i < IN_H * IN_W; i += 256) {
+    const int ry = i / IN_W, rx = i - ry * IN_W;
+    const int iy = iy0 + ry, ix = ix0 + rx;
+    sx[ry][rx] = (iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) ? xp[(size_t)iy * in_w + ix] : 0.f;
+  }
+  __syncthreads();
+  for (int o = tid; o < TH * TW; o += 256) {
+    const int ry = o / TW, rx = o - ry * TW;
+    const int oy = oy0 + ry, ox = ox0 + rx;
+    if (oy >= out_h || ox >= out_w) continue;
+    const int by = oy * DOWN - pad_y0, bx = ox * DOWN - pad_x0;
+    const int ky0 = ((-by) % UP + UP) % UP, kx0 = ((-bx) % UP + UP) % UP;  // first tap that lands on a real sample
+    // (by + ky0) is a multiple of UP; exact division also for negatives
+    const int sy = (by + ky0 >= 0 ? (by + ky0) / UP : -((-(by + ky0)) / UP)) - iy0;
+    const int sxx = (bx + kx0 >= 0 ? (bx + kx0) / UP : -((-(bx + kx0)) / UP)) - ix0;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int i = 0; i < NT; ++i) acc += sx[sy + j][sxx + i] * sk[ky0 + j * UP][kx0 + i * UP];
+    y[((size_t)plane * out_h + oy) * out_w + ox] = acc;
+  }
+}
+
 __global__ void upfirdn2d_kernel(const float* __restrict__ x, int in_h, int in_w, const float* __restrict__ k, int kh,
                                  int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_y0, int out_h,
                                  int out_w, float* __restrict__ y, long total) {
@@ -435,6 +519,37 @@ extern "C" int cf_fused_bias_act(const float* x, const float* bias, int64_t nume
   return CF_OK;
 }
 
+extern "C" int cf_fused_bias_act_ex(const void* x, const void* bias, const void* ref, int64_t numel, int c, int hw, int act, int grad,
+                                    float alpha, float scale, int dtype, void* y, cf_stream_t stream) {
+  CF_REQUIRE(x && y && numel > 0 && c > 0 && hw > 0, "cf_fused_bias_act_ex: bad args");
+  CF_REQUIRE((act == 1 || act == 3) && grad >= 0 && grad <= 2, "cf_fused_bias_act_ex: act must be 1 (linear) or 3 (leaky ReLU), grad 0..2 (got %d, %d)",
+             act, grad);
+  CF_REQUIRE(grad != 1 || act != 3 || ref, "cf_fused_bias_act_ex: the leaky-ReLU derivative needs ref (the forward output)");
+  long blocks = (numel + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  const int mode = act * 10 + grad;
+  hipStream_t st = (hipStream_t)stream;
+  switch (dtype) {
+    case 0:
+      hipLaunchKernelGGL(fused_bias_act_ex_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, (const float*)bias,
+                         (const float*)ref, (long)numel, c, hw, mode, alpha, scale, (float*)y);
+      break;
+    case 1:
+      hipLaunchKernelGGL(fused_bias_act_ex_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, st, (const _Float16*)x,
+                         (const _Float16*)bias, (const _Float16*)ref, (long)numel, c, hw, mode, alpha, scale, (_Float16*)y);
+      break;
+    case 2:
+      hipLaunchKernelGGL(fused_bias_act_ex_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, st, (const __bf16*)x, (const __bf16*)bias,
+                         (const __bf16*)ref, (long)numel, c, hw, mode, alpha, scale, (__bf16*)y);
+      break;
+    default:
+      cf_set_error("cf_fused_bias_act_ex: dtype %d (0 float, 1 half, 2 bf16)", dtype);
+      return CF_ERR_ARG;
+  }
+  CF_CHECK_LAUNCH("cf_fused_bias_act_ex");
+  return CF_OK;
+}
+
 extern "C" int cf_upfirdn2d(const float* x, int nplanes, int in_h, int in_w, const float* kernel, int kh, int kw, int up_x,
                             int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, float* y,
                             cf_stream_t stream) {
@@ -443,6 +558,32 @@ extern "C" int cf_upfirdn2d(const float* x, int nplanes, int in_h, int in_w, con
   const int out_h = (in_h * up_y + pad_y0 + pad_y1 - kh) / down_y + 1;
   const int out_w = (in_w * up_x + pad_x0 + pad_x1 - kw) / down_x + 1;
   CF_REQUIRE(out_h > 0 && out_w > 0, "cf_upfirdn2d: empty output");
+  // the six tiled configurations: (up, down) in {(1,1), (2,1), (1,2)} x two tap classes; everything else: the general polyphase kernel
+  hipStream_t st = (hipStream_t)stream;
+  if (up_x == up_y && down_x == down_y && kh <= 4 && kw <= 4) {
+#define CF_UPFIRDN_TILED(UP, DOWN, K, TH, TW)                                                                                      \
+  {                                                                                                                                 \
+    const int tiles_x = (out_w + TW - 1) / TW, tiles_y = (out_h + TH - 1) / TH;                                                     \
+    hipLaunchKernelGGL((upfirdn2d_tiled_kernel<UP, DOWN, K, TH, TW>), dim3((unsigned)((long)tiles_x * tiles_y * nplanes)), dim3(256), \
+                       0, st, x, in_h, in_w, kernel, kh, kw, pad_x0, pad_y0, out_h, out_w, y, tiles_x, tiles_y);                    \
+    CF_CHECK_LAUNCH("cf_upfirdn2d");                                                                                                \
+    return CF_OK;                                                                                                                   \
+  }
+    const bool small3 = kh <= 3 && kw <= 3, small2 = kh <= 2 && kw <= 2;
+    if (up_x == 1 && down_x == 1) {
+      if (small3) CF_UPFIRDN_TILED(1, 1, 3, 16, 64)
+      CF_UPFIRDN_TILED(1, 1, 4, 16, 64)
+    }
+    if (up_x == 2 && down_x == 1) {
+      if (small2) CF_UPFIRDN_TILED(2, 1, 2, 16, 64)
+      CF_UPFIRDN_TILED(2, 1, 4, 16, 64)
+    }
+    if (up_x == 1 && down_x == 2) {
+      if (small2) CF_UPFIRDN_TILED(1, 2, 2, 8, 32)
+      CF_UPFIRDN_TILED(1, 2, 4, 8, 32)
+    }
+#undef CF_UPFIRDN_TILED
+  }
   const long total = (long)nplanes * out_h * out_w;
   hipLaunchKernelGGL(upfirdn2d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, in_h,
                      in_w, kernel, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0, out_h, out_w, y, total);

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('CF_LIB_PATH') or os.path.join(_PKG, 'libcodeformer_hi
 
 c_float_p = ctypes.c_void_p  # device pointers are passed as integers
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 PRO_NONE, PRO_AFFINE, PRO_AFFINE_SWISH, PRO_LEAKY = 0, 1, 2, 3
 EPI_NONE, EPI_RESIDUAL, EPI_SFT, EPI_GELU, EPI_LEAKY, EPI_AXPY, EPI_AXPY2 = 0, 1, 2, 3, 4, 5, 6
 PAD_ZERO, PAD_REFLECT, PAD_EDGE = 0, 1, 2
@@ -80,6 +80,7 @@ SIGNATURES = {
     'cf_tensor_to_img_u8': (_I, [_P, _I, _I, _I, _P, _P]),
     'cf_mask_composite': (_I, [_P, _P, _I, _I, _I, _P, _P]),
     'cf_fused_bias_act': (_I, [_P, _P, _L, _I, _I, _F, _F, _P, _P]),
+    'cf_fused_bias_act_ex': (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _F, _F, _I, _P, _P]),
     'cf_upfirdn2d': (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'cf_warp_affine_u8': (_I, [_P, _L, _I, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'cf_warp_affine_f32': (_I, [_P, _I, _I, ctypes.POINTER(ctypes.c_double), _P, _I, _I, _I, _I, _P]),

@@ -503,16 +503,30 @@ def mask_composite(x, y):
     return out
 
 
-def fused_bias_act(x, bias, negative_slope=0.2, scale=math.sqrt(2.0)):
-    """x: (N,C,...) NCHW-style contiguous; y = leaky_relu(x + bias[c]) * scale."""
+_FBA_DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+def fused_bias_act(x, bias, negative_slope=0.2, scale=math.sqrt(2.0), ref=None, act=3, grad=0):
+    """x: (N,C,...) NCHW-style; every mode of the reference op (fused_bias_act_kernel.cu:20-50): act 1 linear | 3 leaky ReLU; grad 0
+    forward y = act(x + bias[c]) * scale, 1 first derivative gated by the sign of `ref` (the forward output), 2 zeros.
+    float32 / float16 / bfloat16; bias / ref may be None (or empty, as the reference passes them)."""
     lib = L.load()
-    x = _f32(x).contiguous()
+    if x.dtype not in _FBA_DTYPES:
+        raise TypeError(f'fused_bias_act: float32 / float16 / bfloat16 tensors (got {x.dtype})')
+    x = x.contiguous()
+    bias = None if bias is None or bias.numel() == 0 else bias.detach().to(x.dtype).contiguous()
+    ref = None if ref is None or ref.numel() == 0 else ref.detach().to(x.dtype).contiguous()
+    if ref is not None and ref.shape != x.shape:
+        raise ValueError('fused_bias_act: ref must have the shape of x')
+    if bias is not None and bias.numel() != x.shape[1]:
+        raise ValueError('fused_bias_act: bias must have one value per channel (dim 1)')
     hw = 1
     for s in x.shape[2:]:
         hw *= s
     y = torch.empty_like(x)
-    L.check(lib.cf_fused_bias_act(L.ptr(x), L.ptr(bias), x.numel(), x.shape[1], hw, float(negative_slope), float(scale),
-                                  L.ptr(y), L.stream_ptr()), 'cf_fused_bias_act')
+    L.check(lib.cf_fused_bias_act_ex(x.data_ptr(), 0 if bias is None else bias.data_ptr(), 0 if ref is None else ref.data_ptr(),
+                                     x.numel(), x.shape[1] if x.dim() > 1 else 1, hw, int(act), int(grad), float(negative_slope),
+                                     float(scale), _FBA_DTYPES[x.dtype], y.data_ptr(), L.stream_ptr()), 'cf_fused_bias_act_ex')
     return y
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 11
+#define CF_ABI_VERSION 12
 
 typedef void* cf_stream_t; /* hipStream_t */
 
@@ -267,9 +267,16 @@ int cf_mask_composite(const float* x, const float* y, int batch, int h, int w, f
 /* ---- bundled StyleGAN2 ops of basicsr/ops (unused by the hot path) ---------------
  * cf_fused_bias_act: basicsr/ops/fused_act/src/fused_bias_act_kernel.cu:20-50 forward (act=3, grad=0):
  *    y = leaky_relu(x + bias[(i / hw) % c], slope) * scale                     (x is NCHW)
- * cf_upfirdn2d: basicsr/ops/upfirdn2d/src/upfirdn2d_kernel.cu:50-208: planes [nplanes][in_h][in_w]. */
+ * cf_fused_bias_act_ex: every mode of the op (:36-46, the switch on act*10 + grad): act 1 linear | 3 leaky ReLU(alpha); grad 0 forward,
+ *    1 first derivative (y = ref > 0 ? x : x*alpha, ref = the forward OUTPUT, fused_act.py:33,47), 2 second derivative (0); bias
+ *    and ref may be NULL; dtype 0 float | 1 IEEE half | 2 bf16 for x / bias / ref / y alike (AT_DISPATCH_FLOATING_TYPES_AND_HALF, :80)
+ * cf_upfirdn2d: basicsr/ops/upfirdn2d/src/upfirdn2d_kernel.cu:50-208: planes [nplanes][in_h][in_w].  The reference's six tiled
+ *    configurations (:251-291: (up, down) in {(1,1), (2,1), (1,2)}, taps <= 4 / <= 3 or 2) run an LDS-tiled kernel, everything else
+ *    the general polyphase kernel (:50-106). */
 int cf_fused_bias_act(const float* x, const float* bias, int64_t numel, int c, int hw, float slope, float scale,
                       float* y, cf_stream_t stream);
+int cf_fused_bias_act_ex(const void* x, const void* bias, const void* ref, int64_t numel, int c, int hw, int act, int grad, float alpha,
+                         float scale, int dtype, void* y, cf_stream_t stream);
 int cf_upfirdn2d(const float* x, int nplanes, int in_h, int in_w, const float* kernel, int kh, int kw, int up_x,
                  int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, float* y,
                  cf_stream_t stream);

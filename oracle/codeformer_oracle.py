@@ -353,6 +353,23 @@ def fused_bias_act(x, bias, negative_slope=0.2, scale=2 ** 0.5):
     return F.leaky_relu(x + bias.view(*shape), negative_slope) * scale
 
 
+def fused_bias_act_modes(x, bias, ref, act, grad, alpha, scale):
+    """Every mode of the op (fused_bias_act_kernel.cu:26-47): x += bias[channel]; act*10+grad: 10/11 y = x, 12/32 y = 0,
+    30 y = x > 0 ? x : x*alpha, 31 y = ref > 0 ? x : x*alpha; out = y*scale.  Arithmetic in x's dtype, as scalar_t."""
+    if bias is not None:
+        x = x + bias.view(*([1, -1] + [1] * (x.dim() - 2)))
+    mode = act * 10 + grad
+    if mode in (12, 32):
+        y = torch.zeros_like(x)
+    elif mode == 30:
+        y = torch.where(x > 0, x, x * alpha)
+    elif mode == 31:
+        y = torch.where(ref > 0, x, x * alpha)
+    else:
+        y = x
+    return y * scale
+
+
 def upfirdn2d(inp, kernel, up=1, down=1, pad=(0, 0)):
     """upfirdn2d restatement following upfirdn2d_native
     (basicsr/ops/upfirdn2d/upfirdn2d.py:156-186); input (N,C,H,W), square up/down,

@@ -82,6 +82,52 @@ def test_bundled_ops(chk):
     k3 = seeded_randn((3, 3), 4)
     assert torch.allclose(upfirdn2d(x.cuda(), k3.cuda(), up=3, down=2, pad=(2, 2)).cpu(),
                           O.upfirdn2d(x, k3, up=3, down=2, pad=(2, 2)), atol=2e-6)
+    # the six LDS-tiled configurations (upfirdn2d_kernel.cu:251-291) on planes that span several tiles with ragged edges
+    xl = seeded_randn((2, 3, 37, 150), 5)
+    for up, down, ks, pads in ((1, 1, (4, 3), ((1, 2), (0, 0), (-2, 3))), (2, 1, (4, 2), ((2, 1), (0, 3))), (1, 2, (4, 2), ((1, 1), (0, 2), (-1, 0)))):
+        for kk in ks:
+            kern = seeded_randn((kk, kk), 10 + kk)
+            for pad in pads:
+                got = ops.upfirdn2d(xl.cuda(), kern.cuda(), up=up, down=down, pad=pad).cpu()
+                ref = O.upfirdn2d(xl, kern, up=up, down=down, pad=pad)
+                assert got.shape == ref.shape and torch.allclose(got, ref, atol=3e-6), (up, down, kk, pad)
+
+
+def test_fused_bias_act_every_mode_dtype_and_autograd(chk):
+    """cf_fused_bias_act_ex: the act*10+grad switch of fused_bias_act_kernel.cu:36-46 in float / half / bf16 against the oracle's
+    restatement in the same dtype, and FusedLeakyReLU's first and second derivatives (fused_act.py:25-71) against torch autograd of
+    the plain formula."""
+    import torch
+    from codeformer_amd import ops
+    from oracle import codeformer_oracle as O
+    from oracle.synth import seeded_randn
+    from basicsr.ops.fused_act import FusedLeakyReLU, fused_leaky_relu
+    x, b, r = seeded_randn((3, 6, 5, 7), 11), seeded_randn((6,), 12), seeded_randn((3, 6, 5, 7), 13)
+    for dt, tol in ((torch.float32, 1e-6), (torch.float16, 2e-3), (torch.bfloat16, 2e-2)):
+        for act in (1, 3):
+            for grad in (0, 1, 2):
+                for bias in (b, None):
+                    got = ops.fused_bias_act(x.to(dt).cuda(), None if bias is None else bias.to(dt).cuda(), 0.2, 1.5, ref=r.to(dt).cuda(), act=act, grad=grad)
+                    ref = O.fused_bias_act_modes(x.to(dt), None if bias is None else bias.to(dt), r.to(dt), act, grad, 0.2, 1.5)
+                    assert got.dtype == dt and torch.allclose(got.float().cpu(), ref.float(), atol=tol, rtol=tol), (dt, act, grad)
+    xg = x.clone().cuda().requires_grad_(True)
+    m = FusedLeakyReLU(6).cuda()
+    m.load_state_dict({'bias': b})
+    y = m(xg)
+    go = seeded_randn(tuple(y.shape), 14).cuda()
+    gx, gb = torch.autograd.grad(y, (xg, m.bias), go, create_graph=True)
+    xr, br = x.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = O.fused_bias_act(xr, br)
+    gxr, gbr = torch.autograd.grad(yr, (xr, br), go.cpu())
+    assert torch.allclose(y.detach().cpu(), yr.detach(), atol=1e-6)
+    assert torch.allclose(gx.detach().cpu(), gxr, atol=1e-6) and torch.allclose(gb.detach().cpu(), gbr, atol=1e-4)
+    # second order: d/d(grad_output) of <grad_input, v> is the same gate applied to v
+    v = seeded_randn(tuple(y.shape), 15).cuda()
+    go2 = go.clone().requires_grad_(True)
+    gx2, _ = torch.autograd.grad(fused_leaky_relu(xg, m.bias, 0.2, 2 ** 0.5), (xg, m.bias), go2, create_graph=True)
+    (ggo,) = torch.autograd.grad(gx2, go2, v)
+    gate = torch.where(yr.detach() > 0, torch.ones_like(yr), torch.full_like(yr, 0.2)) * 2 ** 0.5
+    assert torch.allclose(ggo.cpu(), gate * v.cpu(), atol=1e-6)
 
 
 def test_inpainting_config(chk):

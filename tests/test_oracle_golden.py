@@ -97,6 +97,20 @@ def test_oracle_bundled_ops_restatements():
 
 
 @pytest.mark.skipif(not ref_loader.available(), reason='reference tree not mounted (GPU box)')
+def test_oracle_fused_bias_act_modes():
+    """The act*10+grad switch (fused_bias_act_kernel.cu:36-46): mode 30 is the forward formula, mode 31 its derivative w.r.t. the
+    pre-activation gated by the forward output, 12/32 are zero, 10/11 linear."""
+    x, b = torch.randn(2, 3, 4, 5, generator=torch.Generator().manual_seed(5)), torch.tensor([0.1, -0.2, 0.3])
+    fwd = O.fused_bias_act_modes(x, b, None, 3, 0, 0.2, 2 ** 0.5)
+    assert torch.equal(fwd, O.fused_bias_act(x, b))
+    xr = x.clone().requires_grad_(True)
+    go = torch.randn(2, 3, 4, 5, generator=torch.Generator().manual_seed(6))
+    (gx,) = torch.autograd.grad(O.fused_bias_act(xr, b), xr, go)
+    assert torch.allclose(O.fused_bias_act_modes(go, None, fwd, 3, 1, 0.2, 2 ** 0.5), gx, atol=1e-7)
+    assert not O.fused_bias_act_modes(x, b, fwd, 3, 2, 0.2, 1.0).any() and not O.fused_bias_act_modes(x, b, fwd, 1, 2, 0.2, 1.0).any()
+    assert torch.equal(O.fused_bias_act_modes(x, b, fwd, 1, 0, 0.2, 3.0), (x + b.view(1, 3, 1, 1)) * 3.0)
+
+
 def test_oracle_upfirdn2d_matches_reference_native():
     """upfirdn2d_native is the only pure-torch restatement the reference itself ships (upfirdn2d.py:156-186)."""
     import importlib.util

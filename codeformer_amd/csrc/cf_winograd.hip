@@ -422,17 +422,17 @@ __global__ __launch_bounds__(256, 2) void winograd_kernel(const std::conditional
   // latency overlaps the LDS contraction instead of following it.  (n < cout always: the host requires cout % 64 == 0.)
   unsigned offs[NI][4];  // element offsets fit 32 bits (tensors < 16 GiB)
   f32x4 r0[NI][4], r1[NI][4];
+  // offsets: one base per thread, the (pass, k, aa) variants differ by wave-uniform amounts (k: 16 tiles = 4 pixel rows, aa: one row)
+  const unsigned e_rowc = (unsigned)a.w * (unsigned)a.cout;
+  const unsigned e_base = (((unsigned)b * a.h + (y0 + 2 * ((gtid >> 4) >> 3))) * a.w + (x0 + 2 * ((gtid >> 4) & 7) + ((gtid >> 3) & 1))) * (unsigned)a.cout +
+                          (n0 + e_n4 * 4);
 #pragma unroll
   for (int pass = 0; pass < NI; ++pass)
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const int it = gtid + k * GT;
-      const int e_bb = (it >> 3) & 1, e_tile = it >> 4;
-      const int e_ty = e_tile >> 3, e_tx = e_tile & 7;
 #pragma unroll
       for (int aa = 0; aa < 2; ++aa) {
-        const unsigned pixel = ((unsigned)b * a.h + (y0 + 2 * e_ty + aa)) * a.w + (x0 + 2 * e_tx + e_bb);
-        const unsigned off = pixel * (unsigned)a.cout + (n0 + pass * 32 + e_n4 * 4);
+        const unsigned off = e_base + (unsigned)(k * 4 + aa) * e_rowc + pass * 32;
         offs[pass][k * 2 + aa] = off;
         r0[pass][k * 2 + aa] = r1[pass][k * 2 + aa] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (a.epilogue == CF_EPI_RESIDUAL || a.epilogue == CF_EPI_SFT) r0[pass][k * 2 + aa] = *reinterpret_cast<const f32x4*>(a.res + off);

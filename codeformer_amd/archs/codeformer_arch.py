@@ -69,14 +69,15 @@ class TransformerSALayer(HipModule):
     def with_pos_embed(self, tensor, pos):
         return tensor if pos is None else tensor + pos
 
-    def forward_tokens(self, X, pos, batch):
-        """X: (batch*256, E) tokens, pos: (256, E) or None.  Returns the layer output, same shape."""
+    def forward_tokens(self, X, pos, batch, code=0):
+        """X: (batch*256, E) tokens, pos: (256, E) or None.  Returns the layer output, same shape.
+        code: operand code of the five GEMMs (0 exact fp32 MFMA, ops.GSPLIT split-half operands)."""
         E, H = self.embed_dim, self.nhead
         sa = self.self_attn
         w, b = sa.in_proj_weight, sa.in_proj_bias
-        pw_qk = self._packed('qk', lambda: ops.pack_weight(w[:2 * E], b[:2 * E]), w, b)
-        pw_v = self._packed('v', lambda: ops.pack_weight(w[2 * E:], b[2 * E:]), w, b)
-        pw_o = self._pw_conv(sa.out_proj)
+        pw_qk = self._packed(('qk', code), lambda: ops.pack_weight(w[:2 * E], b[:2 * E], bf16=code), w, b)
+        pw_v = self._packed(('v', code), lambda: ops.pack_weight(w[2 * E:], b[2 * E:], bf16=code), w, b)
+        pw_o = self._pw_conv(sa.out_proj, bf16=code)
         if pos is not None:
             t2, t2p = ops.layernorm(X, self.norm1.weight, self.norm1.bias, self.norm1.eps, pos=pos)
         else:
@@ -87,8 +88,8 @@ class TransformerSALayer(HipModule):
         a = ops.attention(qk[:, :E], qk[:, E:], v, batch, H, hd, float(hd) ** -0.5)
         X = ops.linear(a, pw_o, epilogue=EPI_RESIDUAL, res=X)
         t2 = ops.layernorm(X, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        h = ops.linear(t2, self._pw_conv('linear1'), epilogue=EPI_GELU)
-        return ops.linear(h, self._pw_conv('linear2'), epilogue=EPI_RESIDUAL, res=X)
+        h = ops.linear(t2, self._pw_conv('linear1', bf16=code), epilogue=EPI_GELU)
+        return ops.linear(h, self._pw_conv('linear2', bf16=code), epilogue=EPI_RESIDUAL, res=X)
 
     def forward(self, tgt, tgt_mask=None, tgt_key_padding_mask=None, query_pos=None):
         """tgt: (T=256, B, E) sequence-first like the reference."""
@@ -189,6 +190,9 @@ class CodeFormer(VQAutoEncoder):
         # reference's own 1-vs-8-thread noise is 2.6e-6), the smallest (reference top-2 gap) / (2 x our logit error) over all tokens
         # is 9.1 (exact: 8.8), and every index of every golden agrees.  Set 'fp32' to keep logits bitwise equal across precisions.
         self.encoder_precision = os.environ.get('CODEFORMER_HIP_ENCODER_PRECISION', 'auto')
+        # Operand format of the Transformer's Linear layers (feat_emb, q|k / v / out projections, MLP, logits head): 'fp32' = exact fp32
+        # MFMA GEMM, 'f16x2' = split-half operands (cf_gemm_split.hip).
+        self.gemm_precision = os.environ.get('CODEFORMER_HIP_GEMM_PRECISION', 'fp32')
         # Optional HIP-graph replay of the whole forward (one graph per input shape / w / flags): takes the ~250 host launches
         # per call off the critical path.  Measured: no gain at B=1..16 on an otherwise idle host (the kernels, not the launches,
         # bound even B=1), so it is off by default; useful when the host thread is busy (decode / encode of PNGs).
@@ -235,11 +239,14 @@ class CodeFormer(VQAutoEncoder):
         T = lq.shape[1] * lq.shape[2]
         tokens = lq.view(B * T, lq.shape[3])
 
-        X = ops.linear(tokens, self._pw_conv('feat_emb'))
+        if self.gemm_precision not in ('fp32', 'f16x2'):
+            raise ValueError(f"gemm_precision must be 'fp32' or 'f16x2', got {self.gemm_precision!r}")
+        gcode = ops.GSPLIT if self.gemm_precision == 'f16x2' else 0
+        X = ops.linear(tokens, self._pw_conv('feat_emb', bf16=gcode))
         for layer in self.ft_layers:
-            X = layer.forward_tokens(X, self.position_emb, B)
+            X = layer.forward_tokens(X, self.position_emb, B, code=gcode)
         ln, head = self.idx_pred_layer[0], self.idx_pred_layer[1]
-        logits2d = ops.linear(ops.layernorm(X, ln.weight, ln.bias, ln.eps), self._pw_conv(head))
+        logits2d = ops.linear(ops.layernorm(X, ln.weight, ln.bias, ln.eps), self._pw_conv(head, bf16=gcode))
         logits = logits2d.view(B, T, -1)
         lq_feat = ops.to_nchw(lq)
         if code_only:
@@ -301,7 +308,7 @@ class CodeFormer(VQAutoEncoder):
     def _forward_graphed(self, x, w, code_only, adain):
         """Capture-once / replay-many execution of _forward_hip on the current stream.  Outputs are copies, so callers may
         keep them across calls.  A graph is re-captured when any packed weight was rebuilt since its capture."""
-        key = (tuple(x.shape), float(w), bool(code_only), bool(adain), self.precision, self.encoder_precision, bool(self.winograd), bool(self.winograd_encoder), str(x.device))
+        key = (tuple(x.shape), float(w), bool(code_only), bool(adain), self.precision, self.encoder_precision, self.gemm_precision, bool(self.winograd), bool(self.winograd_encoder), str(x.device))
         ent = self._graphs.get(key)
         if ent is None or ent['epoch'] != PACK_EPOCH[0]:
             static_x = x.float().contiguous().clone()

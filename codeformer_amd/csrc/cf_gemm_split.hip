@@ -1,0 +1,220 @@
+// Linear / 1x1 GEMM on token matrices with split-half operands (fp32 = hi + lo IEEE halves, three f16 MFMAs per product, fp32
+// accumulation -- the scheme of cf_split.hip) for gfx950:   out[M][N] = epilogue(acc_scale * A[M][K] . W'[N][K]^T + bias).
+//
+// Serves the Transformer's Linear layers (codeformer_arch.py:104-106,126,132,183,192: feat_emb, the q|k / v / out projections, the
+// MLP, the logits head) when CodeFormer.gemm_precision = 'f16x2'.  The fp32-MFMA GEMM they otherwise run on (cf_igemm.hip, 64x64
+// split-K tiles) reaches 58-75 TFLOP/s on these shapes; the matrix work here is 3/16 of it.
+//
+//   * workgroup = 4 waves (2 x 2), 64 x 64 output tile, wave tile 32 x 32 (one MFMA tile: 16 accumulator registers);
+//   * NO LDS in the main loop: a lane loads its A fragment (row = token, 8 consecutive channels, 32 bytes) and its B fragments (the
+//     weights are packed in MFMA-operand order, hi and lo halves pre-split and scaled by a power of two: 1 KB contiguous per wave
+//     and fragment) straight from global memory / L2, four 16-wide k steps ahead in registers (two groups of four steps, double
+//     buffered); A is split into halves in registers (cf_split_pair);
+//   * K is always cut into virtual chunks of 128 values summed from zero and added in chunk order (cf_common.h, the contract of the
+//     fp32 split-K GEMM): the bits do not depend on how many workgroups (1, 2, 4, 8) share a tile, so the host picks the split
+//     count from the tiles in flight and results stay bitwise batch-invariant;
+//   * epilogue: bias, exact-erf GELU or residual, 128-byte row segments per store instruction.
+#include <type_traits>
+
+#include "cf_common.h"
+
+namespace {
+
+typedef _Float16 gs_f16x8 __attribute__((ext_vector_type(8)));
+
+struct GsArgs {
+  const float* a;     // [M][K] dense tokens
+  const float* w;     // packed: [K/16][N/32][hi, lo][64 lanes][4 words]
+  const float* bias;  // [N] or null
+  const float* res;   // [M][N] (CF_EPI_RESIDUAL)
+  float* out;         // [M][N]
+  int M, N, K;
+  int epilogue;
+  float acc_scale;
+  float* ws;
+  unsigned* counters;
+  int nsplit;
+};
+
+constexpr int GS_GROUP = 4;  // k steps (of 16) per prefetch group; a virtual chunk of 128 values = two groups
+
+__global__ __launch_bounds__(256) void gemm_split_kernel(const GsArgs g) {
+  __shared__ float s_flag;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int half = lane >> 5, l31 = lane & 31;
+  int bid = blockIdx.x;
+  const int split = bid % g.nsplit;
+  const int tile = bid / g.nsplit;
+  const int ntn = g.N >> 6;
+  const int nt = tile % ntn, mt = tile / ntn;
+  const int m0 = mt * 64 + wm * 32, n0 = nt * 64 + wn * 32;
+  const int V = g.K >> 7;            // virtual chunks of 128 K values
+  const int nv = V / g.nsplit;       // ... of this workgroup (host-checked: nsplit divides V)
+  const int c0 = split * nv;
+
+  const float* const arow = g.a + (size_t)(m0 + l31) * g.K + half * 8 + (size_t)c0 * 128;
+  const size_t kstride = (size_t)(g.N >> 5) * 512;  // floats between consecutive k steps of the packed weights
+  const float* const wl = g.w + (size_t)(n0 >> 5) * 512 + lane * 4 + (size_t)c0 * 8 * kstride;
+
+  f32x4 ra[2][GS_GROUP][2], rb[2][GS_GROUP][2];  // [buffer][k step][A: channels 0-3 / 4-7 of the lane's 8; B: hi / lo]
+  auto fetch = [&](int grp, auto buf) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(buf)::value;
+#pragma unroll
+    for (int s = 0; s < GS_GROUP; ++s) {
+      const int ks = grp * GS_GROUP + s;
+      ra[BUF][s][0] = *reinterpret_cast<const f32x4*>(arow + ks * 16);
+      ra[BUF][s][1] = *reinterpret_cast<const f32x4*>(arow + ks * 16 + 4);
+      rb[BUF][s][0] = *reinterpret_cast<const f32x4*>(wl + (size_t)ks * kstride);
+      rb[BUF][s][1] = *reinterpret_cast<const f32x4*>(wl + (size_t)ks * kstride + 256);
+    }
+  };
+  f32x16 acc, tot;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = tot[r] = 0.f;
+  auto compute = [&](auto buf) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(buf)::value;
+#pragma unroll
+    for (int s = 0; s < GS_GROUP; ++s) {
+      f32x4 ah, al;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const f32x4 v = ra[BUF][s][e >> 1];
+        float hh, ll;
+        cf_split_pair(v[(e & 1) * 2], v[(e & 1) * 2 + 1], hh, ll);
+        ah[e] = hh;
+        al[e] = ll;
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gs_f16x8, al), __builtin_bit_cast(gs_f16x8, rb[BUF][s][0]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gs_f16x8, ah), __builtin_bit_cast(gs_f16x8, rb[BUF][s][1]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gs_f16x8, ah), __builtin_bit_cast(gs_f16x8, rb[BUF][s][0]), acc, 0, 0, 0);
+    }
+  };
+
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  const int ngroups = nv * 2;  // two groups per virtual chunk
+  fetch(0, B0{});
+  for (int c = 0; c < nv; ++c) {
+    // first half of the chunk from buffer 0 while buffer 1 loads its second half; then the next chunk's first half into buffer 0
+    fetch(2 * c + 1, B1{});
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (hipcc otherwise sinks every load to its use)
+    compute(B0{});
+    if (2 * c + 2 < ngroups) fetch(2 * c + 2, B0{});
+    __builtin_amdgcn_sched_barrier(0);
+    compute(B1{});
+    // the chunk sum is complete: fold it into the running sum (one workgroup per tile) or park it for the last arriver
+    if (g.nsplit == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tot[r] += acc[r];
+    } else {
+      f32x4 v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = f32x4{acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]};
+      cf_splitk_park(v, g.ws, tile, c0 + c, V, 256);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  }
+  if (g.nsplit > 1) {
+    f32x4 v[4];
+    if (!cf_splitk_finish(v, g.ws, g.counters, tile, V, g.nsplit, 256, &s_flag)) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tot[4 * i + e] = v[i][e];
+  }
+
+  // ---- epilogue: lane holds column n0 + l31 of rows cf_acc_row(r, lane) ----
+  const int n = n0 + l31;
+  const float bias = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const size_t o = (size_t)(m0 + cf_acc_row(r, lane)) * g.N + n;
+    float v = tot[r] * g.acc_scale + bias;
+    if (g.epilogue == CF_EPI_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (g.epilogue == CF_EPI_RESIDUAL) v += g.res[o];
+    g.out[o] = v;
+  }
+}
+
+// W' = scale * W as hi = f16(W'), lo = f16(W' - hi) in MFMA-operand order [K/16][N/32][hi, lo][lane 64][4 words]:
+// a lane's 16 bytes are the 8 halves of W'[n = tile*32 + (lane&31)][k = kstep*16 + (lane>>5)*8 + 0..7]
+__global__ void pack_linear_f16x2_kernel(const float* __restrict__ w, int N, int K, float scale, unsigned* __restrict__ packed, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int e = (int)(i & 3), ln = (int)((i >> 2) & 63), part = (int)((i >> 8) & 1);
+  long r = i >> 9;
+  const int ntiles = N / 32;
+  const int n = (int)(r % ntiles) * 32 + (ln & 31);
+  const int ks = (int)(r / ntiles);
+  unsigned out = 0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int k = ks * 16 + (ln >> 5) * 8 + e * 2 + h;
+    const float v = w[(long)n * K + k] * scale;  // exact: power of two
+    const _Float16 hi = (_Float16)v;
+    const _Float16 hv = part ? (_Float16)(v - (float)hi) : hi;
+    out |= (unsigned)__builtin_bit_cast(unsigned short, hv) << (16 * h);
+  }
+  packed[i] = out;
+}
+
+}  // namespace
+
+extern "C" int cf_pack_linear_weight_f16x2(const float* w, int n, int k, float scale, void* packed, cf_stream_t stream) {
+  CF_REQUIRE(w && packed, "cf_pack_linear_weight_f16x2: null pointer");
+  CF_REQUIRE(n > 0 && k > 0 && n % 64 == 0 && k % 128 == 0, "cf_pack_linear_weight_f16x2: N %d must be a multiple of 64, K %d of 128", n, k);
+  int ex = 0;
+  CF_REQUIRE(scale > 0.f && frexpf(scale, &ex) == 0.5f, "cf_pack_linear_weight_f16x2: scale %g is not a power of two", (double)scale);
+  const long total = (long)n * k;  // 32-bit words: hi + lo half per weight
+  hipLaunchKernelGGL(pack_linear_f16x2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, n, k, scale,
+                     reinterpret_cast<unsigned*>(packed), total);
+  CF_CHECK_LAUNCH("cf_pack_linear_weight_f16x2");
+  return CF_OK;
+}
+
+// Called by cf_conv2d (cf_igemm.hip) for taps == 1 descriptors with bf16_mfma == CF_OPERAND_F16X2; the common argument checks have run.
+int cf_gemm_split_geometry(const cf_conv_desc* d, int* tiles, long* bytes_per_part) {
+  const long m = (long)d->batch * d->hout * d->wout;
+  CF_REQUIRE(d->taps == 1 && m % 64 == 0 && d->cout % 64 == 0 && d->cout_pad == d->cout && (d->c0 + d->c1) % 128 == 0,
+             "cf_conv2d(1x1, f16x2): M %ld and N %d must be multiples of 64, K %d of 128", m, d->cout, d->c0 + d->c1);
+  *tiles = (int)(m / 64) * (d->cout / 64);
+  const int V = (d->c0 + d->c1) / 128;
+  *bytes_per_part = 64L * 64 * 4 * V / (d->split_k > 0 ? d->split_k : 1);  // V chunk sums of 16 KB per tile in all
+  return CF_OK;
+}
+
+int cf_gemm_split_launch(const cf_conv_desc* d, hipStream_t stream) {
+  int tiles = 0;
+  long per = 0;
+  const int rc = cf_gemm_split_geometry(d, &tiles, &per);
+  if (rc != CF_OK) return rc;
+  CF_REQUIRE(d->stride == 1 && !d->in_nchw && !d->out_nchw && d->c1 == 0 && d->prologue == CF_PRO_NONE && !d->stats_out &&
+                 (d->ld_in0 == 0 || d->ld_in0 == d->c0) && (d->ld_out == 0 || d->ld_out == d->cout),
+             "cf_conv2d(1x1, f16x2): dense single-input token GEMMs without prologue / statistics only");
+  CF_REQUIRE(d->epilogue == CF_EPI_NONE || d->epilogue == CF_EPI_GELU || d->epilogue == CF_EPI_RESIDUAL,
+             "cf_conv2d(1x1, f16x2): epilogues are none / GELU / residual");
+  CF_REQUIRE(d->acc_scale > 0.f, "cf_conv2d(1x1, f16x2): acc_scale must be the inverse of the pack-time weight scale (got %g)", (double)d->acc_scale);
+  const int nsplit = d->split_k >= 1 ? d->split_k : 1;
+  const int V = d->c0 / 128;
+  CF_REQUIRE(V % nsplit == 0, "cf_conv2d(1x1, f16x2): split_k %d must divide K/128 = %d", nsplit, V);
+  CF_REQUIRE(nsplit == 1 || (d->workspace && d->counters), "cf_conv2d(1x1, f16x2): split_k > 1 needs workspace and counters");
+  GsArgs g;
+  g.a = d->in0;
+  g.w = d->weight;
+  g.bias = d->bias;
+  g.res = d->res;
+  g.out = d->out;
+  g.M = (int)((long)d->batch * d->hout * d->wout);
+  g.N = d->cout;
+  g.K = d->c0;
+  g.epilogue = d->epilogue;
+  g.acc_scale = d->acc_scale;
+  g.ws = d->workspace;
+  g.counters = d->counters;
+  g.nsplit = nsplit;
+  hipLaunchKernelGGL(gemm_split_kernel, dim3((unsigned)(tiles * nsplit)), dim3(256), 0, stream, g);
+  CF_CHECK_LAUNCH("cf_conv2d(1x1, f16x2)");
+  return CF_OK;
+}

@@ -1297,6 +1297,8 @@ extern "C" int cf_pack_conv_weight(const float* w, int cout, int cin, int taps, 
 }
 
 int cf_winograd_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query);  // cf_winograd.hip
+int cf_gemm_split_launch(const cf_conv_desc* d, hipStream_t stream);                     // cf_gemm_split.hip
+int cf_gemm_split_geometry(const cf_conv_desc* d, int* tiles, long* bytes_per_part);
 int cf_split_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query);     // cf_split.hip
 
 static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
@@ -1373,6 +1375,10 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
   CF_REQUIRE(d->cout_pad >= d->cout && d->cout_pad % 32 == 0, "cf_conv2d: cout_pad %d invalid for cout %d", d->cout_pad,
              d->cout);
 
+  if (d->taps == 1 && d->bf16_mfma == CF_OPERAND_F16X2) {  // token GEMM on split-half operands
+    CF_REQUIRE(!pq, "cf_conv2d(1x1, f16x2): no statistics epilogue");
+    return cf_gemm_split_launch(d, stream);
+  }
   if (d->winograd) return cf_winograd_launch(d, stream, pq);  // fp32 or split-half operands
   if (d->bf16_mfma == CF_OPERAND_F16X2) return cf_split_launch(d, stream, pq);
 
@@ -1522,6 +1528,7 @@ static int splitk_geometry(const cf_conv_desc* d, int* tiles, long* bytes_per_pa
   *tiles = 0;
   *bytes_per_part = 0;
   if (!d || d->split_k < 1) return CF_OK;
+  if (d->taps == 1 && d->bf16_mfma == CF_OPERAND_F16X2) return cf_gemm_split_geometry(d, tiles, bytes_per_part);
   if (d->winograd) return cf_winograd_splitk_geometry(d, tiles, bytes_per_part);
   if (d->bf16_mfma == CF_OPERAND_F16X2) return cf_split_splitk_geometry(d, tiles, bytes_per_part);
   CF_REQUIRE(d->taps == 1 && d->cout_pad % 64 == 0 && ((long)d->batch * d->hout * d->wout) % 64 == 0,

@@ -62,7 +62,8 @@ WINOGRAD = 3   # value of the operand-code argument that selects the Winograd F(
 SPLIT = 4      # ... the split-half evaluation: fp32 operands as hi + lo IEEE halves, 3 f16 MFMAs per product (cf_split.hip)
 SPLIT_DIRECT = 5   # ... the same, but layers the split kernel does not take run on the direct fp32 kernel instead of Winograd
 WSPLIT = 6     # ... Winograd F(2x2,3x3) with split-half operands in the 16 transform-domain GEMMs (cf_winograd.hip, H2)
-OPERAND_F16X2 = 3   # enum cf_operand value behind SPLIT / WSPLIT
+GSPLIT = 7     # ... a Linear / 1x1 weight for the split-half token GEMM (cf_gemm_split.hip)
+OPERAND_F16X2 = 3   # enum cf_operand value behind SPLIT / WSPLIT / GSPLIT
 # SPLIT layers that the Winograd kernel covers take its split-half form (4/9 of the MFMA work); CODEFORMER_HIP_SPLIT_WINOGRAD=0
 # keeps them on the direct split-half kernel.
 SPLIT_WINOGRAD = os.environ.get('CODEFORMER_HIP_SPLIT_WINOGRAD', '1') != '0'
@@ -117,6 +118,16 @@ def pack_weight(weight, bias=None, bf16=False, up2x=False, f16=False):
         L.check(lib.cf_pack_conv_weight_winograd(L.ptr(w), cout, cin, cout, cin, L.ptr(packed, dtype=None), L.stream_ptr()),
                 'cf_pack_conv_weight_winograd')
         return PackedWeight(packed, b, cout, cin, 9, cout, cin, wino=True)
+    if code == GSPLIT:
+        w2 = w.reshape(cout, cin)
+        if w.dim() not in (2, 4) or w.numel() != cout * cin or cout % 64 or cin % 128:
+            raise ValueError('f16x2 GEMM packing needs a Linear / 1x1 weight with cout % 64 == 0 and cin % 128 == 0')
+        wmax = float(w2.abs().max())
+        scale = 1.0 if wmax == 0.0 or not math.isfinite(wmax) else 2.0 ** (14 - math.frexp(wmax)[1] + 1)
+        packed = torch.empty(cout * cin, dtype=torch.float32, device=w.device)
+        L.check(lib.cf_pack_linear_weight_f16x2(L.ptr(w2.contiguous()), cout, cin, scale, L.ptr(packed, dtype=None), L.stream_ptr()),
+                'cf_pack_linear_weight_f16x2')
+        return PackedWeight(packed, b, cout, cin, 1, cout, cin, bf16=OPERAND_F16X2, scale=scale)
     if code == WSPLIT:
         if up2x or w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or cin % 16 or cout % 64:
             raise ValueError('winograd f16x2 packing needs a 3x3 weight with cin % 16 == 0 and cout % 64 == 0 (no up2x)')
@@ -200,7 +211,7 @@ _COUNTERS = {}
 
 def splitk_for(pw, ho, wo, cin, batch=1):
     """Split count for a 1x1 / Linear or a Winograd 3x3 on `batch` images of ho x wo pixels; 0: the layer is not a split-K layer."""
-    if SPLITK_MAX <= 0 or (pw.bf16 and not pw.wino) or ho * wo > 1024 or cin % 128:
+    if SPLITK_MAX <= 0 or (pw.bf16 and not pw.wino and pw.taps != 1) or ho * wo > 1024 or cin % 128:
         return 0
     if pw.wino:
         if ho % 8 or wo % 16 or ho * wo > 256:   # the 16x16 latents only: from 32x32 up a batch fills the CUs without splitting

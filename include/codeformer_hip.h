@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 12
+#define CF_ABI_VERSION 13
 
 typedef void* cf_stream_t; /* hipStream_t */
 
@@ -178,6 +178,10 @@ int cf_pack_conv_weight_winograd(const float* w, int cout, int cin, int cout_pad
  * words); `scale` is a power of two that puts max|scale * U| into [2^14, 2^15) (cf_conv_desc.acc_scale = 1 / scale) */
 int cf_pack_conv_weight_winograd_f16x2(const float* w, int cout, int cin, int cout_pad, int cin_pad, float scale, void* packed,
                                        cf_stream_t stream);
+/* taps == 1 + CF_OPERAND_F16X2 (Linear / 1x1 on token matrices, codeformer_arch.py:104-106,126,132,183,192): w[n][k] -> scale * w as
+ * hi + lo IEEE halves in MFMA-operand order (n*k 32-bit words); n % 64 == 0, k % 128 == 0.  The launch needs M = batch*hout*wout % 64 == 0,
+ * a dense single input, no prologue / statistics, epilogue none | GELU | residual; split_k as for the fp32 GEMM (same bits for every count) */
+int cf_pack_linear_weight_f16x2(const float* w, int n, int k, float scale, void* packed, cf_stream_t stream);
 /* bf16 layout [tap][cin_pad/32][cout_pad][32] (round-to-nearest-even); cin_pad % 32 == 0, cout_pad % 64 == 0; the buffer
  * holds cf_packed_weight_elems(cin_pad, taps, cout_pad) bf16 values (half the bytes of the fp32 packing). */
 int cf_pack_conv_weight_bf16(const float* w, int cout, int cin, int taps, int cout_pad, int cin_pad, void* packed,

@@ -101,6 +101,34 @@ def test_split_conv_refusals_and_overflow_is_loud(sc):
     assert ops.conv_code(ops.SPLIT, 512, 512, 16, 16, up2x=True) == 0 and ops.conv_code(ops.SPLIT, 128, 128, 256, 256, up2x=True) == ops.SPLIT
 
 
+def test_split_half_token_gemm(sc):
+    """cf_gemm_split.hip (CodeFormer.gemm_precision = 'f16x2', off by default): against fp64 at least as close as the exact fp32 GEMM
+    (bias / GELU / residual epilogues, extreme weight magnitudes), bitwise the same for split counts 1 / 2 / 4 / 8, and the network's
+    logits and indices with it against the reference golden."""
+    import importlib.util
+    import numpy as np
+    import torch
+    spec = importlib.util.spec_from_file_location('gemm_split_check', os.path.join(ROOT, 'tools', 'gemm_split_check.py'))
+    gc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gc)
+    for c in gc.CASES:
+        es, ef, rmax, same = gc.case(**c)
+        assert same and es <= 2e-5 + 1e-5 * rmax and es <= 2.0 * ef + 1e-7 * rmax, (c, es, ef)
+    spec = importlib.util.spec_from_file_location('gpu_check', os.path.join(ROOT, 'tools', 'gpu_check.py'))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    from oracle.synth import seeded_input
+    net = chk.build_net().cuda()
+    net.gemm_precision = 'f16x2'
+    g = np.load(os.path.join(ROOT, 'tests/golden/restoration_seed0_face0.npz'))
+    x = seeded_input(2).cuda()
+    out, logits, _ = net(x, w=0.5, adain=True)
+    assert float((logits[:1].cpu() - torch.from_numpy(g['logits'])).abs().max()) <= 1e-4
+    assert np.array_equal(net.last_indices[:1].cpu().numpy(), g['idx'])
+    out1, logits1, _ = net(x[:1].contiguous(), w=0.5, adain=True)
+    assert torch.equal(logits1, logits[:1]) and torch.equal(out1, out[:1])      # batch invariance holds with it
+
+
 def test_splitk_gemm_bits_do_not_depend_on_the_split_count(sc):
     """1x1 / Linear on small token images (cf_conv_desc.split_k): K is always cut into virtual chunks of 128 added in a fixed order,
     so the result is bitwise the same whether 1, 2, 4 or 8 workgroups share a tile -- and equals the fp64 product to fp32 accuracy."""

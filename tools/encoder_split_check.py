@@ -27,8 +27,9 @@ def main():
         cases.append((name, ops.img_u8_to_tensor(torch.from_numpy(g['img']).unsqueeze(0).cuda()), g['logits'], g['idx'], g['gap']))
     g = np.load(os.path.join(GOLD, 'index_sweep_seed2024.npz'))
     x8 = seeded_input(16, seed=2024)[:8].cuda()
-    for mode in ('fp32', 'f16x2'):
-        net.encoder_precision = mode
+    for mode, gmode in (('fp32', 'fp32'), ('f16x2', 'fp32'), ('f16x2', 'f16x2')):
+        net.encoder_precision, net.gemm_precision = mode, gmode
+        mode = f'encoder {mode}, gemm {gmode}'
         for name, x, rl, ridx, gap in cases:
             logits, lq = net(x, w=0.5, code_only=True)
             l = logits.cpu().numpy()
@@ -50,8 +51,9 @@ def main():
     # fp32-encoder vs split-encoder logits against each other, seeded batch
     x = seeded_input(16).cuda()
     res = {}
-    for mode in ('fp32', 'f16x2'):
-        net.encoder_precision = mode
+    for mode, gmode in (('fp32', 'fp32'), ('f16x2', 'fp32'), ('f16x2', 'f16x2')):
+        net.encoder_precision, net.gemm_precision = mode, gmode
+        mode = f'encoder {mode}, gemm {gmode}'
         net.precision = 'f16x2'
         for _ in range(3):
             out = net(x, w=0.5, adain=True)
@@ -63,8 +65,8 @@ def main():
         dt = (time.perf_counter() - t) / 10
         res[mode] = [o.cpu() for o in out] + [net.last_indices.cpu()]
         print(f'[{mode}] encoder: {dt * 1e3:.2f} ms per 16 faces = {16 / dt:.1f} faces/s', flush=True)
-    a, b = res['fp32'], res['f16x2']
-    print(f'split vs exact encoder, 16 seeded faces: logits max {float((a[1] - b[1]).abs().max()):.2e}  lq_feat max {float((a[2] - b[2]).abs().max()):.2e}  '
+    a, b = res['encoder fp32, gemm fp32'], res['encoder f16x2, gemm f16x2']
+    print(f'split (encoder + Transformer GEMMs) vs exact, 16 seeded faces: logits max {float((a[1] - b[1]).abs().max()):.2e}  lq_feat max {float((a[2] - b[2]).abs().max()):.2e}  '
           f'pixels max {float((a[0] - b[0]).abs().max()):.2e}  indices equal {bool(torch.equal(a[3], b[3]))}')
 
 

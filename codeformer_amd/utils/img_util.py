@@ -59,6 +59,98 @@ def resize_bilinear(img, size):
     return np.ascontiguousarray(out.astype(np.uint8).reshape((dh, dw) + img.shape[2:]))
 
 
+def resize_linear_f32(img, size, inv_scale=None):
+    """cv2.resize(..., interpolation=cv2.INTER_LINEAR) for float32 HWC images (the detector's `transform`, retinaface.py:160-161):
+    float weights (1 - f, f), horizontal pass then vertical pass, half-pixel centres, clamped taps.  `inv_scale` = (fx, fy) when
+    the call gives scale factors instead of a size: OpenCV then maps with 1 / fx rather than src / dst."""
+    img = np.asarray(img, dtype=np.float32)
+    h, w = img.shape[:2]
+    dw, dh = int(size[0]), int(size[1])
+
+    def axis(n_src, n_dst, inv):
+        scale = (1.0 / inv) if inv else n_src / n_dst
+        f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+        i0 = np.floor(f).astype(np.int64)
+        frac = (f - i0.astype(np.float32)).astype(np.float32)
+        lo = i0 < 0
+        frac[lo], i0[lo] = 0.0, 0
+        hi = i0 >= n_src - 1
+        frac[hi], i0[hi] = 0.0, n_src - 1
+        return i0, np.minimum(i0 + 1, n_src - 1), (np.float32(1.0) - frac).astype(np.float32), frac
+
+    x0, x1, ax0, ax1 = axis(w, dw, inv_scale[0] if inv_scale else None)
+    y0, y1, ay0, ay1 = axis(h, dh, inv_scale[1] if inv_scale else None)
+    src = img.reshape(h, w, -1)
+    rows = src[:, x0] * ax0[None, :, None] + src[:, x1] * ax1[None, :, None]          # (h, dw, c) float32
+    out = rows[y0] * ay0[:, None, None] + rows[y1] * ay1[:, None, None]
+    return np.ascontiguousarray(out.astype(np.float32).reshape((dh, dw) + img.shape[2:]))
+
+
+def resize_area(img, size):
+    """cv2.resize(img, size, interpolation=cv2.INTER_AREA) for uint8 HWC images when shrinking on both axes (what
+    FaceRestoreHelper.get_face_landmarks_5 feeds the detector for frames larger than `resize`, face_restoration_helper.py:208-215).
+
+    OpenCV's rule, restated: every destination pixel is the mean of the source rectangle [d*s, (d+1)*s) with fractional end cells
+    weighted by their covered length.  Integer ratios take the box-sum path (integer sums, one multiply by 1/area, round half to
+    even); other ratios accumulate float32 products column weights first, then row weights, in source order, and round once."""
+    if img.dtype != np.uint8:
+        raise TypeError('resize_area restates the uint8 path of cv2.resize')
+    h, w = img.shape[:2]
+    dw, dh = int(size[0]), int(size[1])
+    if (w, h) == (dw, dh):
+        return img
+    if dw > w or dh > h:
+        raise ValueError('resize_area: INTER_AREA is restated for shrinking only (OpenCV switches to a linear rule when enlarging)')
+    src = img.reshape(h, w, -1)
+    sx, sy = w / dw, h / dh
+    if sx == int(sx) and sy == int(sy):
+        kx, ky = int(sx), int(sy)
+        box = src[:dh * ky, :dw * kx].astype(np.int64).reshape(dh, ky, dw, kx, -1).sum(axis=(1, 3))
+        out = np.rint(box.astype(np.float32) * np.float32(1.0 / (kx * ky)))
+        return np.ascontiguousarray(np.clip(out, 0, 255).astype(np.uint8).reshape((dh, dw) + img.shape[2:]))
+
+    def table(n_src, n_dst, scale):
+        """(dst index, src index, weight) triples in OpenCV's order (computeResizeAreaTab)."""
+        di, si, al = [], [], []
+        for d in range(n_dst):
+            f1 = d * scale
+            f2 = f1 + scale
+            cell = min(scale, n_src - f1)
+            s1, s2 = int(math.ceil(f1)), int(math.floor(f2))
+            s2 = min(s2, n_src - 1)
+            s1 = min(s1, s2)
+            if s1 - f1 > 1e-3:
+                di.append(d), si.append(s1 - 1), al.append(np.float32((s1 - f1) / cell))
+            for s in range(s1, s2):
+                di.append(d), si.append(s), al.append(np.float32(1.0 / cell))
+            if f2 - s2 > 1e-3:
+                di.append(d), si.append(s2), al.append(np.float32(min(min(f2 - s2, 1.0), cell) / cell))
+        return np.asarray(di), np.asarray(si), np.asarray(al, dtype=np.float32)
+
+    xd, xs, xa = table(w, dw, sx)
+    yd, ys, ya = table(h, dh, sy)
+    srcf = src.astype(np.float32)
+    c = srcf.shape[2]
+    # horizontal pass: buf[sy][dx] = sum_k src[sy][xs_k] * xa_k, accumulated in table order (float32)
+    buf = np.zeros((h, dw, c), dtype=np.float32)
+    # taps of one destination column are consecutive in the table; add them one position at a time to keep OpenCV's order
+    counts = np.bincount(xd, minlength=dw)
+    starts = np.concatenate(([0], np.cumsum(counts)[:-1]))
+    for t in range(int(counts.max())):
+        sel = np.nonzero(counts > t)[0]
+        k = starts[sel] + t
+        buf[:, sel] += srcf[:, xs[k]] * xa[k][None, :, None]
+    out = np.zeros((dh, dw, c), dtype=np.float32)
+    ycounts = np.bincount(yd, minlength=dh)
+    ystarts = np.concatenate(([0], np.cumsum(ycounts)[:-1]))
+    for t in range(int(ycounts.max())):
+        sel = np.nonzero(ycounts > t)[0]
+        k = ystarts[sel] + t
+        out[sel] += buf[ys[k]] * ya[k][:, None, None]
+    out = np.clip(np.rint(out), 0, 255).astype(np.uint8)
+    return np.ascontiguousarray(out.reshape((dh, dw) + img.shape[2:]))
+
+
 def img2tensor(imgs, bgr2rgb=True, float32=True):
     """HWC (BGR) ndarray(s) -> CHW (RGB) tensor(s); float64 input is narrowed to float32 before the swap."""
 

@@ -42,10 +42,15 @@ class VideoRestorer:
         return DeviceFaceHelper(self.upscale, 512, self.device, self.use_parse, self.face_parse)
 
     @torch.no_grad()
-    def restore(self, frames, affines, w=0.5, adain=True, return_tensors=False):
+    def restore(self, frames, affines, w=0.5, adain=True, return_tensors=False, keep_faces=False, gray=None):
+        """keep_faces: also keep every frame's (crops, restored faces) as uint8 host arrays in `self.faces_out[i]` (the reference saves
+        them next to the pasted image, inference_codeformer.py:232-247).  gray: per-frame flags; the faces of a gray frame take the
+        reference's gray colour transfer (face_restoration_helper.py:364-369: bgr2gray + adain_npy against the crop) on the host and are
+        rounded back to uint8 before the paste (the reference pastes the float result: at most half a grey level of difference)."""
         n = len(frames)
         assert len(affines) == n
         helpers, out = [None] * n, [None] * n
+        self.faces_out = [None] * n
         pending = [0] * n                    # faces of frame i still in flight
         done = [None] * n                    # per frame: list of restored crops (views), by face index
         queue = []                           # (frame, face, crop view)
@@ -54,7 +59,15 @@ class VideoRestorer:
         def finish(i):
             h = helpers[i]
             k = len(done[i])
-            h.add_restored_faces(torch.stack(done[i]) if k else torch.empty(0, 512, 512, 3, dtype=torch.uint8, device=self.device))
+            faces_i = torch.stack(done[i]) if k else torch.empty(0, 512, 512, 3, dtype=torch.uint8, device=self.device)
+            if k and gray is not None and gray[i]:
+                from .utils.face_misc import adain_npy, bgr2gray
+                crops_np = h.cropped_faces.cpu().numpy()
+                moved = [adain_npy(bgr2gray(f), c) for f, c in zip(faces_i.cpu().numpy(), crops_np)]
+                faces_i = torch.from_numpy(np.clip(np.rint(np.stack(moved)), 0, 255).astype(np.uint8)).to(self.device)
+            if keep_faces:
+                self.faces_out[i] = (h.cropped_faces.cpu().numpy(), faces_i.cpu().numpy())
+            h.add_restored_faces(faces_i)
             bg = self.bg_upsampler(frames[i]) if self.bg_upsampler is not None else None
             out[i] = h.paste_faces_to_input_image(upsample_img=bg, return_tensor=return_tensors)
             helpers[i] = done[i] = None      # release the frame's device buffers

@@ -1,1 +1,1 @@
-"""Import shim: the parts of the reference's `facelib` that exist on the HIP path (face parsing only)."""
+"""Import shim: the parts of the reference's `facelib` that exist here (face parsing, RetinaFace detection, the restoration helper)."""

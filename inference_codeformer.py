@@ -6,8 +6,9 @@ Same flags, same result tree (results/<input>_<w>/restored_faces/<basename>.png)
   * on an MI355X the uint8<->tensor boundary (img2tensor+normalize, tensor2img) runs as HIP kernels on the device
     (cf_img_u8_to_tensor / cf_tensor_to_img_u8) and the network is codeformer_amd's HIP path;
   * under torchrun the face list is sharded over ranks (one process per GPU) -- each rank writes its own results.
-Whole-image / video inputs need the reference's host-side facelib (detection, alignment, paste-back), which is outside
-this package's scope: run that stage with the reference and feed the aligned crops here.
+Whole images (and directories of extracted video frames) take the reference's full flow: RetinaFace detection + alignment fit on the
+host (facelib), crop warp / batched restoration / paste-back on the device; --affine_npz replaces the detector by a file of matrices.
+Video container files (.mp4 ...) need ffmpeg, which this image lacks: extract the frames to a directory first.
 """
 import argparse
 import glob
@@ -59,7 +60,7 @@ def parse_args(argv=None):
                    help='Use torch.manual_seed(SEED) random weights when weights/CodeFormer/codeformer.pth is absent '
                         '(plumbing runs on boxes without the checkpoint)')
     p.add_argument('--affine_npz', type=str, default=None,
-                   help='whole-image inputs: .npz mapping image basename -> (k,2,3) alignment matrices from the host face detector')
+                   help='whole-image inputs: .npz mapping image basename -> (k,2,3) alignment matrices, instead of running the detector')
     p.add_argument('--io_workers', type=int, default=None, help='PNG decode / encode worker threads of the GPU pipeline')
     p.add_argument('--strict', action='store_true', help='Raise on inference errors instead of returning the input face')
     return p.parse_args(argv)
@@ -84,22 +85,55 @@ def set_realesrgan(args, device, random_init_seed=None):
                             half=device.type == 'cuda', device=device)
 
 
+def build_detector(args):
+    """The host-side RetinaFace of facelib (init_detection_model reads weights/facelib/); with --random_init_seed a missing checkpoint
+    becomes seeded random weights (plumbing runs: such a detector finds nothing sensible)."""
+    from facelib.detection import RetinaFace, init_detection_model
+    try:
+        return init_detection_model(args.detection_model, half=False, device='cpu')
+    except FileNotFoundError:
+        if args.random_init_seed is None:
+            raise
+        print(f'WARNING: detector checkpoint not found -- using torch.manual_seed({args.random_init_seed}) random weights')
+        torch.manual_seed(args.random_init_seed)
+        return RetinaFace(network_name=args.detection_model.replace('retinaface_', ''), device='cpu')
+
+
+def build_parser(args, device):
+    """ParseNet for the paste-back masks (the reference's helper is built with use_parse=True, inference_codeformer.py:155-162).
+    Without its checkpoint the square soft mask alone is used, and the run says so."""
+    from facelib.parsing import ParseNet, init_parsing_model
+    try:
+        return init_parsing_model(model_name='parsenet', device=device)
+    except FileNotFoundError as e:
+        if args.random_init_seed is None:
+            print(f'NOTE: {e}; the paste-back uses the square soft mask only')
+            return None
+        torch.manual_seed(args.random_init_seed)
+        return ParseNet(in_size=512, out_size=512, parsing_ch=19).eval().to(device)
+
+
 def restore_whole_images(args, input_img_list, result_root, w):
-    """Whole images / extracted video frames with the host detector's output supplied as a file: --affine_npz maps each image's
-    basename (without extension) to its (k, 2, 3) frame -> 512-face matrices (FaceRestoreHelper.affine_matrices after
-    align_warp_face, face_restoration_helper.py:329-330).  Crops are cut, restored in 16-face batches ACROSS images and pasted back on
-    the device (codeformer_amd.video); the pasted images land in <result_root>/final_results/ like the reference's."""
+    """Whole images / extracted video frames (reference loop: inference_codeformer.py:165-262).  Faces are detected and aligned on the
+    HOST (RetinaFace + the LMedS similarity fit, facelib) -- or their alignment matrices come from a file (--affine_npz: image
+    basename without extension -> (k, 2, 3) frame -> 512-face matrices, FaceRestoreHelper.affine_matrices) -- and everything that
+    touches pixels runs on the device: crops are cut, restored in 16-face batches ACROSS images and pasted back (codeformer_amd.video).
+    Result tree as the reference's: cropped_faces/, restored_faces/ (<name>_<idx>.png) and final_results/<name>.png."""
     device = torch.device(args.device) if args.device else get_device()
     if device.type != 'cuda':
         raise NotImplementedError('the whole-image path runs on a ROCm device (alignment warp and paste-back are HIP kernels)')
+    if args.draw_box or args.face_upsample:
+        raise NotImplementedError('--draw_box / --face_upsample inside the paste-back are not built')
     from codeformer_amd.video import VideoRestorer, frame_shard
-    table = np.load(args.affine_npz)
+    from facelib.utils.face_restoration_helper import FaceRestoreHelper
+    table = np.load(args.affine_npz) if args.affine_npz else None
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     if world > 1:
         from codeformer_amd import parallel
         _, _, device = parallel.init_distributed(device=device)
     mine = [input_img_list[i] for i in frame_shard(len(input_img_list), rank, world)]       # frames are the unit of sharding
     net = build_net(device, args)
+    parser = build_parser(args, device)
     bg = None
     if args.bg_upsampler == 'realesrgan':
         ups = set_realesrgan(args, device, args.random_init_seed)
@@ -107,19 +141,33 @@ def restore_whole_images(args, input_img_list, result_root, w):
             def bg(frame):
                 img = ups.enhance(frame, outscale=args.upscale)[0]
                 return resize_bilinear(img, (frame.shape[1] * args.upscale, frame.shape[0] * args.upscale))
-    frames, affs, names = [], [], []
+    helper = FaceRestoreHelper(args.upscale, face_size=512, crop_ratio=(1, 1), det_model=args.detection_model, save_ext='png',
+                               use_parse=False, device='cpu', face_detector=build_detector(args) if table is None else False)
+    frames, affs, names, grays = [], [], [], []
     for p in mine:
         name = os.path.splitext(os.path.basename(p))[0]
-        frames.append(imread_bgr(p))
-        a = np.asarray(table[name], dtype=np.float64).reshape(-1, 2, 3) if name in table.files else np.zeros((0, 2, 3))
-        if args.only_center_face and a.shape[0] > 1:
-            a = a[:1]
+        helper.clean_all()
+        helper.read_image(p)                                       # (short side below 512: enlarged, as the reference does)
+        if table is None:
+            helper.get_face_landmarks_5(only_center_face=args.only_center_face, resize=640, eye_dist_threshold=5)
+            a = np.asarray(helper.estimate_affines(), dtype=np.float64).reshape(-1, 2, 3)
+        else:
+            a = np.asarray(table[name], dtype=np.float64).reshape(-1, 2, 3) if name in table.files else np.zeros((0, 2, 3))
+            if args.only_center_face and a.shape[0] > 1:
+                a = a[:1]
+        frames.append(helper.input_img)
+        grays.append(helper.is_gray)
         affs.append(a)
         names.append(name)
         print(f'[{len(names)}/{len(mine)}] Processing: {os.path.basename(p)}\n\tdetect {a.shape[0]} faces')
-    vr = VideoRestorer(net, device, upscale=args.upscale, batch_size=args.batch_size or 16, bg_upsampler=bg)
-    outs = vr.restore(frames, affs, w=w)
-    for name, img in zip(names, outs):
+    vr = VideoRestorer(net, device, upscale=args.upscale, batch_size=args.batch_size or 16, bg_upsampler=bg,
+                       use_parse=parser is not None, face_parse=parser)
+    outs = vr.restore(frames, affs, w=w, keep_faces=True, gray=grays)
+    for name, img, (crops, faces) in zip(names, outs, vr.faces_out):
+        for idx, (crop, face) in enumerate(zip(crops, faces)):
+            imwrite(crop, os.path.join(result_root, 'cropped_faces', f'{name}_{idx:02d}.png'))
+            face_name = f'{name}_{idx:02d}.png' if args.suffix is None else f'{name}_{idx:02d}_{args.suffix}.png'
+            imwrite(face, os.path.join(result_root, 'restored_faces', face_name))
         out_name = name if args.suffix is None else f'{name}_{args.suffix}'
         imwrite(img, os.path.join(result_root, 'final_results', f'{out_name}.png'))
     print(f"{vr.stats['faces']} faces of {vr.stats['frames']} images in {vr.stats['forward_calls']} forward calls")
@@ -133,8 +181,8 @@ def collect_inputs(args):
     if path.endswith(IMAGE_EXT):
         return [path], f'results/test_img_{w}'
     if path.endswith(VIDEO_EXT):
-        raise NotImplementedError('video input needs the host-side facelib + ffmpeg stage of the reference; '
-                                  'this entrypoint covers aligned faces (--has_aligned)')
+        raise NotImplementedError('video container input needs ffmpeg (absent on this image): extract the frames to a directory and '
+                                  'pass the directory')
     path = path[:-1] if path.endswith('/') else path
     return sorted(glob.glob(os.path.join(path, '*.[jpJP][pnPN]*[gG]'))), f'results/{os.path.basename(path)}_{w}'
 
@@ -167,11 +215,6 @@ def main(argv=None):
         raise FileNotFoundError('No input image/video is found...\n'
                                 '\tNote that --input_path for video should end with .mp4|.mov|.avi')
     if not args.has_aligned:
-        if args.affine_npz is None:
-            raise NotImplementedError('whole-image inputs need face detection (RetinaFace + landmark alignment), which the reference '
-                                      'keeps on the host in facelib and this package does not rebuild: pass aligned 512x512 crops with '
-                                      '--has_aligned, or run the host detector once and hand its alignment matrices over with '
-                                      '--affine_npz (crop warp, restoration and paste-back then run on the GPU)')
         return restore_whole_images(args, input_img_list, result_root, w)
     # The reference builds the Real-ESRGAN upsampler for these flags (inference_codeformer.py:112-124) but only ever USES it in the
     # paste-back of whole images (:217-229): on the --has_aligned path it never runs.  Same here: build it when its checkpoint is

@@ -127,3 +127,55 @@ def load_reference_img_util():
             else:
                 sys.modules[k] = v
     return m
+
+
+def load_reference_retinaface():
+    """The reference's facelib/detection/retinaface/{retinaface_net,retinaface_utils,retinaface}.py (last clause)
+    with stand-ins for what this container lacks: torchvision (oracle/tv_stub.py: ResNet-50, IntermediateLayerGetter, nms -- restated
+    from torchvision's published definitions), cv2 (never reached by `detect_faces(ndarray, use_origin_size=True)` /
+    `batched_detect_faces(float tensor)`), basicsr.utils.misc.get_device -> cpu.  facelib.detection.align_trans (+ matlab_cp2tform)
+    are the reference's own files.  Returns (retinaface_module, net_module, utils_module)."""
+    if not available():
+        raise RuntimeError(f'reference not found under {REF}')
+    from . import tv_stub
+    keys = ('facelib', 'basicsr', 'torchvision', 'cv2')
+    saved = {k: v for k, v in sys.modules.items() if k.split('.')[0] in keys}
+    for k in saved:
+        del sys.modules[k]
+    for pkg in ('facelib', 'facelib.detection', 'facelib.detection.retinaface', 'basicsr', 'basicsr.utils', 'basicsr.utils.misc', 'cv2'):
+        m = types.ModuleType(pkg)
+        m.__path__ = []
+        sys.modules[pkg] = m
+    sys.modules['basicsr.utils.misc'].get_device = lambda gpu_id=None: 'cpu'
+    sys.modules.update(tv_stub.modules())
+    try:
+        base = f'{REF}/facelib/detection'
+        _load('facelib.detection.matlab_cp2tform', f'{base}/matlab_cp2tform.py')
+        _load('facelib.detection.align_trans', f'{base}/align_trans.py')
+        net = _load('facelib.detection.retinaface.retinaface_net', f'{base}/retinaface/retinaface_net.py')
+        utils = _load('facelib.detection.retinaface.retinaface_utils', f'{base}/retinaface/retinaface_utils.py')
+        rf = _load('facelib.detection.retinaface.retinaface', f'{base}/retinaface/retinaface.py')
+    finally:
+        for k in [k for k in sys.modules if k.split('.')[0] in keys]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+    return rf, net, utils
+
+
+class torchvision_stub:
+    """Context manager: oracle/tv_stub.py visible as `torchvision` (the reference's RetinaFace imports torchvision.models inside its
+    constructor, retinaface.py:96)."""
+
+    def __enter__(self):
+        from . import tv_stub
+        self.saved = {k: v for k, v in sys.modules.items() if k.split('.')[0] == 'torchvision'}
+        for k in self.saved:
+            del sys.modules[k]
+        sys.modules.update(tv_stub.modules())
+        return self
+
+    def __exit__(self, *exc):
+        for k in [k for k in sys.modules if k.split('.')[0] == 'torchvision']:
+            del sys.modules[k]
+        sys.modules.update(self.saved)
+        return False

@@ -39,12 +39,17 @@ def test_missing_checkpoint_is_an_error_without_opt_in(tmp_path):
     assert r.returncode != 0 and 'codeformer.pth' in (r.stdout + r.stderr)
 
 
-def test_whole_image_path_is_explicitly_out_of_scope(tmp_path):
+def test_whole_image_path_needs_the_device(tmp_path):
+    """Whole images: detection runs on the host, but crop warp and paste-back are HIP kernels -- on a CPU-only box the entrypoint says
+    so instead of silently doing something else; .mp4 input says it needs ffmpeg."""
     src = tmp_path / 'faces'
     _faces(str(src), 1)
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'inference_codeformer.py'), '-i', str(src), '--device', 'cpu',
                         '--random_init_seed', '0'], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
-    assert r.returncode != 0 and '--has_aligned' in (r.stdout + r.stderr)
+    assert r.returncode != 0 and 'ROCm device' in (r.stdout + r.stderr)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'inference_codeformer.py'), '-i', str(tmp_path / 'clip.mp4'), '--device', 'cpu'],
+                       capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode != 0 and 'ffmpeg' in (r.stdout + r.stderr)
 
 
 def test_inpainting_entrypoint_cpu(tmp_path):

@@ -164,8 +164,8 @@ def test_entrypoint_whole_images_with_host_affines(env, tmp_path):
     os.makedirs(src)
     table = {}
     for i in range(2):
-        Image.fromarray(_img(240, 320, 70 + i)[:, :, ::-1]).save(src / f'im{i}.png')
-        table[f'im{i}'] = np.stack([_affine(P, 120 + 60 * i, 110, 100, 0.1 * i)])
+        Image.fromarray(_img(520, 640, 70 + i)[:, :, ::-1]).save(src / f'im{i}.png')
+        table[f'im{i}'] = np.stack([_affine(P, 220 + 60 * i, 210, 180, 0.1 * i)])
     np.savez(tmp_path / 'aff.npz', **table)
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'inference_codeformer.py'), '-i', str(src), '-o', str(tmp_path / 'o'), '-s', '2',
                         '--device', 'cuda', '--random_init_seed', '0', '--affine_npz', str(tmp_path / 'aff.npz')],
@@ -173,4 +173,89 @@ def test_entrypoint_whole_images_with_host_affines(env, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     assert sorted(os.listdir(tmp_path / 'o' / 'final_results')) == ['im0.png', 'im1.png']
     out = np.asarray(Image.open(tmp_path / 'o' / 'final_results' / 'im0.png'))
-    assert out.shape == (480, 640, 3) and '2 faces of 2 images in 1 forward calls' in r.stdout
+    assert out.shape == (1040, 1280, 3) and '2 faces of 2 images in 1 forward calls' in r.stdout
+    assert sorted(os.listdir(tmp_path / 'o' / 'cropped_faces')) == ['im0_00.png', 'im1_00.png']
+    assert sorted(os.listdir(tmp_path / 'o' / 'restored_faces')) == ['im0_00.png', 'im1_00.png']
+    crop = np.asarray(Image.open(tmp_path / 'o' / 'cropped_faces' / 'im0_00.png'))[:, :, ::-1]
+    frame = np.asarray(Image.open(src / 'im0.png'))[:, :, ::-1]
+    assert np.array_equal(crop, P.align_warp_face(np.ascontiguousarray(frame), table['im0'][0]))
+
+
+class _FixedDetector:
+    """Stands in for RetinaFace.detect_faces: returns prepared (k, 15) rows for whatever image it is given."""
+
+    def __init__(self, rows):
+        self.rows = np.asarray(rows, dtype=np.float32)
+
+    def detect_faces(self, image, **kw):
+        self.seen = image.shape
+        return self.rows
+
+
+def test_face_restore_helper_host_detection_device_pixels(env):
+    """FaceRestoreHelper end to end with a prepared detector output: landmarks -> LMedS similarity (host) -> crops (device, one
+    launch) -> paste-back (device) == the numpy restatement driven by the same matrices; detector input is the INTER_AREA-reduced frame
+    and its boxes are scaled back; the too-small-eye-distance rule and only_center_face apply."""
+    torch, ops, P = env
+    from codeformer_amd.facelib.align import estimate_affine_partial_2d
+    from codeformer_amd.facelib.utils.face_restoration_helper import _TEMPLATE_5, FaceRestoreHelper
+    frame = _img(720, 960, 5)
+    tpl = np.array(_TEMPLATE_5)
+
+    def landmarks(cx, cy, size, ang):
+        c, s = np.cos(ang), np.sin(ang)
+        return ((tpl - 256) / 512 * size) @ np.array([[c, -s], [s, c]]).T + [cx, cy]
+
+    scale = 640 / 720
+    rows = []
+    for cx, cy, size, ang in ((300, 260, 220, 0.15), (700, 420, 260, -0.2), (120, 600, 12, 0.0)):      # the third one is tiny
+        lm = landmarks(cx, cy, size, ang) * scale
+        box = [lm[:, 0].min() - 20, lm[:, 1].min() - 30, lm[:, 0].max() + 20, lm[:, 1].max() + 20, 0.99]
+        rows.append(box + lm.reshape(-1).tolist())
+    det = _FixedDetector(rows)
+    fh = FaceRestoreHelper(2, face_size=512, det_model='retinaface_resnet50', use_parse=False, device='cuda', face_detector=det)
+    fh.read_image(frame)
+    n = fh.get_face_landmarks_5(resize=640, eye_dist_threshold=5)
+    assert det.seen == (640, 853, 3) and n == 2                       # the 12-pixel face is dropped by the eye-distance rule
+    assert np.allclose(fh.all_landmarks_5[1], landmarks(700, 420, 260, -0.2), atol=1e-3)
+    fh.align_warp_face()
+    crops = fh.cropped_faces
+    assert len(crops) == 2 and crops[0].shape == (512, 512, 3)
+    for k in range(2):
+        m = estimate_affine_partial_2d(fh.all_landmarks_5[k], tpl)[0]
+        assert np.array_equal(fh.affine_matrices[k], m)
+        assert np.array_equal(crops[k], P.align_warp_face(frame, m))
+    restored = 255 - fh.cropped_faces_device
+    fh.add_restored_faces(restored)
+    fh.get_inverse_affine()
+    out = fh.paste_faces_to_input_image()
+    want = P.paste_faces(frame, [255 - c for c in crops], list(fh.affine_matrices), upscale=2)
+    assert out.shape == (1440, 1920, 3) and np.array_equal(out, want)
+    # only_center_face keeps the detection nearest to the image centre
+    fh.clean_all()
+    fh.read_image(frame)
+    assert fh.get_face_landmarks_5(only_center_face=True, resize=640, eye_dist_threshold=5) == 1
+    assert np.allclose(fh.all_landmarks_5[0], landmarks(300, 260, 220, 0.15), atol=1e-3)      # box centre 203 px from (480, 360); the other 231
+    # per-face host path of the reference's loop (add_restored_face with numpy arrays)
+    fh.align_warp_face()
+    fh.add_restored_face(255 - fh.cropped_faces[0], fh.cropped_faces[0])
+    out1 = fh.paste_faces_to_input_image()
+    want1 = P.paste_faces(frame, [255 - fh.cropped_faces[0]], list(fh.affine_matrices), upscale=2)
+    assert np.array_equal(out1, want1)
+
+
+def test_entrypoint_whole_images_with_host_detector(env, tmp_path):
+    """The reference's default invocation (no --has_aligned, no matrices file): RetinaFace runs on the host.  With seeded random
+    weights the detections are meaningless, but the flow -- read, detect at 640, fit, warp, restore, paste, result tree -- is the real one."""
+    import subprocess
+    import sys
+    from PIL import Image
+    src = tmp_path / 'whole_imgs'
+    os.makedirs(src)
+    Image.fromarray(_img(300, 400, 90)[:, :, ::-1]).save(src / 'a.png')         # short side below 512: enlarged to 512 x 683 first
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'inference_codeformer.py'), '-i', str(src), '-o', str(tmp_path / 'o'), '-s', '1',
+                        '--device', 'cuda', '--random_init_seed', '0', '--detection_model', 'retinaface_mobile0.25'],
+                       capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert 'detect ' in r.stdout and os.listdir(tmp_path / 'o' / 'final_results') == ['a.png']
+    assert np.asarray(Image.open(tmp_path / 'o' / 'final_results' / 'a.png')).shape == (512, 683, 3)

@@ -36,6 +36,17 @@ for cin, cout, H, swish, up in shapes:
         for _ in range(3):
             assert l.cf_conv2d(ctypes.byref(d), st) == 0, k
     torch.cuda.synchronize()
+    if os.environ.get('AB_COMPARE'):   # outputs and statistics partials of every variant against the first one, bitwise
+        ref = None
+        for k, l in libs.items():
+            out.fill_(float('nan')); stats.zero_()
+            assert l.cf_conv2d(ctypes.byref(d), st) == 0, k
+            torch.cuda.synchronize()
+            cur = (out.clone(), stats.clone())
+            if ref is None:
+                ref = cur
+            else:
+                print(f'   compare {k}: out equal {torch.equal(cur[0], ref[0])} nan {int(torch.isnan(cur[0]).sum())} stats equal {torch.equal(cur[1], ref[1])}', flush=True)
     for rnd in range(5):
         for k, l in libs.items():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

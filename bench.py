@@ -118,6 +118,8 @@ def roofline_leg(net, x, w):
         'conv3x3_wino': ('winograd_kernel<.,false> (3x3 s1 as Winograd F(2x2,3x3), fp32 MFMA)', 4.0 / 9.0, FP32_MFMA_PEAK_TFLOPS, ('winograd_kernel<false, false', 'winograd_kernel<true, false')),
         'conv3x3_wino_f16x2_8w': ('wsplit_kernel (3x3 s1 as Winograd F(2x2,3x3), 128 channels per 8-wave workgroup; U and V as hi+lo halves: 3 f16 '
                                   'MFMAs per transform-domain product, fp32 accumulate)', 3.0 * 4.0 / 9.0, F16_MFMA_PEAK_TFLOPS, ('wsplit_kernel',)),
+        'conv3x3_wino_f16_8w': ('wsplit_kernel<., F16> (Winograd F(2x2,3x3), single IEEE-half operands, one MFMA per product)', 4.0 / 9.0, F16_MFMA_PEAK_TFLOPS, ('wsplit_kernel',)),
+        'conv3x3_wino_bf16_8w': ('wsplit_kernel<., BF16> (Winograd F(2x2,3x3), single bf16 operands, one MFMA per product)', 4.0 / 9.0, F16_MFMA_PEAK_TFLOPS, ('wsplit_kernel',)),
         'conv3x3_wino_f16x2': ('winograd_kernel<.,true> (the same on the four-wave 64-channel kernel: 64-channel layers and the 16x16 latents)',
                                3.0 * 4.0 / 9.0, F16_MFMA_PEAK_TFLOPS, ('winograd_kernel<false, true', 'winograd_kernel<true, true')),
         'conv3x3': ('igemm_kernel<9,1,...> (direct 3x3 s1 implicit GEMM, fp32 MFMA)', 1.0, FP32_MFMA_PEAK_TFLOPS, ('igemm_kernel<9, 1',)),
@@ -255,7 +257,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': {'fp32': 'f32', 'f16x2': 'f32 (tensors, accumulation, Transformer / 1x1 / stride-2 convs / argmax on exact fp32 MFMA; 3x3 stride-1 '
                                                   'products on split operands: fp32 = hi + lo IEEE halves, 3 f16 MFMAs per product)'}.get(
-                args.precision, f'{args.precision} operands / f32 accumulate (generator+CFT); f32 (encoder, Transformer)'),
+                args.precision, f'{args.precision} operands / f32 accumulate (3x3 convs of generator + CFT); encoder on split halves (hi + lo, fp32-grade); f32 (Transformer, 1x1, stride 2)'),
             'data': 'synthetic',
             'config': {'workload': (('BASELINE config 2' if (args.precision in ('fp32', 'f16x2') and args.w == 0.5 and B == 16) else 'custom')
                                     + f': batch={B} aligned 512x512 faces per GPU, w={args.w}, adain=True, precision={args.precision}, '

@@ -168,8 +168,10 @@ class CodeFormer(VQAutoEncoder):
         #            7.1e-5; tolerance 1e-3), logits 6.7e-6 (exact: 7.6e-6; tolerance 1e-4), code indices identical.  1.5x the exact
         #            path's faces/s.
         #   'fp32':  everything on exact fp32 MFMA (Winograd F(2x2,3x3) where eligible, see below).
-        #   'bf16' (BASELINE configs 3/5) / 'fp16': single 16-bit operands with fp32 accumulate in generator + CFT, encoder exact fp32
-        #            (pixel gates in tests/test_gpu_real_images.py).
+        #   'bf16' (BASELINE configs 3/5) / 'fp16': single 16-bit operands with fp32 accumulate in generator + CFT -- in the Winograd domain
+        #            (one MFMA per transform-domain product, cf_wsplit.hip) for the 128-channel-tile layers from 32x32 up, the direct 16-bit
+        #            kernel elsewhere; the encoder runs as in the default mode (split halves, fp32-grade), so logits and code indices are
+        #            bitwise those of 'f16x2' (pixel gates in tests/test_gpu_real_images.py).
         self.precision = os.environ.get('CODEFORMER_HIP_PRECISION', 'f16x2')
         # Exact-fp32 convolutions (precision='fp32', and in every mode the layers the split kernel does not take): evaluate 3x3
         # stride-1 convolutions with Winograd F(2x2,3x3) -- the same function in fp32 with 2.25x fewer multiplies (cf_winograd.hip).
@@ -183,8 +185,8 @@ class CodeFormer(VQAutoEncoder):
         # reference's on every token whose reference gap is >= 1e-5 (tests/test_gpu_real_images.py).
         self.winograd_encoder = os.environ.get('CODEFORMER_HIP_WINOGRAD_ENCODER', '1') != '0'
         # Operand format of the ENCODER's 3x3 stride-1 convolutions: 'fp32' (exact fp32 MFMA, Winograd where eligible), 'f16x2' (the
-        # split-half kernel on every layer it covers: all but the first conv and the 16x16 latents) or 'auto' = 'f16x2' when
-        # precision is 'f16x2', 'fp32' otherwise.  The code indices hang on the encoder, so this was measured before it became the
+        # split-half kernel on every layer it covers: all but the first conv and the 16x16 latents) or 'auto' = 'fp32' when
+        # precision is 'fp32', 'f16x2' otherwise (a 16-bit generator does not ask for an exact-fp32 encoder at 0.54 of the fp32 MFMA peak).  The code indices hang on the encoder, so this was measured before it became the
         # default (tools/encoder_split_check.py, profiles/r02_encoder_split_check.txt): against the reference's logits on its own
         # crops the split encoder is as close as the exact one (max 6.7e-6 / 5.4e-6 / 5.7e-6 vs 7.6e-6 / 5.5e-6 / 6.0e-6; the
         # reference's own 1-vs-8-thread noise is 2.6e-6), the smallest (reference top-2 gap) / (2 x our logit error) over all tokens
@@ -233,7 +235,7 @@ class CodeFormer(VQAutoEncoder):
         if self.encoder_precision not in ('auto', 'fp32', 'f16x2'):
             raise ValueError(f"encoder_precision must be 'auto', 'fp32' or 'f16x2', got {self.encoder_precision!r}")
         enc_code = ops.WINOGRAD if (self.winograd and self.winograd_encoder) else 0
-        if self.encoder_precision == 'f16x2' or (self.encoder_precision == 'auto' and self.precision == 'f16x2'):
+        if self.encoder_precision == 'f16x2' or (self.encoder_precision == 'auto' and self.precision != 'fp32'):
             enc_code = ops.SPLIT if enc_code == ops.WINOGRAD else ops.SPLIT_DIRECT
         lq = self.encoder.forward_nhwc(x, enc_taps, bf16=enc_code)        # (B,16,16,256) channels-last
         T = lq.shape[1] * lq.shape[2]

@@ -549,8 +549,10 @@ __global__ void pack_weight_winograd_kernel(const float* __restrict__ w, int cou
 // H2 operands: U' = scale * G g G^T (fp64, rounded once to fp32) as hi = f16(U'), lo = f16(U' - hi), in MFMA-operand order
 // [pos][cin_pad/16][cout_pad/32][part: hi, lo][lane 64][4 words]; a lane's 16 bytes are the 8 halves of
 // U'[n = tile*32 + (lane&31)][c = chunk*16 + (lane>>5)*8 + 0..7]  (v_mfma_f32_32x32x16_f16 B operand).
+// bf16_single: the hi slot holds bf16(U') instead and the lo slot zeros (the single-operand bf16 form of cf_wsplit.hip; its IEEE-half
+// form reads the hi slot of the split packing as it is).
 __global__ void pack_weight_winograd_f16x2_kernel(const float* __restrict__ w, int cout, int cin, int cout_pad, int nchunks, float scale,
-                                                  unsigned* __restrict__ packed, long total) {
+                                                  unsigned* __restrict__ packed, long total, int bf16_single) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one 32-bit word = two halves
   if (i >= total) return;
   const int e = (int)(i & 3), ln = (int)((i >> 2) & 63), part = (int)((i >> 8) & 1);
@@ -577,17 +579,22 @@ __global__ void pack_weight_winograd_f16x2_kernel(const float* __restrict__ w, i
       const double u = nu == 0 ? row[0] : (nu == 1 ? 0.5 * (row[0] + row[1] + row[2]) : (nu == 2 ? 0.5 * (row[0] - row[1] + row[2]) : row[2]));
       val = (float)(u * (double)scale);
     }
-    const _Float16 hi = (_Float16)val;
-    const _Float16 hv = part ? (_Float16)(val - (float)hi) : hi;
-    out |= (unsigned)__builtin_bit_cast(unsigned short, hv) << (16 * h);
+    if (bf16_single) {
+      const __bf16 bv = (__bf16)(part ? 0.f : val);
+      out |= (unsigned)__builtin_bit_cast(unsigned short, bv) << (16 * h);
+    } else {
+      const _Float16 hi = (_Float16)val;
+      const _Float16 hv = part ? (_Float16)(val - (float)hi) : hi;
+      out |= (unsigned)__builtin_bit_cast(unsigned short, hv) << (16 * h);
+    }
   }
   packed[i] = out;
 }
 
 }  // namespace
 
-extern "C" int cf_pack_conv_weight_winograd_f16x2(const float* w, int cout, int cin, int cout_pad, int cin_pad, float scale, void* packed,
-                                                  cf_stream_t stream) {
+static int pack_winograd_halves(const float* w, int cout, int cin, int cout_pad, int cin_pad, float scale, void* packed, cf_stream_t stream,
+                                int bf16_single) {
   CF_REQUIRE(w && packed, "cf_pack_conv_weight_winograd_f16x2: null pointer");
   CF_REQUIRE(cin_pad % CF_BK == 0 && cin_pad >= cin && cout_pad >= cout && cout_pad % 64 == 0,
              "cf_pack_conv_weight_winograd_f16x2: bad padding cin %d->%d cout %d->%d", cin, cin_pad, cout, cout_pad);
@@ -595,9 +602,17 @@ extern "C" int cf_pack_conv_weight_winograd_f16x2(const float* w, int cout, int 
   CF_REQUIRE(scale > 0.f && frexpf(scale, &ex) == 0.5f, "cf_pack_conv_weight_winograd_f16x2: scale %g is not a power of two", (double)scale);
   const long total = 16L * cin_pad * cout_pad;  // 32-bit words: hi + lo half per weight
   hipLaunchKernelGGL(pack_weight_winograd_f16x2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
-                     cout, cin, cout_pad, cin_pad / CF_BK, scale, reinterpret_cast<unsigned*>(packed), total);
+                     cout, cin, cout_pad, cin_pad / CF_BK, scale, reinterpret_cast<unsigned*>(packed), total, bf16_single);
   CF_CHECK_LAUNCH("cf_pack_conv_weight_winograd_f16x2");
   return CF_OK;
+}
+extern "C" int cf_pack_conv_weight_winograd_f16x2(const float* w, int cout, int cin, int cout_pad, int cin_pad, float scale, void* packed,
+                                                  cf_stream_t stream) {
+  return pack_winograd_halves(w, cout, cin, cout_pad, cin_pad, scale, packed, stream, 0);
+}
+extern "C" int cf_pack_conv_weight_winograd_bf16(const float* w, int cout, int cin, int cout_pad, int cin_pad, float scale, void* packed,
+                                                 cf_stream_t stream) {
+  return pack_winograd_halves(w, cout, cin, cout_pad, cin_pad, scale, packed, stream, 1);
 }
 
 extern "C" int cf_pack_conv_weight_winograd(const float* w, int cout, int cin, int cout_pad, int cin_pad, float* packed,
@@ -618,9 +633,11 @@ int cf_wsplit_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query
 // Called by cf_conv2d (cf_igemm.hip) for descriptors with winograd != 0; the common argument checks have run there.
 int cf_winograd_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query) {
   CF_REQUIRE(d->taps == 9 && d->stride == 1 && !d->upsample && !d->in_nchw && !d->out_nchw &&
-                 (d->bf16_mfma == CF_OPERAND_F32 || d->bf16_mfma == CF_OPERAND_F16X2),
-             "cf_conv2d: winograd covers fp32 and split-half (f16x2) 3x3 stride-1 NHWC convolutions");
-  const bool h2 = d->bf16_mfma == CF_OPERAND_F16X2;
+                 d->bf16_mfma >= CF_OPERAND_F32 && d->bf16_mfma <= CF_OPERAND_F16X2,
+             "cf_conv2d: winograd covers 3x3 stride-1 NHWC convolutions");
+  const bool h1 = d->bf16_mfma == CF_OPERAND_F16 || d->bf16_mfma == CF_OPERAND_BF16;  // single 16-bit operands: the eight-wave kernel only
+  CF_REQUIRE(!h1 || cf_wsplit_covers(d), "cf_conv2d(winograd, single 16-bit operands): needs cout %% 128 == 0 and at least 32x32 pixels per image");
+  const bool h2 = d->bf16_mfma == CF_OPERAND_F16X2 || h1;
   CF_REQUIRE(!h2 || d->acc_scale > 0.f, "cf_conv2d(winograd, f16x2): acc_scale must be the inverse of the pack-time weight scale (got %g)",
              (double)d->acc_scale);
   CF_REQUIRE(d->hout % WG_TH == 0 && d->wout % WG_TW == 0, "cf_conv2d: winograd needs an output of %dx%d multiples (got %dx%d)",
@@ -633,6 +650,7 @@ int cf_winograd_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_que
                  (d->ld_out == 0 || d->ld_out == d->cout),
              "cf_conv2d: winograd reads / writes dense tensors with zero padding");
   if (h2 && cf_wsplit_covers(d)) return cf_wsplit_launch(d, stream, parts_query);
+  CF_REQUIRE(!h1, "cf_conv2d(winograd, single 16-bit operands): not covered");
   WinoArgs a;
   a.in0 = d->in0;
   a.in1 = d->in1;

@@ -21,6 +21,11 @@
 //     after its last use (a whole iteration of cover).
 // Epilogue (nu axis in registers, xi axis through LDS, bias / residual / SFT, GroupNorm statistics of what was written) as in
 // cf_winograd.hip, one 64-channel half per four-wave group.
+//
+// OP = CF_OPERAND_F16 / CF_OPERAND_BF16 (precision 'fp16' / 'bf16' of the network: BASELINE configs 3 and 5): the same kernel with
+// SINGLE 16-bit operands -- U rounded once at pack time (the hi slot of the same fragment layout), V rounded when a lane reads its
+// fragment, one MFMA per transform-domain product instead of three, half the weight-fragment registers and L2 traffic, no lo
+// conversion.  fp32 tensors, transform, accumulation and epilogue are unchanged.
 #include <type_traits>
 
 #include "cf_common.h"
@@ -74,9 +79,10 @@ struct WsArgs {
 
 // PRO = the prologue (enum cf_prologue) as a template parameter: with a switch inside the slab loop hipcc's wait-count pass merged the
 // branches into s_waitcnt vmcnt(0) before the patch store, i.e. every iteration waited for the weight fragments it had just requested.
-template <int PRO>
+template <int PRO, int OP = CF_OPERAND_F16X2>
 __global__ __launch_bounds__(WS_THREADS, 1) void wsplit_kernel(const WsArgs a) {
   constexpr int NI = WS_NI;
+  constexpr int NPART = OP == CF_OPERAND_F16X2 ? 2 : 1;  // weight-fragment parts a lane keeps: hi + lo, or the single rounded operand
   constexpr int APT = 2;  // float4 gather items per thread: 256 pixel slots x 4 quads / 512 threads
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const patch0 = smem;
@@ -199,13 +205,13 @@ __global__ __launch_bounds__(WS_THREADS, 1) void wsplit_kernel(const WsArgs a) {
       for (int r = 0; r < 16; ++r) acc[nu][ni][r] = 0.f;
   const size_t pos_stride = (size_t)a.nchunks * a.cout * CF_BK;
   const float* const wlane = a.weight + (size_t)(xi * 4) * pos_stride + (size_t)(n0 / 32) * 512 + lane * 4;
-  f32x4 bq[4][NI][2];  // [nu][n tile][hi, lo]
+  f32x4 bq[4][NI][NPART];  // [nu][n tile][hi, lo]
   auto load_B = [&](int chunk, int nu) __attribute__((always_inline)) {
     const float* wc = wlane + (size_t)chunk * a.cout * CF_BK + nu * pos_stride;
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int part = 0; part < 2; ++part) bq[nu][ni][part] = *reinterpret_cast<const f32x4*>(wc + ni * 512 + part * 256);
+      for (int part = 0; part < NPART; ++part) bq[nu][ni][part] = *reinterpret_cast<const f32x4*>(wc + ni * 512 + part * 256);
   };
   const int a_off = (xi * 4) * WS_PS + l31 * CF_LDK + half * 8;
   // A fragments: this lane's 8 channels of the slab (row = tile l31, channels half*8 .. +7) of position (xi, nu); the reads for
@@ -217,27 +223,55 @@ __global__ __launch_bounds__(WS_THREADS, 1) void wsplit_kernel(const WsArgs a) {
   };
   auto mma = [&](int nu) __attribute__((always_inline)) {
     const f32x4 v0 = va[nu & 1][0], v1 = va[nu & 1][1];
-    f32x4 ah, al;
+    if constexpr (OP != CF_OPERAND_F16X2) {  // single 16-bit operands: round to nearest even, one MFMA per product
+      f32x4 as;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float x0 = e < 2 ? v0[2 * e] : v1[2 * e - 4], x1 = e < 2 ? v0[2 * e + 1] : v1[2 * e - 3];
-      float hh, ll;
-      cf_split_pair(x0, x1, hh, ll);
-      ah[e] = hh;
-      al[e] = ll;
-    }
+      for (int e = 0; e < 4; ++e) {
+        const float x0 = e < 2 ? v0[2 * e] : v1[2 * e - 4], x1 = e < 2 ? v0[2 * e + 1] : v1[2 * e - 3];
+        if constexpr (OP == CF_OPERAND_F16) {
+          const ws_f16x2 h = {(_Float16)x0, (_Float16)x1};
+          as[e] = __builtin_bit_cast(float, h);
+        } else {
+          typedef __bf16 ws_bf16x2 __attribute__((ext_vector_type(2)));
+          const ws_bf16x2 h = {(__bf16)x0, (__bf16)x1};
+          as[e] = __builtin_bit_cast(float, h);
+        }
+      }
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
+      for (int ni = 0; ni < NI; ++ni) {
+        if constexpr (OP == CF_OPERAND_F16) {
+          acc[nu][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ws_f16x8, as), __builtin_bit_cast(ws_f16x8, bq[nu][ni][0]),
+                                                               acc[nu][ni], 0, 0, 0);
+        } else {
+          typedef __bf16 ws_bf16x8 __attribute__((ext_vector_type(8)));
+          acc[nu][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ws_bf16x8, as), __builtin_bit_cast(ws_bf16x8, bq[nu][ni][0]),
+                                                                acc[nu][ni], 0, 0, 0);
+        }
+      }
+      return;
+    } else {
+      f32x4 ah, al;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x0 = e < 2 ? v0[2 * e] : v1[2 * e - 4], x1 = e < 2 ? v0[2 * e + 1] : v1[2 * e - 3];
+        float hh, ll;
+        cf_split_pair(x0, x1, hh, ll);
+        ah[e] = hh;
+        al[e] = ll;
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
 #if WS_ABLATE & 1
-      acc[nu][ni][0] += al[0] + ah[1] + bq[nu][ni][0][0] + bq[nu][ni][1][1];
-      continue;
+        acc[nu][ni][0] += al[0] + ah[1] + bq[nu][ni][0][0] + bq[nu][ni][NPART - 1][1];
+        continue;
 #endif
-      acc[nu][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ws_f16x8, al), __builtin_bit_cast(ws_f16x8, bq[nu][ni][0]),
-                                                           acc[nu][ni], 0, 0, 0);
-      acc[nu][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ws_f16x8, ah), __builtin_bit_cast(ws_f16x8, bq[nu][ni][1]),
-                                                           acc[nu][ni], 0, 0, 0);
-      acc[nu][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ws_f16x8, ah), __builtin_bit_cast(ws_f16x8, bq[nu][ni][0]),
-                                                           acc[nu][ni], 0, 0, 0);
+        acc[nu][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ws_f16x8, al), __builtin_bit_cast(ws_f16x8, bq[nu][ni][0]),
+                                                             acc[nu][ni], 0, 0, 0);
+        acc[nu][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ws_f16x8, ah), __builtin_bit_cast(ws_f16x8, bq[nu][ni][NPART - 1]),
+                                                             acc[nu][ni], 0, 0, 0);
+        acc[nu][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ws_f16x8, ah), __builtin_bit_cast(ws_f16x8, bq[nu][ni][0]),
+                                                             acc[nu][ni], 0, 0, 0);
+      }
     }
   };
   auto mma_stage = [&](const float* V, int next_chunk) __attribute__((always_inline)) {
@@ -417,7 +451,8 @@ __global__ __launch_bounds__(WS_THREADS, 1) void wsplit_kernel(const WsArgs a) {
 
 // Called by cf_winograd_launch (cf_winograd.hip) for split-half Winograd descriptors this kernel covers; argument checks have run there.
 bool cf_wsplit_covers(const cf_conv_desc* d) {
-  return d->winograd && d->bf16_mfma == CF_OPERAND_F16X2 && d->split_k < 1 && d->cout % WS_BN == 0 && d->cout_pad == d->cout &&
+  return d->winograd && (d->bf16_mfma == CF_OPERAND_F16X2 || d->bf16_mfma == CF_OPERAND_F16 || d->bf16_mfma == CF_OPERAND_BF16) &&
+         d->split_k < 1 && d->cout % WS_BN == 0 && d->cout_pad == d->cout &&
          d->hout % WS_TH == 0 && d->wout % WS_TW == 0 && (long)d->hout * d->wout >= 32 * 32 && (d->stats_cpg == 0 || d->stats_cpg >= 4);
 }
 
@@ -460,10 +495,14 @@ int cf_wsplit_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query
   (void)hipGetDevice(&dev);
   if (dev >= 64 || !((attr_devs >> dev) & 1ull)) {
     hipError_t e = hipSuccess;
-    const void* const kerns[4] = {reinterpret_cast<const void*>(wsplit_kernel<CF_PRO_NONE>), reinterpret_cast<const void*>(wsplit_kernel<CF_PRO_AFFINE>),
-                                  reinterpret_cast<const void*>(wsplit_kernel<CF_PRO_AFFINE_SWISH>),
-                                  reinterpret_cast<const void*>(wsplit_kernel<CF_PRO_LEAKY>)};
-    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipFuncSetAttribute(kerns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const void* const kerns[12] = {
+        reinterpret_cast<const void*>(wsplit_kernel<CF_PRO_NONE>), reinterpret_cast<const void*>(wsplit_kernel<CF_PRO_AFFINE>),
+        reinterpret_cast<const void*>(wsplit_kernel<CF_PRO_AFFINE_SWISH>), reinterpret_cast<const void*>(wsplit_kernel<CF_PRO_LEAKY>),
+        reinterpret_cast<const void*>(wsplit_kernel<CF_PRO_NONE, CF_OPERAND_F16>), reinterpret_cast<const void*>(wsplit_kernel<CF_PRO_AFFINE, CF_OPERAND_F16>),
+        reinterpret_cast<const void*>(wsplit_kernel<CF_PRO_AFFINE_SWISH, CF_OPERAND_F16>), reinterpret_cast<const void*>(wsplit_kernel<CF_PRO_LEAKY, CF_OPERAND_F16>),
+        reinterpret_cast<const void*>(wsplit_kernel<CF_PRO_NONE, CF_OPERAND_BF16>), reinterpret_cast<const void*>(wsplit_kernel<CF_PRO_AFFINE, CF_OPERAND_BF16>),
+        reinterpret_cast<const void*>(wsplit_kernel<CF_PRO_AFFINE_SWISH, CF_OPERAND_BF16>), reinterpret_cast<const void*>(wsplit_kernel<CF_PRO_LEAKY, CF_OPERAND_BF16>)};
+    for (int i = 0; i < 12 && e == hipSuccess; ++i) e = hipFuncSetAttribute(kerns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       cf_set_error("cf_conv2d(winograd f16x2): hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
       return CF_ERR_LAUNCH;
@@ -471,12 +510,18 @@ int cf_wsplit_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query
     if (dev < 64) attr_devs |= 1ull << dev;  // benign race: the attribute call is idempotent
   }
   const dim3 grid(a.tiles_per_img * d->batch * a.ntn), block(WS_THREADS);
-  switch (d->prologue) {
-    case CF_PRO_AFFINE: hipLaunchKernelGGL(wsplit_kernel<CF_PRO_AFFINE>, grid, block, lds, stream, a); break;
-    case CF_PRO_AFFINE_SWISH: hipLaunchKernelGGL(wsplit_kernel<CF_PRO_AFFINE_SWISH>, grid, block, lds, stream, a); break;
-    case CF_PRO_LEAKY: hipLaunchKernelGGL(wsplit_kernel<CF_PRO_LEAKY>, grid, block, lds, stream, a); break;
-    default: hipLaunchKernelGGL(wsplit_kernel<CF_PRO_NONE>, grid, block, lds, stream, a); break;
-  }
+  auto launch_op = [&](auto op) {
+    constexpr int OP = decltype(op)::value;
+    switch (d->prologue) {
+      case CF_PRO_AFFINE: hipLaunchKernelGGL((wsplit_kernel<CF_PRO_AFFINE, OP>), grid, block, lds, stream, a); break;
+      case CF_PRO_AFFINE_SWISH: hipLaunchKernelGGL((wsplit_kernel<CF_PRO_AFFINE_SWISH, OP>), grid, block, lds, stream, a); break;
+      case CF_PRO_LEAKY: hipLaunchKernelGGL((wsplit_kernel<CF_PRO_LEAKY, OP>), grid, block, lds, stream, a); break;
+      default: hipLaunchKernelGGL((wsplit_kernel<CF_PRO_NONE, OP>), grid, block, lds, stream, a); break;
+    }
+  };
+  if (d->bf16_mfma == CF_OPERAND_F16) launch_op(std::integral_constant<int, CF_OPERAND_F16>{});
+  else if (d->bf16_mfma == CF_OPERAND_BF16) launch_op(std::integral_constant<int, CF_OPERAND_BF16>{});
+  else launch_op(std::integral_constant<int, CF_OPERAND_F16X2>{});
   CF_CHECK_LAUNCH("cf_conv2d(winograd f16x2)");
   return CF_OK;
 }

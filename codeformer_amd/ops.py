@@ -63,6 +63,8 @@ SPLIT = 4      # ... the split-half evaluation: fp32 operands as hi + lo IEEE ha
 SPLIT_DIRECT = 5   # ... the same, but layers the split kernel does not take run on the direct fp32 kernel instead of Winograd
 WSPLIT = 6     # ... Winograd F(2x2,3x3) with split-half operands in the 16 transform-domain GEMMs (cf_winograd.hip, H2)
 GSPLIT = 7     # ... a Linear / 1x1 weight for the split-half token GEMM (cf_gemm_split.hip)
+WF16 = 8       # ... Winograd F(2x2,3x3) with SINGLE IEEE-half operands (eight-wave kernel of cf_wsplit.hip; precision 'fp16')
+WBF16 = 9      # ... the same with single bf16 operands (precision 'bf16')
 OPERAND_F16X2 = 3   # enum cf_operand value behind SPLIT / WSPLIT / GSPLIT
 # SPLIT layers that the Winograd kernel covers take its split-half form (4/9 of the MFMA work); CODEFORMER_HIP_SPLIT_WINOGRAD=0
 # keeps them on the direct split-half kernel.
@@ -83,6 +85,16 @@ def winograd_ok(cin, cout, hout, wout):
 SPLIT_MIN_PIXELS = 32 * 32   # below this input size (the 16x16 latents) the layer stays on fp32 Winograd: too few 8x16 tiles per image
 
 
+def wsingle_ok(cin, cout, h, w):
+    """Shapes the eight-wave Winograd kernel covers (the rule of cf_wsplit_covers): 128-wide channel tiles from 32x32 pixels up."""
+    return winograd_ok(cin, cout, h, w) and cout % 128 == 0 and h * w >= SPLIT_MIN_PIXELS
+
+
+# Single 16-bit operand modes ('bf16' / 'fp16'): layers the eight-wave Winograd kernel covers run there (one MFMA per transform-domain
+# product); CODEFORMER_HIP_WINOGRAD_16BIT=0 keeps every layer on the direct 16-bit instantiations of cf_igemm.hip.
+WINOGRAD_16BIT = os.environ.get('CODEFORMER_HIP_WINOGRAD_16BIT', '1') != '0'
+
+
 def conv_code(code, cin, cout, h, w, up2x=False, c_split=None, plain=True):
     """Operand code a 3x3 stride-1 convolution really runs with, given the requested one and its shape ((h, w) = INPUT size).
     SPLIT falls back to WINOGRAD and WINOGRAD to the direct fp32 kernel where their kernels do not apply; the decision depends
@@ -98,6 +110,8 @@ def conv_code(code, cin, cout, h, w, up2x=False, c_split=None, plain=True):
         return WINOGRAD if (plain and not up2x and winograd_ok(cin, cout, h, w)) else 0
     if code and not (plain and cin % 32 == 0 and cout % 4 == 0):
         return 0
+    if code in (1, 2) and WINOGRAD_16BIT and plain and not up2x and wsingle_ok(cin, cout, h, w):
+        return WBF16 if code == 1 else WF16
     return code
 
 
@@ -128,7 +142,7 @@ def pack_weight(weight, bias=None, bf16=False, up2x=False, f16=False):
         L.check(lib.cf_pack_linear_weight_f16x2(L.ptr(w2.contiguous()), cout, cin, scale, L.ptr(packed, dtype=None), L.stream_ptr()),
                 'cf_pack_linear_weight_f16x2')
         return PackedWeight(packed, b, cout, cin, 1, cout, cin, bf16=OPERAND_F16X2, scale=scale)
-    if code == WSPLIT:
+    if code in (WSPLIT, WF16, WBF16):
         if up2x or w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or cin % 16 or cout % 64:
             raise ValueError('winograd f16x2 packing needs a 3x3 weight with cin % 16 == 0 and cout % 64 == 0 (no up2x)')
         # max |G g G^T| for the power-of-two scale (elementwise: G's rows are g0, (g0 + g1 + g2)/2, (g0 - g1 + g2)/2, g2)
@@ -140,9 +154,10 @@ def pack_weight(weight, bias=None, bf16=False, up2x=False, f16=False):
             umax = max(umax, max(float(c.abs().max()) for c in cols))
         scale = 1.0 if umax == 0.0 or not math.isfinite(umax) else 2.0 ** (14 - math.frexp(umax)[1] + 1)
         packed = torch.empty(16 * cin * cout, dtype=torch.float32, device=w.device)
-        L.check(lib.cf_pack_conv_weight_winograd_f16x2(L.ptr(w), cout, cin, cout, cin, scale, L.ptr(packed, dtype=None), L.stream_ptr()),
-                'cf_pack_conv_weight_winograd_f16x2')
-        return PackedWeight(packed, b, cout, cin, 9, cout, cin, bf16=OPERAND_F16X2, wino=True, scale=scale)
+        fn = 'cf_pack_conv_weight_winograd_bf16' if code == WBF16 else 'cf_pack_conv_weight_winograd_f16x2'   # (WF16 reads the hi slot)
+        L.check(getattr(lib, fn)(L.ptr(w), cout, cin, cout, cin, scale, L.ptr(packed, dtype=None), L.stream_ptr()), fn)
+        operand = {WSPLIT: OPERAND_F16X2, WF16: 2, WBF16: 1}[code]
+        return PackedWeight(packed, b, cout, cin, 9, cout, cin, bf16=operand, wino=True, scale=scale)
     if code == SPLIT:
         if w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or cin % 32 or cout % 64:
             raise ValueError('f16x2 packing needs a 3x3 weight with cin % 32 == 0 and cout % 64 == 0')

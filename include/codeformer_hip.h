@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 13
+#define CF_ABI_VERSION 14
 
 typedef void* cf_stream_t; /* hipStream_t */
 
@@ -145,7 +145,9 @@ typedef struct cf_conv_desc {
                              is below the direct kernel's, so the host uses it for every eligible 3x3 stride-1 convolution.
                              With bf16_mfma == CF_OPERAND_F16X2 (`weight` from cf_pack_conv_weight_winograd_f16x2, acc_scale set)
                              the 16 Winograd-domain GEMMs run on split operands: U and V as hi + lo IEEE halves, three f16
-                             MFMAs per product, fp32 accumulation -- 4/9 of the split-half MFMA work of the direct form */
+                             MFMAs per product, fp32 accumulation -- 4/9 of the split-half MFMA work of the direct form.
+                             With CF_OPERAND_F16 / CF_OPERAND_BF16 (cout % 128 == 0, >= 32x32 pixels): single rounded operands,
+                             one MFMA per product (weight: see cf_pack_conv_weight_winograd_bf16) */
   float acc_scale;        /* CF_OPERAND_F16X2 only (direct or winograd): the accumulator is multiplied by this before the bias is added -- the exact
                              inverse of the power-of-two scale given to cf_pack_conv_weight_f16x2 (> 0) */
   /* Deterministic split-K for layers with few output tiles (one face: 16x16 .. 64x64 pixels), where latency is the serial K loop of
@@ -178,6 +180,12 @@ int cf_pack_conv_weight_winograd(const float* w, int cout, int cin, int cout_pad
  * words); `scale` is a power of two that puts max|scale * U| into [2^14, 2^15) (cf_conv_desc.acc_scale = 1 / scale) */
 int cf_pack_conv_weight_winograd_f16x2(const float* w, int cout, int cin, int cout_pad, int cin_pad, float scale, void* packed,
                                        cf_stream_t stream);
+/* winograd + SINGLE 16-bit operands (cout % 128 == 0, at least 32x32 pixels per image: the eight-wave kernel of cf_wsplit.hip; the
+ * network's 'fp16' / 'bf16' modes, BASELINE configs 3 and 5): one MFMA per transform-domain product.  CF_OPERAND_F16 reads the hi slot of
+ * the split packing above as it is; CF_OPERAND_BF16 takes this buffer: bf16(scale * U) in the hi slot of the same layout, zeros in the
+ * lo slot (same size; scale a power of two, acc_scale = 1 / scale) */
+int cf_pack_conv_weight_winograd_bf16(const float* w, int cout, int cin, int cout_pad, int cin_pad, float scale, void* packed,
+                                      cf_stream_t stream);
 /* taps == 1 + CF_OPERAND_F16X2 (Linear / 1x1 on token matrices, codeformer_arch.py:104-106,126,132,183,192): w[n][k] -> scale * w as
  * hi + lo IEEE halves in MFMA-operand order (n*k 32-bit words); n % 64 == 0, k % 128 == 0.  The launch needs M = batch*hout*wout % 64 == 0,
  * a dense single input, no prologue / statistics, epilogue none | GELU | residual; split_k as for the fp32 GEMM (same bits for every count) */

@@ -11,7 +11,7 @@ The checks themselves live in tools/gpu_check.py (also runnable stand-alone with
           logits 1e-4, code indices bit-exact; batch-of-4 == batch-of-1 bitwise; run-to-run bitwise
   bf16    the bf16-MFMA conv instantiations against fp64 convs of the SAME bf16-rounded operands (2e-4: only the
           accumulation order differs), and the whole net with precision='bf16' (BASELINE configs 3/5: generator + CFT in
-          bf16, encoder/Transformer/argmax fp32): logits bitwise equal to the fp32 mode, code indices exact, pixels within
+          bf16, encoder on split halves, Transformer/argmax fp32): logits bitwise equal to the default mode, code indices exact, pixels within
           the stated bf16 gate of the fp32 reference (max|d| <= 0.25, mean|d| <= 0.02 on outputs of std 0.5); precision='fp16'
           (IEEE-half operands, same split): same logits / indices conditions, pixel gate max|d| <= 0.04, mean|d| <= 0.003
 """
@@ -141,16 +141,17 @@ def test_inpainting_config(chk):
     assert float((logits.cpu() - torch.from_numpy(g['logits'])).abs().max()) <= 1e-4
     assert np.array_equal(net.last_indices.cpu().numpy(), g['idx'])
     assert float((out.cpu()[:, :, ::4, ::4] - torch.from_numpy(g['out_sub'])).abs().max()) <= 1e-3
+    logits_default = logits
     net.precision = 'fp32'                                                   # (the run above was the default, split-half, mode)
     out, logits, _ = net(seeded_input(1).cuda(), w=1, adain=False)
     assert float((logits.cpu() - torch.from_numpy(g['logits'])).abs().max()) <= 1e-4
     assert float((out.cpu()[:, :, ::4, ::4] - torch.from_numpy(g['out_sub'])).abs().max()) <= 1e-3
-    # BASELINE config 5 names bf16: 16-bit operands in generator + CFT only -> logits bitwise those of fp32 mode, indices
-    # exact, pixels inside the gates of tools/gpu_check.py:g_bf16 (bf16 0.25 max, fp16 0.04 max on outputs of std ~0.5)
+    # BASELINE config 5 names bf16: 16-bit operands in generator + CFT only (the encoder runs as in the default mode) -> logits bitwise
+    # those of the default mode, indices exact, pixels inside the gates of tools/gpu_check.py:g_bf16 (bf16 0.25 max, fp16 0.04 max on outputs of std ~0.5)
     for prec, gate in (('bf16', 0.25), ('fp16', 0.04)):
         net.precision = prec
         out16, logits16, _ = net(seeded_input(1).cuda(), w=1, adain=False)
-        assert torch.equal(logits16, logits) and np.array_equal(net.last_indices.cpu().numpy(), g['idx'])
+        assert torch.equal(logits16, logits_default) and np.array_equal(net.last_indices.cpu().numpy(), g['idx'])
         d = (out16 - out).abs()
         print(f'inpainting config {prec}: max|d| {float(d.max()):.4f} mean|d| {float(d.mean()):.5f}')
         assert float(d.max()) <= gate

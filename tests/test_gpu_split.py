@@ -193,3 +193,63 @@ def test_splitk_winograd_bits_do_not_depend_on_the_split_count(sc):
         if B > 1:
             kw1 = dict(kw, scale=sc_[:1].cuda(), shift=sh_[:1].cuda(), res=res[:1].cuda() if epi else None)
             assert torch.equal(ops.conv2d(x[:1].cuda(), pw, **kw1), ops.conv2d(x.cuda(), pw, **kw)[:1])
+
+
+def test_winograd_single_16bit_operands(sc):
+    """precision 'fp16' / 'bf16' on the eight-wave Winograd kernel (ops.WF16 / ops.WBF16: U and V rounded once to 16 bits, one MFMA per
+    transform-domain product).  Oracle: the SAME convolution in fp64 on operands rounded the way the kernel rounds them is not
+    available in closed form (V is rounded after the input transform), so the gates are the operand formats' own error levels against
+    the fp64 convolution of the unrounded operands -- K = 9*128 products of relative error 2^-11 (half) / 2^-8 (bf16) each -- and, as
+    a sharper check of the data path, agreement with the split-half kernel (three MFMAs per product) far below those levels when the
+    inputs are exactly representable in 8 bits.  Also: prologue / residual / statistics, bitwise repeatability and batch invariance,
+    the C ABI's refusal of shapes the eight-wave kernel does not cover."""
+    import torch
+    import torch.nn.functional as F
+    from codeformer_amd import ops
+    g = torch.Generator().manual_seed(91)
+    B, H, W, C = 3, 32, 48, 128
+    x = torch.randn(B, H, W, C, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) * 0.03
+    b = torch.randn(C, generator=g)
+    sc_, sh_ = torch.rand(B, C, generator=g) + 0.5, torch.randn(B, C, generator=g) * 0.1
+    res = torch.randn(B, H, W, C, generator=g)
+    y = x.double() * sc_.double()[:, None, None, :] + sh_.double()[:, None, None, :]
+    y = y * torch.sigmoid(y)
+    ref = F.conv2d(y.permute(0, 3, 1, 2), w.double(), b.double(), padding=1).permute(0, 2, 3, 1) + res.double()
+    rms = float(ref.pow(2).mean().sqrt())
+    xs, ws_, bs, scd, shd, resd = (t.cuda() for t in (x, w, b, sc_, sh_, res))
+    outs = {}
+    for name, code, gate in (('f16x2', ops.WSPLIT, 2e-5), ('fp16', ops.WF16, 4e-3), ('bf16', ops.WBF16, 3e-2)):
+        pw = ops.pack_weight(ws_, bs, bf16=code)
+        o = ops.conv2d(xs, pw, prologue=ops.PRO_AFFINE_SWISH, scale=scd, shift=shd, epilogue=ops.EPI_RESIDUAL, res=resd, emit_stats=True)
+        o2 = ops.conv2d(xs, pw, prologue=ops.PRO_AFFINE_SWISH, scale=scd, shift=shd, epilogue=ops.EPI_RESIDUAL, res=resd, emit_stats=True)
+        assert torch.equal(o, o2) and torch.equal(o._cf_stats.part, o2._cf_stats.part), name
+        o1 = ops.conv2d(xs[1:2].contiguous(), pw, prologue=ops.PRO_AFFINE_SWISH, scale=scd[1:2].contiguous(), shift=shd[1:2].contiguous(),
+                        epilogue=ops.EPI_RESIDUAL, res=resd[1:2].contiguous(), emit_stats=True)
+        assert torch.equal(o[1:2], o1), name
+        err = (o.double().cpu() - ref).abs()
+        print(f'winograd {name}: max {float(err.max()):.3e} mean {float(err.mean()):.3e} (output rms {rms:.3f})')
+        assert float(err.max()) <= gate * max(1.0, rms) * 4 and float(err.mean()) <= gate * max(1.0, rms) * 0.5, (name, float(err.max()), float(err.mean()))
+        # statistics partials describe what was written (a thread adds its 16 values in fp32 before the fp64 partials)
+        s = o._cf_stats
+        tot = s.part.view(B, 32, s.parts, 2).sum(dim=2).cpu()
+        grp = o.double().cpu().view(B, H * W, 32, C // 32)
+        assert torch.allclose(tot[..., 0], grp.sum(dim=(1, 3)), rtol=1e-5, atol=5e-3) and \
+            torch.allclose(tot[..., 1], grp.pow(2).sum(dim=(1, 3)), rtol=1e-5, atol=5e-3), name
+        outs[name] = o
+    # inputs exactly representable in 8 significant bits: V = B^T d B (sums of four such values) and U are not, but the single-operand
+    # kernels must then sit within their rounding of U and V only -- and the data path (fragment order, scale, epilogue) is the split kernel's
+    xq = (torch.randint(-8, 9, (1, 32, 32, 128), generator=g).float() / 8).cuda()
+    wq = (torch.randint(-4, 5, (128, 128, 3, 3), generator=g).float() / 64).cuda()
+    exact = F.conv2d(xq.double().permute(0, 3, 1, 2), wq.double(), padding=1).permute(0, 2, 3, 1)
+    for code, tol in ((ops.WSPLIT, 1e-5), (ops.WF16, 1e-5), (ops.WBF16, 2e-2)):
+        o = ops.conv2d(xq, ops.pack_weight(wq, None, bf16=code))
+        # G g G^T of multiples of 1/64 has at most 8 significant bits (quarters of sums of nine small integers), B^T d B at most 7:
+        # exact in IEEE half, so 'fp16' reproduces the convolution exactly here; bf16 (8 bits) rounds some U
+        assert float((o.double() - exact).abs().max()) <= tol, (code, float((o.double() - exact).abs().max()))
+    # shapes outside the eight-wave kernel: the host falls back to the direct 16-bit kernel, the C ABI refuses
+    assert ops.conv_code(2, 128, 128, 32, 48) == ops.WF16 and ops.conv_code(1, 128, 128, 32, 48) == ops.WBF16
+    assert ops.conv_code(2, 64, 64, 512, 512) == 2 and ops.conv_code(1, 512, 512, 16, 16) == 1 and ops.conv_code(2, 128, 128, 32, 32, up2x=True) == 2
+    pw64 = ops.pack_weight(torch.randn(64, 64, 3, 3, device='cuda') * 0.05, None, bf16=ops.WF16)
+    with pytest.raises(RuntimeError):
+        ops.conv2d(torch.zeros(1, 32, 32, 64, device='cuda'), pw64)

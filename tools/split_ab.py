@@ -12,15 +12,15 @@ for f in sorted(glob.glob(os.path.join(ROOT, 'gpurun_ablate', 'lib_*.so'))):
     l.cf_conv2d.argtypes = [ctypes.POINTER(L.ConvDesc), ctypes.c_void_p]
     libs[os.path.basename(f)[4:-3]] = l
 B = int(os.environ.get('AB_BATCH', 16))
-KIND = os.environ.get('AB_KIND', 'split')   # split | wino (fp32 Winograd) | wsplit (split-half Winograd)
-WINO = KIND in ('wino', 'wsplit')
+KIND = os.environ.get('AB_KIND', 'split')   # split | wino (fp32 Winograd) | wsplit (split-half Winograd) | wf16 / wbf16 (single-operand Winograd)
+WINO = KIND in ('wino', 'wsplit', 'wf16', 'wbf16')
 shapes = [(128, 128, 256, 1, 0), (64, 64, 512, 1, 0), (256, 256, 64, 1, 0), (128, 128, 256, 0, 0), (128, 128, 256, 0, 1)]
 if os.environ.get('AB_SHAPES'):   # "cin,cout,H,swish,up;..."
     shapes = [tuple(int(v) for v in item.split(',')) for item in os.environ['AB_SHAPES'].split(';')]
 for cin, cout, H, swish, up in shapes:
     x = torch.randn(B, H, H, cin, device='cuda')
     Ho = 2 * H if up else H
-    pw = ops.pack_weight(torch.randn(cout, cin, 3, 3, device='cuda') * 0.05, torch.randn(cout, device='cuda'), bf16={'wino': ops.WINOGRAD, 'wsplit': ops.WSPLIT}.get(KIND, ops.SPLIT), up2x=bool(up))
+    pw = ops.pack_weight(torch.randn(cout, cin, 3, 3, device='cuda') * 0.05, torch.randn(cout, device='cuda'), bf16={'wino': ops.WINOGRAD, 'wsplit': ops.WSPLIT, 'wf16': ops.WF16, 'wbf16': ops.WBF16}.get(KIND, ops.SPLIT), up2x=bool(up))
     sc, sh = torch.rand(B, cin, device='cuda') + 0.5, torch.randn(B, cin, device='cuda') * 0.1
     res = torch.randn(B, Ho, Ho, cout, device='cuda')
     out = torch.empty(B, Ho, Ho, cout, device='cuda')
@@ -28,7 +28,7 @@ for cin, cout, H, swish, up in shapes:
     d = L.ConvDesc(in0=x.data_ptr(), c0=cin, batch=B, hin=H, win=H, hout=Ho, wout=Ho, cout=cout, cout_pad=pw.cout_pad, taps=9,
                    stride=1, upsample=up, prologue=2 if swish else 0, epilogue=1 if swish else 0, pro_scale=sc.data_ptr(),
                    pro_shift=sh.data_ptr(), weight=pw.w.data_ptr(), bias=pw.bias.data_ptr(), res=res.data_ptr(), out=out.data_ptr(),
-                   bf16_mfma=0 if KIND == 'wino' else ops.OPERAND_F16X2, winograd=int(WINO), acc_scale=1.0 / pw.scale, stats_out=stats.data_ptr(),
+                   bf16_mfma={'wino': 0, 'wf16': 2, 'wbf16': 1}.get(KIND, ops.OPERAND_F16X2), winograd=int(WINO), acc_scale=1.0 / pw.scale, stats_out=stats.data_ptr(),
                    stats_cpg=cout // 32)
     st = torch.cuda.current_stream().cuda_stream
     times = {k: [] for k in libs}

@@ -92,7 +92,7 @@ def resize_area(img, size):
 
     OpenCV's rule, restated: every destination pixel is the mean of the source rectangle [d*s, (d+1)*s) with fractional end cells
     weighted by their covered length.  Integer ratios take the box-sum path (integer sums, one multiply by 1/area, round half to
-    even); other ratios accumulate float32 products column weights first, then row weights, in source order, and round once."""
+    even; 2 x 2 boxes the integer form (sum + 2) >> 2); other ratios accumulate float32 products column weights first, then row weights, in source order, and round once."""
     if img.dtype != np.uint8:
         raise TypeError('resize_area restates the uint8 path of cv2.resize')
     h, w = img.shape[:2]
@@ -106,6 +106,8 @@ def resize_area(img, size):
     if sx == int(sx) and sy == int(sy):
         kx, ky = int(sx), int(sy)
         box = src[:dh * ky, :dw * kx].astype(np.int64).reshape(dh, ky, dw, kx, -1).sum(axis=(1, 3))
+        if kx == 2 and ky == 2:          # OpenCV's 2x2 kernel is integer: (a + b + c + d + 2) >> 2, i.e. halves round UP
+            return np.ascontiguousarray(((box + 2) >> 2).astype(np.uint8).reshape((dh, dw) + img.shape[2:]))
         out = np.rint(box.astype(np.float32) * np.float32(1.0 / (kx * ky)))
         return np.ascontiguousarray(np.clip(out, 0, 255).astype(np.uint8).reshape((dh, dw) + img.shape[2:]))
 

@@ -170,6 +170,8 @@ def test_resize_area_and_float_linear():
     out = resize_area(img, (20, 16))
     box = img.reshape(16, 3, 20, 3, 3).astype(np.float64).mean(axis=(1, 3))
     assert out.shape == (16, 20, 3) and np.abs(out.astype(np.float64) - box).max() <= 0.5 + 1e-6
+    half = resize_area(img, (30, 24))                                    # 2 x 2 boxes: (sum + 2) >> 2
+    assert np.array_equal(half, ((img.reshape(24, 2, 30, 2, 3).astype(np.int64).sum(axis=(1, 3)) + 2) >> 2).astype(np.uint8))
     # fractional ratio: area-weighted mean of the covered source rectangle
     out = resize_area(img, (25, 20))
     sx, sy = 60 / 25, 48 / 20

@@ -9,6 +9,7 @@
 //   np.sum (face area)                                                -> sum_kernel (fp64 partials, fixed order)
 //   inv_soft_mask*pasted + (1-inv_soft_mask)*img, parse-mask fusion   -> blend_kernel (samples the restored face itself)
 //   cv2.resize(INTER_LINEAR) of the background, final astype(uint8)   -> resize_u8_kernel, trunc_u8_kernel
+//   cv2.resize(INTER_AREA) of the frame for the detector (:208-215)    -> resize_area_u8_kernel
 //
 // The arithmetic follows OpenCV's fixed-point definitions (restated with citations in oracle/paste_oracle.py): source coordinates
 // in 10-bit fixed point from per-axis rounded terms, +1/64 px, truncated to 1/32 px; uint8 taps weighted with the 15-bit table and
@@ -212,6 +213,83 @@ __global__ __launch_bounds__(256) void resize_u8_kernel(const uint8_t* __restric
   }
 }
 
+// cv2.resize(INTER_AREA), uint8, shrinking on both axes (FaceRestoreHelper.get_face_landmarks_5 reduces frames to the detector's
+// working size with it, face_restoration_helper.py:208-215).  OpenCV's rule (computeResizeAreaTab / ResizeArea_Invoker), evaluated per
+// output pixel: the covered source interval [d*s, (d+1)*s) as [fractional first cell] + whole cells + [fractional last cell], weights
+// in double rounded to float; float32 accumulation in source order -- row sums first (buf += src * alpha), then sum += beta * buf -- with
+// separately rounded multiplies and adds; cvRound at the end.  Integer ratios: integer box sums, (sum + 2) >> 2 for 2 x 2, else
+// cvRound(sum * (1.f / area)).  Restated in numpy as codeformer_amd.utils.img_util.resize_area (the test oracle of this kernel).
+struct AreaTaps {
+  int first;        // first source index touched
+  int n;            // number of taps
+  float a0, am, a1; // weight of the fractional first cell (0: none), of a whole cell, of the fractional last cell (0: none)
+  bool has0, has1;
+};
+__device__ __forceinline__ AreaTaps area_taps(int d, double scale, int nsrc) {
+  const double f1 = (double)d * scale, f2 = f1 + scale;
+  const double cell = fmin(scale, (double)nsrc - f1);
+  int s1 = (int)ceil(f1), s2 = (int)floor(f2);
+  s2 = s2 < nsrc - 1 ? s2 : nsrc - 1;
+  s1 = s1 < s2 ? s1 : s2;
+  AreaTaps t;
+  t.has0 = (double)s1 - f1 > 1e-3;
+  t.has1 = f2 - (double)s2 > 1e-3;
+  t.a0 = t.has0 ? (float)(((double)s1 - f1) / cell) : 0.f;
+  t.am = (float)(1.0 / cell);
+  t.a1 = t.has1 ? (float)(fmin(fmin(f2 - (double)s2, 1.0), cell) / cell) : 0.f;
+  t.first = t.has0 ? s1 - 1 : s1;
+  t.n = (s2 - s1) + (t.has0 ? 1 : 0) + (t.has1 ? 1 : 0);
+  return t;
+}
+__device__ __forceinline__ float area_weight(const AreaTaps& t, int k) {
+  if (k == 0 && t.has0) return t.a0;
+  if (k == t.n - 1 && t.has1) return t.a1;
+  return t.am;
+}
+__global__ __launch_bounds__(256) void resize_area_u8_kernel(const uint8_t* __restrict__ src, int sh, int sw, uint8_t* __restrict__ dst, int dh,
+                                                             int dw, double scale_x, double scale_y, int kx, int ky) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)dw * dh) return;
+  const int x = (int)(i % dw), y = (int)(i / dw);
+  if (kx > 0) {  // integer ratios: box sums
+    int sum[3] = {0, 0, 0};
+    for (int r = 0; r < ky; ++r)
+      for (int q = 0; q < kx; ++q) {
+        const uint8_t* p = src + ((long)(y * ky + r) * sw + (x * kx + q)) * 3;
+        sum[0] += p[0];
+        sum[1] += p[1];
+        sum[2] += p[2];
+      }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      int v;
+      if (kx == 2 && ky == 2) v = (sum[c] + 2) >> 2;
+      else v = (int)__float2ll_rn(mul_rn((float)sum[c], 1.f / (float)(kx * ky)));
+      dst[i * 3 + c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+    return;
+  }
+  const AreaTaps tx = area_taps(x, scale_x, sw), ty = area_taps(y, scale_y, sh);
+  float sum[3] = {0.f, 0.f, 0.f};
+  for (int r = 0; r < ty.n; ++r) {
+    const float beta = area_weight(ty, r);
+    float buf[3] = {0.f, 0.f, 0.f};
+    for (int q = 0; q < tx.n; ++q) {
+      const float alpha = area_weight(tx, q);
+      const uint8_t* p = src + ((long)(ty.first + r) * sw + (tx.first + q)) * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) buf[c] = add_rn(buf[c], mul_rn((float)p[c], alpha));
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) sum[c] = add_rn(sum[c], mul_rn(buf[c], beta));
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const long long v = __float2ll_rn(sum[c]);
+    dst[i * 3 + c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+  }
+}
+
 __global__ __launch_bounds__(256) void u8_to_f32_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = (float)src[i];
@@ -320,6 +398,17 @@ extern "C" int cf_resize_linear_u8(const uint8_t* src, int sh, int sw, float* ds
   else
     hipLaunchKernelGGL(resize_u8_kernel, dim3(nblk((long)dh * dw)), dim3(256), 0, (hipStream_t)stream, src, sh, sw, dst, dh, dw);
   CF_CHECK_LAUNCH("cf_resize_linear_u8");
+  return CF_OK;
+}
+
+extern "C" int cf_resize_area_u8(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw, cf_stream_t stream) {
+  CF_REQUIRE(src && dst && sh > 0 && sw > 0 && dh > 0 && dw > 0, "cf_resize_area_u8: bad args");
+  CF_REQUIRE(dh <= sh && dw <= sw, "cf_resize_area_u8: INTER_AREA is built for shrinking (%dx%d -> %dx%d)", sw, sh, dw, dh);
+  const double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
+  const bool integer = sw % dw == 0 && sh % dh == 0;
+  hipLaunchKernelGGL(resize_area_u8_kernel, dim3(nblk((long)dh * dw)), dim3(256), 0, (hipStream_t)stream, src, sh, sw, dst, dh, dw, scale_x,
+                     scale_y, integer ? sw / dw : 0, integer ? sh / dh : 0);
+  CF_CHECK_LAUNCH("cf_resize_area_u8");
   return CF_OK;
 }
 

@@ -2,9 +2,11 @@
 
 Same constructor, configs, `state_dict` keys (body.* / fpn.* / ssh1-3.* / ClassHead|BboxHead|LandmarkHead.N.conv1x1.*) and result
 conventions as the reference: `detect_faces(bgr image)` -> (k, 15) rows [x1, y1, x2, y2, score, 5 x (lx, ly)] in pixels of the given
-image, score-sorted and NMS-filtered; `batched_detect_faces(frames)` -> per-frame lists.  Detection is the host half of the
-pipeline (north star: "facelib detection/alignment left on host"): the module runs stock torch ops on whatever device it lives on,
-CPU by default; the crops it yields are cut, restored and pasted back by the HIP path (codeformer_amd.facelib.paste).
+image, score-sorted and NMS-filtered; `batched_detect_faces(frames)` -> per-frame lists.  Detection is the host-code half of the
+pipeline (north star: "facelib detection/alignment left on host"): the module is stock torch ops and runs on whatever device it is
+placed on -- the entrypoint puts it on the compute device, as the reference does (MIOpen: 193 frames/s at 640x1138 on an MI355X,
+2 frames/s on 64 host threads; tools/detector_bench.py) -- and takes device-resident frames; the crops its boxes yield are cut,
+restored and pasted back by the HIP path (codeformer_amd.facelib.paste).
 
 Not built: `align_multi` (112x112 crops through matlab_cp2tform; unused by the restoration entrypoints).
 """
@@ -96,6 +98,11 @@ class RetinaFace(nn.Module):
 
     # ---- single image (:142-213) ------------------------------------------------------------------------------------------------
     def transform(self, image, use_origin_size):
+        if torch.is_tensor(image):                                 # uint8 / float (H, W, 3) BGR tensor, e.g. a frame that already lives on the device
+            resize = self._test_scale(image.shape[0], image.shape[1], use_origin_size)
+            if resize != 1:
+                raise NotImplementedError('tensor inputs are taken at their own size (use_origin_size=True)')
+            return image.permute(2, 0, 1).unsqueeze(0).float(), resize
         if not isinstance(image, np.ndarray):                      # PIL image: RGB -> BGR
             image = np.asarray(image)[:, :, ::-1]
         image = image.astype(np.float32)
@@ -106,7 +113,7 @@ class RetinaFace(nn.Module):
         return torch.from_numpy(np.ascontiguousarray(image.transpose(2, 0, 1))).unsqueeze(0), resize
 
     def detect_faces(self, image, conf_threshold=0.8, nms_threshold=0.4, use_origin_size=True):
-        """image: uint8 / float HWC BGR (or a PIL image).  Returns float32 (k, 15)."""
+        """image: uint8 / float HWC BGR array, a PIL image, or an (H, W, 3) BGR tensor on any device.  Returns float32 (k, 15)."""
         image, self.resize = self.transform(image, use_origin_size)
         image = image.to(self.device)
         if self.half_inference:

@@ -124,13 +124,22 @@ class FaceRestoreHelper(object):
     # ---- detection (:195-247) -------------------------------------------------------------------------------------------------
     def get_face_landmarks_5(self, only_keep_largest=False, only_center_face=False, resize=None, blur_ratio=0.01,
                              eye_dist_threshold=None):
+        # When the detector lives on the compute device, so does its input: the frame was uploaded by read_image, the reduction to the
+        # detector's working size is a kernel (cf_resize_area_u8 / cf_resize_linear_u8), and nothing crosses PCIe but the boxes.
+        on_dev = self.device.type == 'cuda' and getattr(self.face_detector, 'device', torch.device('cpu')).type == 'cuda'
         if resize is None:
-            scale, det_in = 1, self.input_img
+            scale, det_in = 1, (self._device_helper().input_img if on_dev else self.input_img)
         else:
             h, w = self.input_img.shape[0:2]
             scale = resize / min(h, w)
             size = (int(w * scale), int(h * scale))
-            det_in = resize_area(self.input_img, size) if scale < 1 else resize_bilinear(self.input_img, size)
+            if on_dev:
+                from ... import ops
+                frame = self._device_helper().input_img
+                det_in = ops.resize_area_u8(frame, size[1], size[0]) if scale < 1 else \
+                    ops.f32_to_u8_trunc(ops.resize_linear_u8(frame, size[1], size[0]))
+            else:
+                det_in = resize_area(self.input_img, size) if scale < 1 else resize_bilinear(self.input_img, size)
         if self.face_detector is None:
             raise RuntimeError('this helper was built without a detector (face_detector=False)')
         with torch.no_grad():

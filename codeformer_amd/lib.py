@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('CF_LIB_PATH') or os.path.join(_PKG, 'libcodeformer_hi
 
 c_float_p = ctypes.c_void_p  # device pointers are passed as integers
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 PRO_NONE, PRO_AFFINE, PRO_AFFINE_SWISH, PRO_LEAKY = 0, 1, 2, 3
 EPI_NONE, EPI_RESIDUAL, EPI_SFT, EPI_GELU, EPI_LEAKY, EPI_AXPY, EPI_AXPY2 = 0, 1, 2, 3, 4, 5, 6
 PAD_ZERO, PAD_REFLECT, PAD_EDGE = 0, 1, 2
@@ -91,6 +91,7 @@ SIGNATURES = {
     'cf_sum_f32': (_I, [_P, _L, _P, _P]),
     'cf_paste_blend': (_I, [_P, _I, _I, _P, _I, _I, ctypes.POINTER(ctypes.c_double), _P, _P, _P, _I, _I, _I, _I, _P]),
     'cf_resize_linear_u8': (_I, [_P, _I, _I, _P, _I, _I, _P]),
+    'cf_resize_area_u8': (_I, [_P, _I, _I, _P, _I, _I, _P]),
     'cf_f32_to_u8_trunc': (_I, [_P, _L, _P, _P]),
     'cf_label_lut_f32': (_I, [_P, _L, ctypes.POINTER(ctypes.c_float), _I, _P, _P]),
     'cf_scale_clear_border_f32': (_I, [_P, _I, _I, _I, _I, _F, _P]),

@@ -648,6 +648,17 @@ def resize_linear_u8(src, dh, dw):
     return out
 
 
+def resize_area_u8(src, dh, dw):
+    """cv2.resize(src uint8 (sh, sw, 3) on the device, (dw, dh), INTER_AREA) -> uint8 (dh, dw, 3); shrinking only."""
+    lib = L.load()
+    if src.dim() != 3 or src.shape[2] != 3 or not src.is_contiguous():
+        raise ValueError('resize_area_u8 expects a contiguous uint8 (H, W, 3) image')
+    out = torch.empty(dh, dw, 3, dtype=torch.uint8, device=src.device)
+    L.check(lib.cf_resize_area_u8(L.ptr(src, dtype=torch.uint8), src.shape[0], src.shape[1], L.ptr(out, dtype=torch.uint8), dh, dw, L.stream_ptr()),
+            'cf_resize_area_u8')
+    return out
+
+
 def f32_to_u8_trunc(x):
     lib = L.load()
     out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)

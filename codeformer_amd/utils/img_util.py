@@ -102,10 +102,14 @@ def resize_area(img, size):
     if dw > w or dh > h:
         raise ValueError('resize_area: INTER_AREA is restated for shrinking only (OpenCV switches to a linear rule when enlarging)')
     src = img.reshape(h, w, -1)
+    c = src.shape[2]
     sx, sy = w / dw, h / dh
     if sx == int(sx) and sy == int(sy):
         kx, ky = int(sx), int(sy)
-        box = src[:dh * ky, :dw * kx].astype(np.int64).reshape(dh, ky, dw, kx, -1).sum(axis=(1, 3))
+        box = np.zeros((dh, dw, c), dtype=np.uint32)
+        for i in range(ky):
+            for j in range(kx):
+                box += src[i:dh * ky:ky, j:dw * kx:kx]
         if kx == 2 and ky == 2:          # OpenCV's 2x2 kernel is integer: (a + b + c + d + 2) >> 2, i.e. halves round UP
             return np.ascontiguousarray(((box + 2) >> 2).astype(np.uint8).reshape((dh, dw) + img.shape[2:]))
         out = np.rint(box.astype(np.float32) * np.float32(1.0 / (kx * ky)))
@@ -113,42 +117,49 @@ def resize_area(img, size):
 
     def table(n_src, n_dst, scale):
         """(dst index, src index, weight) triples in OpenCV's order (computeResizeAreaTab)."""
+        d = np.arange(n_dst)
+        f1 = d * scale
+        f2 = f1 + scale
+        cell = np.minimum(scale, n_src - f1)
+        s1 = np.ceil(f1).astype(np.int64)
+        s2 = np.minimum(np.floor(f2).astype(np.int64), n_src - 1)
+        s1 = np.minimum(s1, s2)
         di, si, al = [], [], []
-        for d in range(n_dst):
-            f1 = d * scale
-            f2 = f1 + scale
-            cell = min(scale, n_src - f1)
-            s1, s2 = int(math.ceil(f1)), int(math.floor(f2))
-            s2 = min(s2, n_src - 1)
-            s1 = min(s1, s2)
-            if s1 - f1 > 1e-3:
-                di.append(d), si.append(s1 - 1), al.append(np.float32((s1 - f1) / cell))
-            for s in range(s1, s2):
-                di.append(d), si.append(s), al.append(np.float32(1.0 / cell))
-            if f2 - s2 > 1e-3:
-                di.append(d), si.append(s2), al.append(np.float32(min(min(f2 - s2, 1.0), cell) / cell))
+        for k in range(n_dst):
+            if s1[k] - f1[k] > 1e-3:
+                di.append(k), si.append(s1[k] - 1), al.append(np.float32((s1[k] - f1[k]) / cell[k]))
+            for t in range(s1[k], s2[k]):
+                di.append(k), si.append(t), al.append(np.float32(1.0 / cell[k]))
+            if f2[k] - s2[k] > 1e-3:
+                di.append(k), si.append(s2[k]), al.append(np.float32(min(min(f2[k] - s2[k], 1.0), cell[k]) / cell[k]))
         return np.asarray(di), np.asarray(si), np.asarray(al, dtype=np.float32)
 
     xd, xs, xa = table(w, dw, sx)
     yd, ys, ya = table(h, dh, sy)
-    srcf = src.astype(np.float32)
-    c = srcf.shape[2]
-    # horizontal pass: buf[sy][dx] = sum_k src[sy][xs_k] * xa_k, accumulated in table order (float32)
-    buf = np.zeros((h, dw, c), dtype=np.float32)
-    # taps of one destination column are consecutive in the table; add them one position at a time to keep OpenCV's order
-    counts = np.bincount(xd, minlength=dw)
-    starts = np.concatenate(([0], np.cumsum(counts)[:-1]))
-    for t in range(int(counts.max())):
-        sel = np.nonzero(counts > t)[0]
-        k = starts[sel] + t
-        buf[:, sel] += srcf[:, xs[k]] * xa[k][None, :, None]
-    out = np.zeros((dh, dw, c), dtype=np.float32)
-    ycounts = np.bincount(yd, minlength=dh)
-    ystarts = np.concatenate(([0], np.cumsum(ycounts)[:-1]))
-    for t in range(int(ycounts.max())):
-        sel = np.nonzero(ycounts > t)[0]
-        k = ystarts[sel] + t
-        out[sel] += buf[ys[k]] * ya[k][:, None, None]
+    try:                                  # both passes as sparse float32 products: a row's taps are added in table (= source) order
+        from scipy import sparse
+        wx = sparse.csr_matrix((xa, (xd, xs)), shape=(dw, w), dtype=np.float32)
+        wy = sparse.csr_matrix((ya, (yd, ys)), shape=(dh, h), dtype=np.float32)
+        cols = np.ascontiguousarray(src.transpose(1, 0, 2)).reshape(w, h * c).astype(np.float32)
+        buf = np.asarray(wx @ cols, dtype=np.float32).reshape(dw, h, c)                 # buf[dx][sy] = sum_k src[sy][xs_k] * xa_k
+        rows = np.ascontiguousarray(buf.transpose(1, 0, 2)).reshape(h, dw * c)
+        out = np.asarray(wy @ rows, dtype=np.float32).reshape(dh, dw, c)                # sum_k buf[ys_k][dx] * ya_k
+    except ImportError:
+        srcf = src.astype(np.float32)
+        buf = np.zeros((h, dw, c), dtype=np.float32)
+        counts = np.bincount(xd, minlength=dw)
+        starts = np.concatenate(([0], np.cumsum(counts)[:-1]))
+        for t in range(int(counts.max())):
+            sel = np.nonzero(counts > t)[0]
+            k = starts[sel] + t
+            buf[:, sel] += srcf[:, xs[k]] * xa[k][None, :, None]
+        out = np.zeros((dh, dw, c), dtype=np.float32)
+        ycounts = np.bincount(yd, minlength=dh)
+        ystarts = np.concatenate(([0], np.cumsum(ycounts)[:-1]))
+        for t in range(int(ycounts.max())):
+            sel = np.nonzero(ycounts > t)[0]
+            k = ystarts[sel] + t
+            out[sel] += buf[ys[k]] * ya[k][:, None, None]
     out = np.clip(np.rint(out), 0, 255).astype(np.uint8)
     return np.ascontiguousarray(out.reshape((dh, dw) + img.shape[2:]))
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 14
+#define CF_ABI_VERSION 15
 
 typedef void* cf_stream_t; /* hipStream_t */
 
@@ -320,6 +320,9 @@ int cf_paste_blend(float* canvas, int ch, int cw, const uint8_t* face, int fh, i
                    const float* soft_region, const float* parse_region, int rx, int ry, int rw, int rh, cf_stream_t stream);
 /* cv2.resize(src u8 [sh][sw][3], INTER_LINEAR) -> f32 [dh][dw][3] (a plain widening copy when the sizes are equal) */
 int cf_resize_linear_u8(const uint8_t* src, int sh, int sw, float* dst, int dh, int dw, cf_stream_t stream);
+/* cv2.resize(src u8 [sh][sw][3], (dw, dh), INTER_AREA) -> u8 [dh][dw][3], dh <= sh and dw <= sw: the reduction of a frame to the detector's
+ * working size (facelib/utils/face_restoration_helper.py:208-215) */
+int cf_resize_area_u8(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw, cf_stream_t stream);
 /* astype(np.uint8) of a float image in [0, 256): truncation */
 int cf_f32_to_u8_trunc(const float* src, int64_t n, uint8_t* dst, cf_stream_t stream);
 /* parse-map colouring out[i] = lut[labels[i]] (face_restoration_helper.py:468-471; lut_host: nlut <= 32 floats in HOST memory) */

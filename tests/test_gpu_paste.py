@@ -181,6 +181,21 @@ def test_entrypoint_whole_images_with_host_affines(env, tmp_path):
     assert np.array_equal(crop, P.align_warp_face(np.ascontiguousarray(frame), table['im0'][0]))
 
 
+def test_area_reduction_kernel_is_bit_exact(env):
+    """cf_resize_area_u8 (cv2.resize INTER_AREA for the detector's input) against its numpy restatement: fractional ratios (float32
+    accumulation in OpenCV's order), integer ratios, the 2 x 2 rule, identity; enlarging is refused."""
+    torch, ops, P = env
+    from basicsr.utils.img_util import resize_area
+    for (h, w, dh, dw, seed) in ((1080, 1920, 640, 1137, 1), (720, 960, 640, 853, 2), (531, 777, 200, 301, 3), (96, 120, 32, 40, 4),
+                                 (96, 120, 48, 60, 5), (90, 120, 30, 40, 6), (64, 64, 64, 64, 7), (513, 640, 512, 639, 8)):
+        img = _img(h, w, seed)
+        got = ops.resize_area_u8(torch.from_numpy(img).cuda(), dh, dw).cpu().numpy()
+        want = resize_area(img, (dw, dh))
+        assert got.shape == want.shape == (dh, dw, 3) and np.array_equal(got, want), (h, w, dh, dw, int(np.abs(got.astype(int) - want).max()))
+    with pytest.raises(RuntimeError):
+        ops.resize_area_u8(torch.zeros(10, 10, 3, dtype=torch.uint8, device='cuda'), 11, 10)
+
+
 class _FixedDetector:
     """Stands in for RetinaFace.detect_faces: returns prepared (k, 15) rows for whatever image it is given."""
 
@@ -236,6 +251,22 @@ def test_face_restore_helper_host_detection_device_pixels(env):
     fh.read_image(frame)
     assert fh.get_face_landmarks_5(only_center_face=True, resize=640, eye_dist_threshold=5) == 1
     assert np.allclose(fh.all_landmarks_5[0], landmarks(300, 260, 220, 0.15), atol=1e-3)      # box centre 203 px from (480, 360); the other 231
+    # a detector that lives on the device is handed the device frame, reduced by the INTER_AREA kernel: nothing but boxes crosses PCIe
+    from basicsr.utils.img_util import resize_area
+    det.device = torch.device('cuda')
+    fh.clean_all()
+    fh.read_image(frame)
+    det.seen_input = None
+    orig = det.detect_faces
+    det.detect_faces = lambda image, **kw: (setattr(det, 'seen_input', image), orig(image, **kw))[1]
+    assert fh.get_face_landmarks_5(resize=640, eye_dist_threshold=5) == 2
+    assert torch.is_tensor(det.seen_input) and det.seen_input.is_cuda and det.seen_input.dtype == torch.uint8
+    assert np.array_equal(det.seen_input.cpu().numpy(), resize_area(frame, (853, 640)))
+    det.detect_faces = orig
+    del det.device
+    fh.clean_all()
+    fh.read_image(frame)
+    assert fh.get_face_landmarks_5(only_center_face=True, resize=640, eye_dist_threshold=5) == 1
     # per-face host path of the reference's loop (add_restored_face with numpy arrays)
     fh.align_warp_face()
     fh.add_restored_face(255 - fh.cropped_faces[0], fh.cropped_faces[0])

@@ -145,13 +145,12 @@ def pack_weight(weight, bias=None, bf16=False, up2x=False, f16=False):
     if code in (WSPLIT, WF16, WBF16):
         if up2x or w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or cin % 16 or cout % 64:
             raise ValueError('winograd f16x2 packing needs a 3x3 weight with cin % 16 == 0 and cout % 64 == 0 (no up2x)')
-        # max |G g G^T| for the power-of-two scale (elementwise: G's rows are g0, (g0 + g1 + g2)/2, (g0 - g1 + g2)/2, g2)
+        # max |G g G^T| for the power-of-two scale (elementwise: G's rows are g0, (g0 + g1 + g2)/2, (g0 - g1 + g2)/2, g2), all 16 positions
+        # in one tensor and ONE reduction / host read-back per weight
         g = w.double()
-        rows = (g[:, :, 0], 0.5 * (g[:, :, 0] + g[:, :, 1] + g[:, :, 2]), 0.5 * (g[:, :, 0] - g[:, :, 1] + g[:, :, 2]), g[:, :, 2])
-        umax = 0.0
-        for r in rows:                                   # r: (cout, cin, 3) -- the same combination along the kernel's columns
-            cols = (r[..., 0], 0.5 * (r[..., 0] + r[..., 1] + r[..., 2]), 0.5 * (r[..., 0] - r[..., 1] + r[..., 2]), r[..., 2])
-            umax = max(umax, max(float(c.abs().max()) for c in cols))
+        r = torch.stack((g[:, :, 0], 0.5 * (g[:, :, 0] + g[:, :, 1] + g[:, :, 2]), 0.5 * (g[:, :, 0] - g[:, :, 1] + g[:, :, 2]), g[:, :, 2]), dim=2)
+        u = torch.stack((r[..., 0], 0.5 * (r[..., 0] + r[..., 1] + r[..., 2]), 0.5 * (r[..., 0] - r[..., 1] + r[..., 2]), r[..., 2]), dim=3)
+        umax = float(u.abs().max())
         scale = 1.0 if umax == 0.0 or not math.isfinite(umax) else 2.0 ** (14 - math.frexp(umax)[1] + 1)
         packed = torch.empty(16 * cin * cout, dtype=torch.float32, device=w.device)
         fn = 'cf_pack_conv_weight_winograd_bf16' if code == WBF16 else 'cf_pack_conv_weight_winograd_f16x2'   # (WF16 reads the hi slot)

@@ -35,6 +35,10 @@
 #ifndef WS_ABLATE
 #define WS_ABLATE 0
 #endif
+// WS_STORE_FIRST = 0: the feed stage in its first order (transform, then store) -- A/B timing only, same bits
+#ifndef WS_STORE_FIRST
+#define WS_STORE_FIRST 1
+#endif
 
 namespace {
 
@@ -296,12 +300,17 @@ __global__ __launch_bounds__(WS_THREADS, 1) void wsplit_kernel(const WsArgs a) {
     // The store comes first: it retires the sixteen registers of the activation prefetch (values + GroupNorm rows) before the transform
     // takes its thirty-two (the two stages touch different buffers: patch[buf] / patch[buf ^ 1] -> V[buf ^ 1]).  In the other order the
     // GN-swish instantiations spilled ten registers: 0.877 -> 0.841 ms on 128->128 @256^2, 0.598 -> 0.543 ms on 64->128 (same bits).
+#if WS_STORE_FIRST
 #if !(WS_ABLATE & 8)
     if (k + 2 < n) store_patch(patch0 + buf * WS_PATCH_FLOATS);
 #endif
     __builtin_amdgcn_sched_barrier(0);
 #if !(WS_ABLATE & 4)
     if (k + 1 < n) transform(patch0 + (buf ^ 1) * WS_PATCH_FLOATS, V0 + (buf ^ 1) * WS_V_FLOATS);
+#endif
+#else
+    if (k + 1 < n) transform(patch0 + (buf ^ 1) * WS_PATCH_FLOATS, V0 + (buf ^ 1) * WS_V_FLOATS);
+    if (k + 2 < n) store_patch(patch0 + buf * WS_PATCH_FLOATS);
 #endif
     load_A(k + 3 < n ? k + 3 : n - 1);
     __builtin_amdgcn_sched_barrier(0);

@@ -77,3 +77,20 @@ def test_colorization_entrypoint_cpu(tmp_path):
                        cwd=str(tmp_path))
     assert r.returncode == 0 and 'Failed inference' not in r.stdout, r.stdout + r.stderr
     assert os.listdir(tmp_path / 'o') == ['f0_c.png']
+
+
+def test_vqgan_reconstruction_script_cpu(tmp_path):
+    """scripts/inference_vqgan.py (the caller of VectorQuantizer.forward, reference scripts/inference_vqgan.py:12-59): CPU plumbing with
+    seeded weights; a missing checkpoint without the opt-in is an error."""
+    src = tmp_path / 'ffhq_512'
+    _faces(str(src), 2)
+    script = os.path.join(ROOT, 'scripts', 'inference_vqgan.py')
+    r = subprocess.run([sys.executable, script, '-i', str(src), '-o', str(tmp_path / 'rec') + '/', '--device', 'cpu', '--random_init_seed', '0'],
+                       capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert sorted(os.listdir(tmp_path / 'rec')) == ['f0.png', 'f1.png'] and 'All results are saved in' in r.stdout
+    from PIL import Image
+    assert Image.open(tmp_path / 'rec' / 'f0.png').size == (512, 512)
+    r = subprocess.run([sys.executable, script, '-i', str(src), '-o', str(tmp_path / 'rec2'), '--device', 'cpu'], capture_output=True, text=True,
+                       timeout=300, cwd=str(tmp_path))
+    assert r.returncode != 0 and 'net_g.pth' in (r.stdout + r.stderr)

@@ -198,3 +198,57 @@ def test_resize_area_and_float_linear():
     cy = (np.arange(60) + 0.5) / 2 - 0.5
     inner = np.s_[2:-2, 2:-2]
     assert np.abs(up[..., 0] - cx[None, :])[inner].max() < 1e-4 and np.abs(up[..., 1] - cy[:, None])[inner].max() < 1e-4
+
+
+class _FixedDetector:
+    def __init__(self, rows):
+        self.rows = np.asarray(rows, dtype=np.float32)
+
+    def detect_faces(self, image, **kw):
+        self.seen = image.shape
+        return self.rows
+
+
+def test_restore_helper_host_half():
+    """FaceRestoreHelper's host half (no device): the detector sees the INTER_AREA-reduced frame (resize=640), boxes / landmarks are
+    scaled back, the reference's eye-distance rule (face_restoration_helper.py:223, indices as written) drops the tiny face,
+    only_center_face / only_keep_largest select as the reference does, and the alignment fit maps every landmark set onto the template;
+    the pixel steps refuse to run without a device instead of doing something else."""
+    from codeformer_amd.facelib.utils.face_restoration_helper import _TEMPLATE_5, FaceRestoreHelper
+    tpl = np.array(_TEMPLATE_5)
+
+    def landmarks(cx, cy, size, ang):
+        c, s = np.cos(ang), np.sin(ang)
+        return ((tpl - 256) / 512 * size) @ np.array([[c, -s], [s, c]]).T + [cx, cy]
+
+    scale = 640 / 720
+    rows = []
+    for cx, cy, size, ang in ((300, 260, 220, 0.15), (700, 420, 260, -0.2), (120, 600, 12, 0.0)):
+        lm = landmarks(cx, cy, size, ang) * scale
+        rows.append([lm[:, 0].min() - 20, lm[:, 1].min() - 30, lm[:, 0].max() + 20, lm[:, 1].max() + 20, 0.99] + lm.reshape(-1).tolist())
+    det = _FixedDetector(rows)
+    fh = FaceRestoreHelper(2, device='cpu', face_detector=det)
+    frame = np.random.RandomState(0).randint(0, 255, (720, 960, 3)).astype(np.uint8)
+    fh.read_image(frame)
+    assert fh.get_face_landmarks_5(resize=640, eye_dist_threshold=5) == 2 and det.seen == (640, 853, 3)
+    assert np.allclose(fh.all_landmarks_5[1], landmarks(700, 420, 260, -0.2), atol=1e-3) and len(fh.det_faces) == 2
+    for lm, m in zip(fh.all_landmarks_5, fh.estimate_affines()):
+        assert np.abs(lm @ m[:, :2].T + m[:, 2] - tpl).max() < 0.05          # similarity data: the fit reproduces the template
+    with pytest.raises(RuntimeError):
+        fh.align_warp_face()                                                 # crops are HIP kernels: no silent host substitute
+    for kw, want in ((dict(only_center_face=True), (300, 260, 220, 0.15)), (dict(only_keep_largest=True), (700, 420, 260, -0.2))):
+        fh.clean_all()
+        fh.read_image(frame)
+        assert fh.get_face_landmarks_5(resize=640, eye_dist_threshold=5, **kw) == 1
+        assert np.allclose(fh.all_landmarks_5[0], landmarks(*want), atol=1e-3)
+    # images whose short side is below 512 are enlarged first (read_image), gray inputs are flagged
+    fh.clean_all()
+    small = np.repeat(np.random.RandomState(1).randint(0, 255, (300, 400, 1)).astype(np.uint8), 3, axis=2)
+    fh.read_image(small)
+    assert fh.input_img.shape == (512, 683, 3) and fh.is_gray
+    no_det = FaceRestoreHelper(1, device='cpu', face_detector=False)
+    no_det.read_image(frame)
+    with pytest.raises(RuntimeError):
+        no_det.get_face_landmarks_5()
+    with pytest.raises(NotImplementedError):
+        FaceRestoreHelper(1, device='cpu', face_detector=False, pad_blur=True)

@@ -161,3 +161,39 @@ def test_entrypoint_under_two_ranks_writes_the_same_pngs(tmp_path):
         a = np.asarray(Image.open(tmp_path / 'one' / 'restored_faces' / n))
         b = np.asarray(Image.open(tmp_path / 'two' / 'restored_faces' / n))
         assert np.array_equal(a, b), n
+
+
+# ---- frames as the unit of sharding (whole-image / video path, codeformer_amd.video) ----------------------------------------------
+def _frame_worker(rank, world, port, n_frames, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    from codeformer_amd import parallel
+    from codeformer_amd.video import frame_shard, gather_frames
+    parallel.init_distributed(backend='gloo', device='cpu')
+    frames = torch.arange(n_frames * 6 * 8 * 3, dtype=torch.int64).view(n_frames, 6, 8, 3).remainder(251).to(torch.uint8)
+    mine = frame_shard(n_frames, rank, world)
+    local = [255 - frames[i] for i in mine]                       # "restoration" of this rank's block of frames
+    got = gather_frames(local, n_frames, dst=0)
+    if rank == 0:
+        q.put(bool(torch.equal(got, 255 - frames)) and got.dtype == torch.uint8)
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_frames', [6, 7])
+def test_frames_are_sharded_in_contiguous_blocks_and_gathered_once(n_frames):
+    from codeformer_amd.video import frame_shard
+    assert [list(frame_shard(7, r, 3)) for r in range(3)] == [[0, 1, 2], [3, 4], [5, 6]]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_frame_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True

@@ -146,8 +146,10 @@ def restore_whole_images(args, input_img_list, result_root, w):
             def bg(frame):
                 img = ups.enhance(frame, outscale=args.upscale)[0]
                 return resize_bilinear(img, (frame.shape[1] * args.upscale, frame.shape[0] * args.upscale))
+    # (the helper lives on the compute device: a detector placed there reads the uploaded frame through the INTER_AREA / INTER_LINEAR
+    # kernels instead of a host-side resize; crops and paste-back are the VideoRestorer's)
     helper = FaceRestoreHelper(args.upscale, face_size=512, crop_ratio=(1, 1), det_model=args.detection_model, save_ext='png',
-                               use_parse=False, device='cpu', face_detector=build_detector(args, device) if table is None else False)
+                               use_parse=False, device=device, face_detector=build_detector(args, device) if table is None else False)
     frames, affs, names, grays = [], [], [], []
     for p in mine:
         name = os.path.splitext(os.path.basename(p))[0]

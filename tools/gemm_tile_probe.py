@@ -1,5 +1,8 @@
+"""Tile-size probe for the Transformer's token GEMMs (GPU box): the 64x64 split-K kernel the network uses at every batch size against the
+128-wide-tile kernel (split_k=0) at 4096 / 1024 / 256 tokens.  Result (round 2): within +-4 % at 4096 tokens, 1.5-2.8x slower at 256.
+usage: python tools/gemm_tile_probe.py"""
 import sys, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from codeformer_amd import ops
 torch.manual_seed(0)
 def t(fn, n=50):

@@ -132,11 +132,18 @@ class Fuse_sft_block(HipModule):
     def forward_nhwc(self, enc, dec, w=1, bf16=False):
         e = self.encode_enc.forward_nhwc(enc, dec, bf16=bf16)
         hw = e.shape[1:3]
-        s = ops.conv2d(e, self._pw_conv(self.scale[0], bf16, hw=hw))
-        s = ops.conv2d(s, self._pw_conv(self.scale[2], bf16, hw=hw), prologue=PRO_LEAKY)
-        h = ops.conv2d(e, self._pw_conv(self.shift[0], bf16, hw=hw))
-        return ops.conv2d(h, self._pw_conv(self.shift[2], bf16, hw=hw), prologue=PRO_LEAKY, epilogue=EPI_SFT, res=dec, sft_scale=s,
-                          sft_w=float(w), emit_stats=True)
+        if int(bf16) == 2 and not ops.wsingle_ok(e.shape[3], e.shape[3], hw[0], hw[1]):
+            bf16 = ops.SPLIT   # (single IEEE halves on the direct kernel have no range scaling; un-normalised inputs need it)
+        # The four convs below read UN-NORMALISED tensors (e; the outputs of scale.0 / shift.0): on the 16-bit-operand kernels each
+        # gets a per-image power-of-two range scale derived from the statistics its producer wrote (ops.act_scale).
+        pws = [self._pw_conv(m, bf16, hw=hw) for m in (self.scale[0], self.scale[2], self.shift[0], self.shift[2])]
+        rs = [ops.needs_act_scale(p) for p in pws]
+        act_e = ops.act_scale(e) if (rs[0] or rs[2]) else None
+        s = ops.conv2d(e, pws[0], act=act_e, emit_stats=rs[1])
+        s = ops.conv2d(s, pws[1], prologue=PRO_LEAKY, act=ops.act_scale(s) if rs[1] else None)
+        h = ops.conv2d(e, pws[2], act=act_e, emit_stats=rs[3])
+        return ops.conv2d(h, pws[3], prologue=PRO_LEAKY, epilogue=EPI_SFT, res=dec, sft_scale=s, sft_w=float(w), emit_stats=True,
+                          act=ops.act_scale(h) if rs[3] else None)
 
     def forward(self, enc_feat, dec_feat, w=1):
         if enc_feat.is_cuda:

@@ -45,6 +45,18 @@ class HipModule(nn.Module):
         key = (name if isinstance(name, str) else id(conv), code, bool(up2x))
         return self._packed(key, lambda: ops.pack_weight(conv.weight, conv.bias, bf16=code, up2x=up2x), conv.weight, conv.bias)
 
+    def _range_code(self, norm, code, n):
+        """Operand code for a 3x3 conv whose input passes GroupNorm `norm` with n elements per group: `code`, or its exact-fp32
+        replacement when |gamma| * sqrt(n - 1) + |beta| could leave the IEEE-half operand range (ops.gn_range_ok).  The two maxima are
+        read back once per parameter version."""
+        code = int(code)
+        if code in (0, 1, ops.WINOGRAD):
+            return code
+        gmax, bmax = self._packed(('gn_range', id(norm)),
+                                  lambda: (float(norm.weight.detach().abs().max()), float(norm.bias.detach().abs().max())),
+                                  norm.weight, norm.bias)
+        return code if ops.gn_range_ok(gmax, bmax, n) else ops.exact_code(code)
+
     def invalidate_packed_weights(self):
         """Drop every cached packed weight of this module tree.  The cache already follows load_state_dict / .to() /
         optimizer steps (parameter version + storage pointer); call this after editing `param.data` in place, which

@@ -124,7 +124,10 @@ class Upsample(HipModule):
         self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
 
     def forward_nhwc(self, x, bf16=False):
-        return ops.conv2d(x, self._pw_conv('conv', bf16, up2x=True, hw=x.shape[1:3]), upsample=True, emit_stats=True)
+        if int(bf16) == 2:
+            bf16 = ops.SPLIT   # the input is the un-normalised residual stream: single IEEE halves have no range scaling on the direct kernel
+        pw = self._pw_conv('conv', bf16, up2x=True, hw=x.shape[1:3])
+        return ops.conv2d(x, pw, upsample=True, emit_stats=True, act=ops.act_scale(x) if ops.needs_act_scale(pw) else None)
 
     def forward_host(self, x):
         return self.conv(F.interpolate(x, scale_factor=2.0, mode='nearest'))
@@ -154,13 +157,16 @@ class ResBlock(HipModule):
         xs = (x,) if x2 is None else (x, x2)
         sc, sh = _gn_tables(self.norm1, *xs)
         hw = x.shape[1:3]
-        h = ops.conv2d(x, self._pw_conv('conv1', bf16, hw=hw, c_split=None if x2 is None else x.shape[3]), x2=x2, prologue=PRO_AFFINE_SWISH, scale=sc, shift=sh, emit_stats=True)
+        npix = hw[0] * hw[1]
+        code1 = self._range_code(self.norm1, bf16, npix * self.in_channels // GN_GROUPS)
+        code2 = self._range_code(self.norm2, bf16, npix * self.out_channels // GN_GROUPS)
+        h = ops.conv2d(x, self._pw_conv('conv1', code1, hw=hw, c_split=None if x2 is None else x.shape[3]), x2=x2, prologue=PRO_AFFINE_SWISH, scale=sc, shift=sh, emit_stats=True)
         sc, sh = _gn_tables(self.norm2, h)
         if self.in_channels != self.out_channels:
             skip = ops.conv2d(x, self._pw_conv('conv_out'), x2=x2)
         else:
             skip = x
-        return ops.conv2d(h, self._pw_conv('conv2', bf16, hw=hw), prologue=PRO_AFFINE_SWISH, scale=sc, shift=sh,
+        return ops.conv2d(h, self._pw_conv('conv2', code2, hw=hw), prologue=PRO_AFFINE_SWISH, scale=sc, shift=sh,
                           epilogue=EPI_RESIDUAL, res=skip, emit_stats=True)
 
     def forward_host(self, x_in):
@@ -227,8 +233,14 @@ class _Conv3x3(HipModule):
         plain = not kw.get('out_nchw') and not kw.get('in_nchw')
         # operand code: 0 fp32 / 1 bf16 / 2 f16 / ops.WINOGRAD / ops.SPLIT, reduced to what this layer's shape supports
         h, w = (x.shape[2], x.shape[3]) if kw.get('in_nchw') else (x.shape[1], x.shape[2])
+        unnormalised = plain and kw.get('prologue', ops.PRO_NONE) in (ops.PRO_NONE, ops.PRO_LEAKY)
+        if unnormalised and int(bf16) == 2:
+            bf16 = ops.SPLIT   # (single IEEE halves on the direct kernel have no range scaling; the split kernels do)
         code = ops.conv_code(bf16, self.in_channels, self.out_channels, h, w, plain=plain)
-        return ops.conv2d(x, self.pw(code), **kw)
+        pw = self.pw(code)
+        if unnormalised and ops.needs_act_scale(pw):
+            kw['act'] = ops.act_scale(x)
+        return ops.conv2d(x, pw, **kw)
 
     def forward_host(self, x):
         return F.conv2d(x, self.weight, self.bias, stride=1, padding=1)
@@ -257,18 +269,20 @@ def _run_blocks_nhwc(blocks, x, taps=None, first_nchw=False, last_nchw=False, bf
     n = len(blocks)
     for i, blk in enumerate(blocks):
         if isinstance(blk, _GroupNorm):
-            pending = ops.groupnorm_tables([x], blk.weight, blk.bias, blk.eps, blk.num_groups)
+            pending = ops.groupnorm_tables([x], blk.weight, blk.bias, blk.eps, blk.num_groups) + (blk,)
         elif isinstance(blk, _Conv3x3):
             kw = {}
+            code = bf16
             if pending is not None:
                 kw.update(prologue=PRO_AFFINE, scale=pending[0], shift=pending[1])
+                code = blk._range_code(pending[2], bf16, x.shape[1] * x.shape[2] * x.shape[3] // pending[2].num_groups)
                 pending = None
             if i == 0 and first_nchw:
                 kw['in_nchw'] = True
             if i == n - 1 and last_nchw:
                 kw['out_nchw'] = True
             kw['emit_stats'] = i != n - 1      # every inner conv feeds a GroupNorm of the next block
-            x = blk.forward_nhwc(x, bf16=bf16, **kw)
+            x = blk.forward_nhwc(x, bf16=code, **kw)
         else:
             if pending is not None:
                 raise RuntimeError('GroupNorm must be followed by a conv in the block list')

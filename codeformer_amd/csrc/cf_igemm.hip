@@ -1375,6 +1375,13 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
   CF_REQUIRE(d->cout_pad >= d->cout && d->cout_pad % 32 == 0, "cf_conv2d: cout_pad %d invalid for cout %d", d->cout_pad,
              d->cout);
 
+  if (d->act_scale) {
+    CF_REQUIRE(d->prologue == CF_PRO_NONE || d->prologue == CF_PRO_LEAKY,
+               "cf_conv2d: act_scale is for un-normalised inputs (prologue none / leaky), got prologue %d", d->prologue);
+    CF_REQUIRE(d->taps == 9 && (d->bf16_mfma == CF_OPERAND_F32 || d->winograd || d->bf16_mfma == CF_OPERAND_F16X2),
+               "cf_conv2d: act_scale is applied by the Winograd / split-half 3x3 kernels only (operand %d, winograd %d, taps %d)",
+               d->bf16_mfma, d->winograd, d->taps);
+  }
   if (d->taps == 1 && d->bf16_mfma == CF_OPERAND_F16X2) {  // token GEMM on split-half operands
     CF_REQUIRE(!pq, "cf_conv2d(1x1, f16x2): no statistics epilogue");
     return cf_gemm_split_launch(d, stream);

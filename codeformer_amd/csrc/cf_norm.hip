@@ -129,6 +129,55 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
   }
 }
 
+// ---- per-image range scale for the 16-bit-operand convolutions (cf_conv_desc.act_scale) ----------------------------------------
+// One workgroup per image: A = a rigorous upper bound of max |x| (MODE 0: sqrt of the largest statistics partial sumsq; MODE 1: the
+// exact maximum of the tensor), then s = 2^k with growth * A * s in [2^13, 2^14).  max is order-independent: bitwise reproducible.
+template <int MODE>
+__global__ __launch_bounds__(256) void act_scale_kernel(const void* __restrict__ src, long n, float growth, float* __restrict__ act) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x;
+  float m = 0.f;
+  bool bad = false;
+  if (MODE == 0) {
+    const double2* p = reinterpret_cast<const double2*>(src) + (size_t)b * n;
+    double q = 0;
+    for (long j = tid; j < n; j += 256) {
+      const double v = p[j].y;
+      bad |= !(v == v) || v > 3.0e38;   // NaN / inf statistics: the image itself is not finite
+      q = v > q ? v : q;
+    }
+    m = (float)sqrt(q) * 1.0000002f;    // (rounded up: the bound must not fall below the true maximum)
+  } else {
+    const float* p = reinterpret_cast<const float*>(src) + (size_t)b * n;
+    long j = (long)tid * 4;
+    for (; j + 3 < n; j += 1024) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p + j);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        bad |= !(v[e] == v[e]);
+        m = fmaxf(m, fabsf(v[e]));
+      }
+    }
+  }
+  if (bad) m = __builtin_inff();
+  m = cf_wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  if (tid == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * growth;
+    int k = 0;
+    if (m > 0.f && m < __builtin_inff()) {
+      int e;
+      (void)frexpf(m, &e);              // m = f * 2^e, f in [0.5, 1)  ->  m * 2^(14 - e) in [2^13, 2^14)
+      k = 14 - e;
+      k = k < -100 ? -100 : (k > 100 ? 100 : k);
+    }
+    act[2 * b] = ldexpf(1.f, k);
+    act[2 * b + 1] = ldexpf(1.f, -k);
+  }
+}
+
 // ---- LayerNorm: one wave per row, C = 256*NV (NV float4 per lane) --------------------------------
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int rows, const float* __restrict__ gamma,
@@ -188,6 +237,21 @@ extern "C" int cf_groupnorm_stats(const float* x, int batch, int hw, int c, int 
   hipLaunchKernelGGL(gn_stats_kernel, dim3(parts, batch), dim3(256), 0, (hipStream_t)stream, x, hw, c, cpg, rows_per_blk,
                      partial, parts);
   CF_CHECK_LAUNCH("cf_groupnorm_stats");
+  return CF_OK;
+}
+
+extern "C" int cf_act_scale_from_stats(const double* partial, int batch, int nper, float growth, float* act, cf_stream_t stream) {
+  CF_REQUIRE(partial && act && batch >= 1 && nper >= 1 && growth > 0.f, "cf_act_scale_from_stats: bad arguments");
+  hipLaunchKernelGGL(act_scale_kernel<0>, dim3(batch), dim3(256), 0, (hipStream_t)stream, (const void*)partial, (long)nper, growth, act);
+  CF_CHECK_LAUNCH("cf_act_scale_from_stats");
+  return CF_OK;
+}
+
+extern "C" int cf_act_scale_from_tensor(const float* x, int batch, int64_t n_per_image, float growth, float* act, cf_stream_t stream) {
+  CF_REQUIRE(x && act && batch >= 1 && n_per_image >= 1 && growth > 0.f, "cf_act_scale_from_tensor: bad arguments");
+  CF_REQUIRE(n_per_image % 4 == 0, "cf_act_scale_from_tensor: n_per_image %lld must be a multiple of 4 (16-byte loads)", (long long)n_per_image);
+  hipLaunchKernelGGL(act_scale_kernel<1>, dim3(batch), dim3(256), 0, (hipStream_t)stream, (const void*)x, (long)n_per_image, growth, act);
+  CF_CHECK_LAUNCH("cf_act_scale_from_tensor");
   return CF_OK;
 }
 

@@ -94,6 +94,7 @@ struct SplitArgs {
   const float* sft_scale;
   float sft_w;
   float acc_scale;  // exact power of two: 1 / (weight scale applied at pack time)
+  const float* act_scale;  // [batch][2] (s, 1/s) powers of two for un-normalised inputs (prologue NONE / LEAKY), or null
   float* out;
   double* stats_out;
   int stats_cpg, nparts;
@@ -187,6 +188,13 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 ? SP_NARROW_OCC : 2) :
   }
 
   const bool affine = a.prologue == CF_PRO_AFFINE || a.prologue == CF_PRO_AFFINE_SWISH;
+  // range scale of an un-normalised input (cf_conv_desc.act_scale): powers of two, x * s and acc / s are exact; 1 when unused
+  float act_s = 1.f, act_is = 1.f;
+  if (!affine && a.act_scale) {
+    act_s = a.act_scale[2 * b];
+    act_is = a.act_scale[2 * b + 1];
+  }
+  const float act_s02 = 0.2f * act_s;  // LeakyReLU slope folded with the scale: fl(y * (0.2 s)) == fl(0.2 y) * s
   const float* const tab_sc = affine ? a.pro_scale + (size_t)b * a.cin : a.in0;  // (any valid address when unused)
   const float* const tab_sh = affine ? a.pro_shift + (size_t)b * a.cin : a.in0;
 
@@ -231,7 +239,8 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 ? SP_NARROW_OCC : 2) :
             v = v * rsc[u][e] + rsh[u][e];
             v = SP_FAST_RCP ? v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)) : v * __frcp_rn(1.0f + __expf(-v));  // hardware exp / rcp swish
           }
-          if (PRO == CF_PRO_LEAKY) v = v > 0.f ? v : 0.2f * v;
+          if (PRO == CF_PRO_LEAKY) v = v * (v > 0.f ? act_s : act_s02);
+          if (PRO == CF_PRO_NONE) v = v * act_s;
           y[u * 4 + e] = valid ? v : 0.f;
         }
       f32x4 hi, lo;
@@ -481,7 +490,7 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 ? SP_NARROW_OCC : 2) :
     constexpr bool nvalid = true;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + n);
-    const float s = a.acc_scale;
+    const float s = a.acc_scale * act_is;  // (a product of powers of two: exact)
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
     // Residual / SFT operands of BOTH 32-row halves are requested up front (the main loop's registers are free by now), so their
     // HBM latency overlaps the transposes instead of opening each half.
@@ -711,6 +720,7 @@ int cf_split_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query)
   a.sft_scale = d->sft_scale;
   a.sft_w = d->sft_w;
   a.acc_scale = d->acc_scale;
+  a.act_scale = d->act_scale;
   a.out = d->out;
   a.stats_out = d->stats_out;
   a.stats_cpg = d->stats_cpg > 0 ? d->stats_cpg : 1;

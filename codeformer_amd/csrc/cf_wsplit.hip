@@ -75,6 +75,7 @@ struct WsArgs {
   const float* sft_scale;
   float sft_w;
   float acc_scale;
+  const float* act_scale;  // [batch][2] (s, 1/s) powers of two for un-normalised inputs (PRO NONE / LEAKY), or null
   float* out;
   double* stats_out;
   int stats_cpg, nparts;
@@ -133,6 +134,13 @@ __global__ __launch_bounds__(WS_THREADS, 1) void wsplit_kernel(const WsArgs a) {
     pix[j] = v;
   }
   constexpr bool affine = PRO == CF_PRO_AFFINE || PRO == CF_PRO_AFFINE_SWISH;
+  // range scale of an un-normalised input (cf_conv_desc.act_scale): powers of two, so x * s and acc / s are exact; 1 when unused
+  float act_s = 1.f, act_is = 1.f;
+  if (!affine && a.act_scale) {
+    act_s = a.act_scale[2 * b];
+    act_is = a.act_scale[2 * b + 1];
+  }
+  const float act_s02 = 0.2f * act_s;  // LeakyReLU slope folded with the scale: fl(y * (0.2 s)) == fl(0.2 y) * s
   const float* const tab_sc = affine ? a.pro_scale + (size_t)b * a.cin : a.weight;  // (any valid address when unused)
   const float* const tab_sh = affine ? a.pro_shift + (size_t)b * a.cin : a.weight;
   f32x4 rsc, rsh, ra[APT];
@@ -166,7 +174,8 @@ __global__ __launch_bounds__(WS_THREADS, 1) void wsplit_kernel(const WsArgs a) {
           y = y * sc[e] + sh[e];
           y = y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));  // same hardware exp / rcp swish as the other conv kernels
         }
-        if (PRO == CF_PRO_LEAKY) y = y > 0.f ? y : 0.2f * y;
+        if (PRO == CF_PRO_LEAKY) y = y * (y > 0.f ? act_s : act_s02);
+        if (PRO == CF_PRO_NONE) y = y * act_s;
         v[e] = valid ? y : 0.f;
       }
       *reinterpret_cast<f32x4*>(patch + p * CF_LDK + k4 * 4) = v;
@@ -416,11 +425,12 @@ __global__ __launch_bounds__(WS_THREADS, 1) void wsplit_kernel(const WsArgs a) {
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + nn);
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+    const float acc_s = a.acc_scale * act_is;  // (a product of powers of two: exact)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       f32x4 v = o[i];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = v[e] * a.acc_scale + bias4[e];  // (a power of two: exact)
+      for (int e = 0; e < 4; ++e) v[e] = v[e] * acc_s + bias4[e];  // (a power of two: exact)
       if (a.epilogue == CF_EPI_RESIDUAL) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += r0[pass][i][e];
@@ -491,6 +501,7 @@ int cf_wsplit_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query
   a.sft_scale = d->sft_scale;
   a.sft_w = d->sft_w;
   a.acc_scale = d->acc_scale;
+  a.act_scale = d->act_scale;
   a.out = d->out;
   a.stats_out = d->stats_out;
   a.stats_cpg = d->stats_cpg > 0 ? d->stats_cpg : 4;

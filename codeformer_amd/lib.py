@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('CF_LIB_PATH') or os.path.join(_PKG, 'libcodeformer_hi
 
 c_float_p = ctypes.c_void_p  # device pointers are passed as integers
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 PRO_NONE, PRO_AFFINE, PRO_AFFINE_SWISH, PRO_LEAKY = 0, 1, 2, 3
 EPI_NONE, EPI_RESIDUAL, EPI_SFT, EPI_GELU, EPI_LEAKY, EPI_AXPY, EPI_AXPY2 = 0, 1, 2, 3, 4, 5, 6
 PAD_ZERO, PAD_REFLECT, PAD_EDGE = 0, 1, 2
@@ -41,6 +41,7 @@ class ConvDesc(ctypes.Structure):
         ('pad_mode', ctypes.c_int32), ('pad_lo', ctypes.c_int32), ('winograd', ctypes.c_int32),
         ('acc_scale', ctypes.c_float),
         ('split_k', ctypes.c_int32), ('workspace', ctypes.c_void_p), ('counters', ctypes.c_void_p),
+        ('act_scale', ctypes.c_void_p),
     ]
 
 
@@ -68,6 +69,8 @@ SIGNATURES = {
     'cf_pack_conv_weight_up2x_f16': (_I, [_P, _I, _I, _I, _I, _P, _P]),
     'cf_pack_conv_weight_f16x2': (_I, [_P, _I, _I, _I, _I, _I, _F, _P, _P]),
     'cf_groupnorm_stats': (_I, [_P, _I, _I, _I, _I, _P, _I, _P]),
+    'cf_act_scale_from_stats': (_I, [_P, _I, _I, _F, _P, _P]),
+    'cf_act_scale_from_tensor': (_I, [_P, _I, _L, _F, _P, _P]),
     'cf_groupnorm_finalize': (_I, [_P, _I, _I, _I, _I, _I, _L, _P, _P, _F, _P, _P, _I, _P]),
     'cf_layernorm': (_I, [_P, _I, _I, _P, _P, _F, _P, _I, _P, _P, _P]),
     'cf_attention': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P]),

@@ -115,6 +115,57 @@ def conv_code(code, cin, cout, h, w, up2x=False, c_split=None, plain=True):
     return code
 
 
+# ---- range of the 16-bit MFMA operands --------------------------------------------------------------------------------------------
+# An IEEE-half operand overflows above 65504 (16376 in the Winograd domain: the input transform sums four activations) and its lo half goes
+# subnormal below 2^-3.  Weights are scaled into [2^14, 2^15) when they are packed.  Activations:
+#   * inputs that pass a GroupNorm prologue are bounded by |gamma| * sqrt(n - 1) + |beta| (n = elements of a group); the arch modules check
+#     that bound against HALF_LIMIT when they choose a layer's kernel (gn_range_ok) and fall back to exact fp32 where it fails;
+#   * UN-NORMALISED inputs (the residual stream into Upsample.conv, the quantised feature, the CFT branch) get a per-image power-of-two
+#     scale (act_scale -> cf_conv_desc.act_scale): exact, any fp32 magnitude.  CODEFORMER_HIP_RANGE_SCALE=0 switches it off (A/B only).
+RANGE_SCALE = os.environ.get('CODEFORMER_HIP_RANGE_SCALE', '1') != '0'
+HALF_LIMIT = 65504.0 / 4.0    # largest |activation| a Winograd-domain IEEE-half operand can carry
+
+
+def needs_act_scale(pw):
+    """True when `pw` runs on a kernel with 16-bit MFMA operands that applies cf_conv_desc.act_scale."""
+    return RANGE_SCALE and pw.taps == 9 and int(pw.bf16) in (1, 2, OPERAND_F16X2) and (bool(pw.wino) or int(pw.bf16) == OPERAND_F16X2)
+
+
+def act_scale(x, growth=4.0):
+    """(B, 2) float32 table (s_b, 1 / s_b): power-of-two scale that puts growth * max|x_b| into [2^13, 2^14) -- from the statistics
+    partials the producing conv wrote (no pass over x; the bound is loose by a few bits, which is harmless) or, for tensors without
+    them, from x itself.  Cached on the tensor (one table serves every conv that reads it)."""
+    act = getattr(x, '_cf_act', None)
+    if act is not None:
+        return act
+    lib = L.load()
+    B = x.shape[0]
+    act = torch.empty(B, 2, dtype=torch.float32, device=x.device)
+    st = getattr(x, '_cf_stats', None)
+    if st is not None:
+        nper = st.part.numel() // (2 * B)
+        L.check(lib.cf_act_scale_from_stats(L.ptr(st.part, dtype=torch.float64), B, nper, float(growth), L.ptr(act), L.stream_ptr()),
+                'cf_act_scale_from_stats')
+    else:
+        if not x.is_contiguous() or (x.numel() // B) % 4:
+            raise ValueError('act_scale: expected a dense tensor with a multiple of 4 elements per image')
+        L.check(lib.cf_act_scale_from_tensor(L.ptr(_f32(x)), B, x.numel() // B, float(growth), L.ptr(act), L.stream_ptr()),
+                'cf_act_scale_from_tensor')
+    x._cf_act = act
+    return act
+
+
+def gn_range_ok(gmax, bmax, n):
+    """GroupNorm output bound |gamma| * sqrt(n - 1) + |beta| (n elements per group) against the IEEE-half operand range."""
+    return gmax * math.sqrt(max(n - 1, 1)) + bmax < HALF_LIMIT
+
+
+def exact_code(code):
+    """Operand code of the exact-fp32 evaluation that replaces a 16-bit-operand code (range fallback); bf16 has fp32's exponent."""
+    code = int(code)
+    return {SPLIT: WINOGRAD, SPLIT_DIRECT: 0, 2: WINOGRAD}.get(code, code)
+
+
 def pack_weight(weight, bias=None, bf16=False, up2x=False, f16=False):
     """weight: (cout, cin, 3, 3) | (cout, cin, 1, 1) | (cout, cin) CUDA fp32 -> PackedWeight.
     bf16=True (3x3 only, cin % 32 == 0): bf16 operands for the v_mfma_f32_32x32x16_bf16 path of cf_conv2d.
@@ -253,7 +304,7 @@ def _counters(device, n):
 
 def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale=None, shift=None,
            epilogue=EPI_NONE, res=None, sft_scale=None, sft_w=0.0, in_nchw=False, out_nchw=False, emit_stats=False,
-           out=None, pad_mode=PAD_ZERO, pad_lo=0, split_k=None):
+           out=None, pad_mode=PAD_ZERO, pad_lo=0, split_k=None, act=None):
     """Implicit-GEMM conv (3x3 / 1x1).  x: (B,H,W,C0) [x2: (B,H,W,C1) concatenated after x]; returns (B,Ho,Wo,cout)
     (or (B,cout,Ho,Wo) when out_nchw).  With in_nchw, x is (B,C<=4,H,W).
     emit_stats: also write the GroupNorm(32) partial statistics of the output in the epilogue and attach them to the
@@ -262,7 +313,8 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
     pattern of RRDBNet, where torch.cat never materialises; res / sft_scale (= res2 of EPI_AXPY2) then share out's stride.
     EPI_LEAKY / EPI_AXPY / EPI_AXPY2 use sft_w as alpha (see cf_epilogue in the header).
     pad_mode: PAD_ZERO, PAD_REFLECT (ReflectionPad2d(1) + unpadded 3x3) or PAD_EDGE (with upsample: reflection padding of the
-    upsampled image); pad_lo=1 with stride 2: one padded row / column on every side instead of right / bottom only."""
+    upsampled image); pad_lo=1 with stride 2: one padded row / column on every side instead of right / bottom only.
+    act: (B, 2) range-scale table of an un-normalised input (act_scale(x)); dropped when the layer's kernel has fp32 operands."""
     lib = L.load()
     _f32(x)
     if in_nchw:
@@ -315,6 +367,10 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
         sft_scale=L.ptr(sft_scale, True), sft_w=float(sft_w), out=L.ptr(out, not out_nchw), bf16_mfma=int(pw.bf16),
         ld_in0=ld0, ld_in1=ld1, ld_out=ldo, pad_mode=int(pad_mode), pad_lo=int(pad_lo), winograd=int(pw.wino),
         acc_scale=1.0 / pw.scale)
+    if act is not None and needs_act_scale(pw):
+        if tuple(act.shape) != (B, 2) or prologue not in (PRO_NONE, PRO_LEAKY):
+            raise ValueError('act: expected a (B, 2) table and a none / leaky prologue')
+        d.act_scale = L.ptr(act)
     if split_k is None:
         dense = not in_nchw and not out_nchw and ld0 == c0 and (c1 == 0 or ld1 == c1) and ldo in (0, pw.cout)
         split_k = splitk_for(pw, Ho, Wo, c0 + c1, B) if (stride == 1 and dense) else 0

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 15
+#define CF_ABI_VERSION 16
 
 typedef void* cf_stream_t; /* hipStream_t */
 
@@ -159,6 +159,14 @@ typedef struct cf_conv_desc {
   int32_t split_k;
   float* workspace;
   uint32_t* counters;
+  /* Range scaling of an UN-NORMALISED input for the 16-bit-operand kernels (CF_OPERAND_F16X2 / F16 / BF16; prologue NONE or LEAKY only):
+   * [batch][2] floats (s_b, 1 / s_b) written by cf_act_scale_from_stats / cf_act_scale_from_tensor, or NULL.  The gather multiplies
+   * image b's activations by s_b after the prologue and the epilogue multiplies the accumulator by 1 / s_b on top of acc_scale -- both
+   * powers of two, so the result is the one an unscaled evaluation would give, for inputs of ANY fp32 magnitude: without it an IEEE-half
+   * operand overflows above 65504 (16376 in the Winograd domain, whose input transform sums four activations) and loses its lo half
+   * below 2^-3.  Inputs that went through a GroupNorm prologue need none (their range is bounded by gamma, beta and the group size; the
+   * host checks that bound when it packs the layer).  Ignored by the exact fp32 kernels. */
+  const float* act_scale;
 } cf_conv_desc;
 
 int cf_conv2d(const cf_conv_desc* d, cf_stream_t stream);
@@ -224,6 +232,16 @@ int cf_pack_conv_weight_f16x2(const float* w, int cout, int cin, int up2x, int c
  */
 int cf_groupnorm_stats(const float* x, int batch, int hw, int c, int cpg, double* partial, int parts,
                        cf_stream_t stream);
+/* ---- per-image power-of-two range scale for cf_conv_desc.act_scale ------------------------------------------------------------
+ * act[b] = (s_b, 1 / s_b) with s_b = 2^k such that growth * A_b * s_b lies in [2^13, 2^14), A_b >= max |x| over image b
+ * (s_b = 1 for an all-zero or non-finite image; k clamped to [-100, 100]).  growth = 4 covers the Winograd input transform.
+ * from_stats:  A_b = sqrt(max over the image's `nper` = groups * parts statistics partials of sumsq) -- a rigorous bound on max |x|
+ *              (each partial covers at most a few hundred elements, so it is loose by at most ~5 bits: harmless, the split operands
+ *              keep 22 bits over 18 binades) that costs no pass over the tensor: the partials are the ones cf_conv_desc.stats_out
+ *              of the PRODUCING launch wrote, layout [batch][nper][2] doubles.
+ * from_tensor: A_b = max |x| exactly, one pass over x [batch][n_per_image] (small tensors: the 16x16 quantised feature). */
+int cf_act_scale_from_stats(const double* partial, int batch, int nper, float growth, float* act, cf_stream_t stream);
+int cf_act_scale_from_tensor(const float* x, int batch, int64_t n_per_image, float growth, float* act, cf_stream_t stream);
 int cf_groupnorm_finalize(const double* partial, int batch, int parts, int c, int cpg, int gmerge, int64_t count,
                           const float* gamma, const float* beta, float eps, float* scale, float* shift, int ld,
                           cf_stream_t stream);

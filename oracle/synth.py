@@ -70,3 +70,63 @@ def synth_detector_state_dict(shapes, seed):
                 gain = 0.1                 # heads: unsaturated class probabilities, regression offsets of O(0.1)
             sd[name] = torch.randn(shape, generator=g) * (gain * math.sqrt(2.0 / fan_in))
     return sd
+
+
+# ---- range-robustness variants of a state_dict ---------------------------------------------------------------
+# The un-normalised streams of CodeFormer.forward are the residual stream (fed straight into Upsample.conv), the quantised feature
+# (generator block 0), the CFT branch (`encode_enc` output -> scale.0 / shift.0 -> LeakyReLU -> scale.2 / shift.2) and lq_feat (AdaIN
+# target, Transformer input).  These keys set their magnitude:
+def _stream_keys(sd):
+    keys = []
+    for k in sd:
+        if not (k.endswith('.weight') or k.endswith('.bias')):
+            continue
+        base = k.rsplit('.', 1)[0]
+        if base.endswith('.conv_out') or base.endswith('.conv2') or base.endswith('.proj_out'):
+            keys.append(k)                                                     # what a ResBlock / AttnBlock adds to the residual stream
+        elif base.startswith('generator.blocks.') and base.endswith('.conv') and sd[base + '.weight'].dim() == 4 \
+                and base.count('.') == 3:                                      # Upsample.conv (generator.blocks.N.conv)
+            keys.append(k)
+        elif base.startswith('fuse_convs_dict.') and ('.scale.' in base or '.shift.' in base):
+            keys.append(k)
+        elif base == 'encoder.blocks.24':                                      # encoder head: lq_feat (AdaIN statistics, tokens)
+            keys.append(k)
+    return keys
+
+
+def range_variant(sd, kind, seed=4321, calib=None):
+    """Deterministic modification of a CodeFormer state_dict that stretches the magnitude of the un-normalised streams.
+    kind: 'big' (stream-setting weights and biases x 64: un-normalised conv inputs of 1e3..1e9, far beyond the IEEE-half range;
+                 SFT is multiplicative -- dec * scale(e), with e growing like dec -- so the LAST conv of every scale / shift branch
+                 is divided by `calib[name]`, the power of two oracle/make_golden_range.py measured on that conv's input with the
+                 reference, which keeps the reference itself inside fp32; the goldens store the table),
+          'small' (x 1/4096: streams of 1e-4..1e-6, below the half normals and, in the CFT branch, near its subnormal step),
+          'heavy' (trained-like: every conv / linear weight gets a heavy-tailed per-element factor, norm gains are log-normal,
+                   norm biases N(0, 0.3) -- wide dynamic range inside the normalised streams as well)."""
+    out = {k: v.clone() for k, v in sd.items()}
+    if kind in ('big', 'small'):
+        f = 64.0 if kind == 'big' else 1.0 / 4096.0
+        for k in _stream_keys(sd):
+            if kind == 'big' and ('.scale.2.' in k or '.shift.2.' in k):
+                if k.endswith('.weight'):
+                    out[k] = out[k] / float((calib or {}).get(k, 1.0))
+                continue
+            out[k] = out[k] * f
+        return out
+    if kind == 'heavy':
+        g = torch.Generator().manual_seed(seed)
+        for k in sorted(sd):
+            v = out[k]
+            if not v.dtype.is_floating_point:
+                continue
+            if v.dim() >= 2 and k.endswith('weight') and 'embedding' not in k:
+                t = torch.randn(v.shape, generator=g) / torch.sqrt(torch.randn(v.shape, generator=g) ** 2 * 0.5
+                                                                   + torch.randn(v.shape, generator=g) ** 2 * 0.5 + 1e-3)
+                out[k] = v * (0.5 + 0.5 * t.abs().clamp(max=40.0))           # Student-t(2)-like factor, median ~1, tail to 20x
+            elif v.dim() == 1 and ('norm' in k or k.endswith('.23.weight') or k.endswith('.23.bias') or 'idx_pred_layer.0' in k):
+                if k.endswith('weight'):
+                    out[k] = v * torch.exp(0.5 * torch.randn(v.shape, generator=g))
+                else:
+                    out[k] = v + 0.3 * torch.randn(v.shape, generator=g)
+        return out
+    raise ValueError(kind)

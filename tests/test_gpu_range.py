@@ -1,0 +1,178 @@
+"""-m gpu: range robustness of the 16-bit-operand kernels.
+
+tests/golden/range_*.npz hold the REFERENCE's CodeFormer.forward (oracle/make_golden_range.py) for weights that push the
+un-normalised streams -- residual stream into Upsample.conv, quantised feature, the CFT branch -- to 1e3..1e14 ('big'), down to
+1e-4..5e-6 ('small'), and for trained-like heavy-tailed weights ('heavy', seeded face and the reference's own crop 0143.png).
+The HIP path must meet the north-star gates in the default split-half mode AND the exact mode:
+  logits 1e-4, code indices exact (reference top-2 gap >= 1e-5), pixels 1e-3 x max(1, max |reference output|).
+Without the per-image power-of-two range scale (cf_conv_desc.act_scale) the 'big' case is inf / NaN and the 'small' case loses the
+lo halves; the last test measures that (informational print + the assertion that the scale is what fixes it).
+"""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+pytestmark = pytest.mark.gpu
+
+CASES = [('big', 'seed'), ('small', 'seed'), ('heavy', 'seed'), ('heavy', 'real0143')]
+
+
+@pytest.fixture(scope='module')
+def chk():
+    import torch
+    assert torch.cuda.is_available(), 'gpu tests need an MI355X'
+    from codeformer_amd import lib
+    lib.load()
+    spec = importlib.util.spec_from_file_location('gpu_check', os.path.join(ROOT, 'tools', 'gpu_check.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.fixture(scope='module')
+def nets(chk):
+    """One module per variant (weights = range_variant of the seed-0 state_dict; 'big' uses the golden's calibration table)."""
+    from oracle.synth import range_variant
+    base = chk.build_net()
+    sd0 = {k: v.detach().clone() for k, v in base.state_dict().items()}
+    cache = {}
+
+    def get(kind):
+        if kind not in cache:
+            g = np.load(os.path.join(GOLD, f'range_{kind}_seed.npz'))
+            calib = {str(k): float(v) for k, v in zip(g['calib_keys'], g['calib_vals'])}
+            net = chk.build_net()
+            net.load_state_dict(range_variant(sd0, kind, calib=calib or None))
+            cache[kind] = net.cuda()
+        return cache[kind]
+    return get
+
+
+def _input(tag):
+    import torch
+    from oracle.synth import seeded_input
+    if tag == 'seed':
+        return seeded_input(1).cuda()
+    from codeformer_amd import ops
+    img = np.load(os.path.join(GOLD, 'real_0143.npz'))['img']
+    return ops.img_u8_to_tensor(torch.from_numpy(img).unsqueeze(0).cuda())
+
+
+def _run(net, x, precision):
+    import torch
+    net.precision = precision
+    try:
+        out, logits, lq = net(x, w=0.5, adain=True)
+        torch.cuda.synchronize()
+    finally:
+        net.precision = 'f16x2'
+    return out.cpu(), logits.cpu(), lq.cpu(), net.last_indices.cpu().numpy()
+
+
+@pytest.mark.parametrize('precision', ['f16x2', 'fp32'])
+@pytest.mark.parametrize('kind,tag', CASES)
+def test_range_variants_match_the_reference(nets, kind, tag, precision):
+    import torch
+    g = np.load(os.path.join(GOLD, f'range_{kind}_{tag}.npz'))
+    out, logits, lq, idx = _run(nets(kind), _input(tag), precision)
+    assert bool(torch.isfinite(out).all()) and bool(torch.isfinite(logits).all())
+    dl = float((logits - torch.from_numpy(g['logits'])).abs().max())
+    scale = max(1.0, float(g['out_absmax']))
+    dp = float((out[:, :, ::4, ::4] - torch.from_numpy(g['out_sub'])).abs().max())
+    dq = float((lq[:, ::8] - torch.from_numpy(g['lq_sub'])).abs().max()) / max(float(g['lq_absmax']), 1e-30)
+    ref, gap = g['idx'].reshape(-1), g['gap'].reshape(-1)
+    safe = gap >= 1e-5
+    nbad = int((idx.reshape(-1)[safe] != ref[safe]).sum())
+    print(f'range {kind}/{tag} [{precision}]: logits {dl:.2e}  pixels {dp:.2e} (output scale {scale:.2f})  lq_feat rel {dq:.2e}  '
+          f'indices differing {nbad}  near-ties {int((~safe).sum())}  min gap {float(gap.min()):.2e}')
+    assert dl <= 1e-4
+    assert nbad == 0
+    assert dp <= 1e-3 * scale
+
+
+def test_act_scale_kernels():
+    """cf_act_scale_from_tensor: exact power of two with 4 * max|x| * s in [2^13, 2^14); from_stats: the same from the statistics
+    partials of a producing conv -- a rigorous bound (>= the true maximum, loose by < 2^6); zero / non-finite images give s = 1."""
+    import torch
+    from codeformer_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(6, 16, 16, 64, generator=g)
+    x[0] *= 3.7e9
+    x[1] *= 2.2e-7
+    x[2] = 0
+    x[3, 1, 2, 3] = float('inf')
+    x[4, 0, 0, 0] = 12345.678
+    xd = x.cuda()
+    act = ops.act_scale(xd).cpu()
+    for b in (0, 1, 4, 5):
+        m = 4.0 * float(x[b].abs().max())
+        s, inv = float(act[b, 0]), float(act[b, 1])
+        assert s * inv == 1.0 and np.log2(s) == int(np.log2(s))
+        assert 2.0 ** 13 <= m * s < 2.0 ** 14, (b, m, s)
+    assert act[2].tolist() == [1.0, 1.0] and act[3].tolist() == [1.0, 1.0]
+    # statistics route: producer = a 3x3 conv with emit_stats
+    w = torch.randn(128, 64, 3, 3, generator=g) * 0.05
+    xin = torch.randn(2, 32, 32, 64, generator=g).cuda()
+    xin[1] *= 1.0e6
+    y = ops.conv2d(xin, ops.pack_weight(w.cuda(), None), emit_stats=True)
+    a_stats = ops.act_scale(y).cpu()
+    for b in range(2):
+        m = 4.0 * float(y[b].abs().max())
+        s = float(a_stats[b, 0])
+        assert m * s < 2.0 ** 14 and m * s >= 2.0 ** 7, (b, m * s)       # never above the range, at most 6 bits below the tight scale
+
+
+@pytest.mark.parametrize('mag', [1.0e9, 3.0e-9])
+@pytest.mark.parametrize('pro', ['none', 'leaky'])
+def test_split_conv_kernels_with_extreme_inputs(pro, mag):
+    """The eight-wave Winograd kernel and the folded-upsample direct kernel on un-normalised inputs far outside the IEEE-half range,
+    against fp64: with the range scale the error relative to the output scale is that of O(1) inputs."""
+    import torch
+    import torch.nn.functional as F
+    from codeformer_amd import ops
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(2, 128, 32, 32, generator=g)
+    x[0] *= mag
+    x[1] *= mag * 37.0
+    w = torch.randn(128, 128, 3, 3, generator=g) * 0.03
+    bias = torch.randn(128, generator=g) * 0.1
+    xn = x.permute(0, 2, 3, 1).contiguous().cuda()
+    for up in (False, True):
+        if up and pro == 'leaky':
+            continue
+        code = ops.conv_code(ops.SPLIT, 128, 128, 32, 32, up2x=up)
+        pw = ops.pack_weight(w.cuda(), bias.cuda(), bf16=code, up2x=up)
+        assert ops.needs_act_scale(pw)
+        y = ops.conv2d(xn, pw, upsample=up, prologue=ops.PRO_LEAKY if pro == 'leaky' else ops.PRO_NONE, act=ops.act_scale(xn))
+        xr = x.double()
+        if pro == 'leaky':
+            xr = F.leaky_relu(xr, 0.2)
+        if up:
+            xr = F.interpolate(xr, scale_factor=2.0, mode='nearest')
+        ref = F.conv2d(xr, w.double(), bias.double(), padding=1).permute(0, 2, 3, 1)
+        for b in range(2):
+            err = float((y[b].cpu().double() - ref[b]).abs().max()) / float(ref[b].abs().max())
+            print(f'split conv up={up} pro={pro} mag={mag:g} image {b}: max err / max|ref| = {err:.2e}')
+            assert err < 3e-6
+
+
+def test_without_the_range_scale_the_big_case_overflows(nets):
+    """Documents what the scale is for: the same 'big' weights with CODEFORMER_HIP_RANGE_SCALE off give a non-finite image."""
+    import torch
+    from codeformer_amd import ops
+    g = np.load(os.path.join(GOLD, 'range_big_seed.npz'))
+    net = nets('big')
+    x = _input('seed')
+    ops.RANGE_SCALE = False
+    try:
+        out = net(x, w=0.5, adain=True)[0].cpu()
+    finally:
+        ops.RANGE_SCALE = True
+    finite = bool(torch.isfinite(out).all())
+    d = float((out[:, :, ::4, ::4] - torch.from_numpy(g['out_sub'])).abs().nan_to_num(float('inf')).max())
+    print(f'big variant without the range scale: finite={finite} pixels {d:.2e}')
+    assert (not finite) or d > 1e-3

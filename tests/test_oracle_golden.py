@@ -171,3 +171,20 @@ def test_oracle_tensor2img_and_composite_match_reference_golden(golden_dir):
     comp = O.inpaint_composite(x, y)
     m = torch.from_numpy(g['mask']).bool().expand_as(x)
     assert torch.equal(comp[m], y[m]) and torch.equal(comp[~m], x[~m])
+
+
+@pytest.mark.parametrize('kind', ['big', 'small'])
+def test_oracle_on_range_variants_matches_reference_golden(seed0_net, golden_dir, kind):
+    """Range-robustness fixtures (oracle/make_golden_range.py): the oracle on weights whose un-normalised streams reach 1e14 / 5e-6
+    reproduces the reference's logits, indices and (relative to the output scale) pixels; the recorded agreement is asserted too."""
+    from oracle.synth import range_variant
+    g = np.load(os.path.join(golden_dir, f'range_{kind}_seed.npz'))
+    calib = {str(k): float(v) for k, v in zip(g['calib_keys'], g['calib_vals'])}
+    sd = range_variant(_sd(seed0_net), kind, calib=calib or None)
+    out, logits, lq, idx = O.codeformer_forward(seeded_input(1), sd, w=0.5, adain_flag=True, return_idx=True)
+    assert float((logits - torch.from_numpy(g['logits'])).abs().max()) <= 2e-5
+    assert np.array_equal(idx.numpy(), g['idx'])
+    assert float((out[:, :, ::4, ::4] - torch.from_numpy(g['out_sub'])).abs().max()) <= 1e-4 * max(1.0, float(g['out_absmax']))
+    rep = json.load(open(os.path.join(golden_dir, 'range_oracle_vs_reference.json')))
+    for name, r in rep.items():
+        assert r['oracle_idx_equal'] and r['oracle_vs_ref_logits'] <= 2e-5 and r['oracle_vs_ref_out'] <= 1e-5, name

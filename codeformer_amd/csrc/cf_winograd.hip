@@ -41,6 +41,9 @@
 
 #include "cf_common.h"
 
+#ifndef CF_W64_EXPERIMENT
+#define CF_W64_EXPERIMENT 0
+#endif
 // CF_WABLATE: timing-only ablation builds (tools/ab_variants.sh); 0 / undefined in every product build.
 #ifndef CF_WABLATE
 #define CF_WABLATE 0
@@ -639,6 +642,10 @@ extern "C" int cf_pack_conv_weight_winograd(const float* w, int cout, int cin, i
 
 bool cf_wsplit_covers(const cf_conv_desc* d);                                        // cf_wsplit.hip: the eight-wave,
 int cf_wsplit_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query);  // 128-channel split-half form
+#if CF_W64_EXPERIMENT  // tools/experiments/cf_w64.hip (persistent, DMA-fed 64-output-channel form; measured, not shipped)
+bool cf_w64_covers(const cf_conv_desc* d);
+int cf_w64_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query);
+#endif
 
 // Called by cf_conv2d (cf_igemm.hip) for descriptors with winograd != 0; the common argument checks have run there.
 int cf_winograd_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query) {
@@ -660,6 +667,9 @@ int cf_winograd_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_que
                  (d->ld_out == 0 || d->ld_out == d->cout),
              "cf_conv2d: winograd reads / writes dense tensors with zero padding");
   if (h2 && cf_wsplit_covers(d)) return cf_wsplit_launch(d, stream, parts_query);
+#if CF_W64_EXPERIMENT
+  if (h2 && !h1 && cf_w64_covers(d)) return cf_w64_launch(d, stream, parts_query);
+#endif
   CF_REQUIRE(!h1, "cf_conv2d(winograd, single 16-bit operands): not covered");
   WinoArgs a;
   a.in0 = d->in0;

@@ -21,9 +21,13 @@ Rank 0 prints ONE JSON line with the contract fields plus
                 achieved = MFMA FLOPs it EXECUTES / duration, against the dense peak of the MFMA type it issues (f16: 2500
                 TFLOP/s, fp32: 157.3, MI355X_MICROARCH.md); effective_tflops = the convolution's algorithmic FLOPs
                 (2*taps*Cin*Cout per output pixel) / duration; `other_kernels` holds the same record for every other kernel class;
-                `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_bench.json).
-  cpu_baseline: the CPU oracle (oracle/codeformer_oracle.py, torch CPU fp32, up to 64 host threads) timed on a bounded sample
-                (batch-1 forwards for ~10-30 s) on rank 0 at N=1.
+                `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_bench.json), quoted only when
+                that file's build id equals the loaded library's (null otherwise: the kernels changed since the counters were taken).
+  cpu_baseline: the CPU oracle (oracle/codeformer_oracle.py -- kind "port": the restatement pinned to the reference's outputs, not the
+                reference's own files, which do not exist on the GPU box; torch CPU fp32, up to 64 host threads) timed on a bounded
+                sample (batch-1 forwards for ~10-30 s) on rank 0 at N=1.
+  parity:       the golden-face gate that runs BEFORE the timed region: pixels / logits / code indices of the
+                seeded face against the reference's committed output; the run aborts if it fails.
 """
 import argparse
 import json
@@ -62,17 +66,26 @@ def build_net(device):
 
 def recorded_traffic(prefixes=('wsplit_kernel',)):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_bench.json,
-    produced by tools/pmc_bench.sh on this same bench step; bench.py cannot profile itself).  Per the MI355X guide:
+    produced by tools/pmc_bench.sh on this same bench step; bench.py cannot profile itself -- the file is stamped with the
+    library's build id and ignored (traffic = null) when the kernels have changed since).  Per the MI355X guide:
     FETCH_SIZE / WRITE_SIZE are in KiB, and on gfx950 FETCH_SIZE reports half of the bytes of wide (16 B/lane) reads, so
     bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024, launch-weighted over the kernels whose name (without the
     `void (anonymous namespace)::` decoration) starts with one of `prefixes`."""
     import glob
+    from codeformer_amd import lib
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_bench.json')))
     if not files:
         return None
     d = json.load(open(files[-1]))
+    # Counters are only as good as the kernels they were taken from: the file carries the build id (source hash) of the library
+    # that was profiled (tools/pmc_bench.sh); if the loaded library differs, nothing is quoted -- a stale number is worse than null.
+    have, want = d.get('_meta', {}).get('cf_build_id'), lib.load().cf_build_id().decode()
+    if have != want:
+        return None
     n = tot = 0
     for k, v in d.items():
+        if k == '_meta':
+            continue
         name = k.replace('void ', '').replace('(anonymous namespace)::', '')
         if name.startswith(tuple(prefixes)) and 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
             ln = v['FETCH_SIZE']['launches']
@@ -157,6 +170,31 @@ def roofline_leg(net, x, w):
     return roof, table
 
 
+def parity_gate(net, sd_cpu, weights, w):
+    """nothing is timed before the path has reproduced the reference.  Seed-0 weights: the committed golden
+    of the REFERENCE's forward on the seeded face (tests/golden/restoration_seed0_face0.npz: pixels 1e-3, logits 1e-4, code indices
+    exact); other weights (a real checkpoint): the CPU oracle on the same face."""
+    import numpy as np
+    from oracle.synth import seeded_input
+    x = seeded_input(1)
+    out, logits, _ = net(x.to(next(net.parameters()).device), w=w, adain=True)
+    torch.cuda.synchronize()
+    idx = net.last_indices.cpu().view(-1)
+    gold = os.path.join(ROOT, 'tests', 'golden', 'restoration_seed0_face0.npz')
+    if weights == 'seed-0 random-init' and w == 0.5 and os.path.exists(gold):
+        g = np.load(gold)
+        ref_out, ref_logits, ref_idx, src = torch.from_numpy(g['out']), torch.from_numpy(g['logits']), torch.from_numpy(g['idx']).view(-1), 'reference golden (tests/golden/restoration_seed0_face0.npz)'
+    else:
+        from oracle import codeformer_oracle as O
+        ref_out, ref_logits, _, ref_idx = O.codeformer_forward(x, sd_cpu, w=w, adain_flag=True, return_idx=True)
+        ref_idx, src = ref_idx.view(-1), 'CPU oracle (oracle/codeformer_oracle.py)'
+    res = {'against': src, 'max_abs_pixel_diff': float((out.cpu() - ref_out).abs().max()), 'max_abs_logit_diff': float((logits.cpu() - ref_logits).abs().max()),
+           'code_indices_equal': bool(torch.equal(idx, ref_idx)), 'tolerances': 'pixels 1e-3, logits 1e-4, code indices exact'}
+    if not (res['max_abs_pixel_diff'] <= 1e-3 and res['max_abs_logit_diff'] <= 1e-4 and res['code_indices_equal']):
+        raise SystemExit(f'bench.py: parity gate FAILED, nothing timed: {json.dumps(res)}')
+    return res
+
+
 def cpu_baseline_leg(sd_cpu, w, budget_s=25.0):
     """CPU oracle, batch-1 forwards, bounded: at most ~budget_s of timed work (>= 1 forward) after one warm-up.
     Threads = the CPUs this process may run on, capped at 64 (torch's intra-op pool stops scaling well before that on
@@ -191,9 +229,11 @@ def main():
     ap.add_argument('--batch-per-gpu', type=int, default=16)
     ap.add_argument('--w', type=float, default=0.5)
     ap.add_argument('--precision', choices=['fp32', 'f16x2', 'bf16', 'fp16'], default='f16x2',
-                    help="operand format of the generator + CFT 3x3 convolutions (encoder / Transformer / argmax are exact fp32 in every "
-                         "mode): f16x2 = fp32 operands split into hi+lo halves, fp32-grade accuracy (default); fp32 = exact fp32 MFMA; "
-                         "bf16 / fp16 = 16-bit operands (BASELINE configs 3/5)")
+                    help="operand format of the 3x3 stride-1 convolutions (Transformer, 1x1 / stride-2 convs, statistics and the code argmax are "
+                         "exact fp32 in every mode): f16x2 = fp32 operands split into hi+lo IEEE halves, fp32-grade accuracy, encoder included "
+                         "(default); fp32 = exact fp32 MFMA everywhere; bf16 / fp16 = single 16-bit operands in generator + CFT (BASELINE configs "
+                         "3/5), encoder on split halves")
+    ap.add_argument('--no-parity-gate', action='store_true', help='skip the golden-face check that precedes the timed region')
     ap.add_argument('--no-exact-leg', action='store_true', help='skip the extra exact-fp32 timing of the default run')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -217,6 +257,9 @@ def main():
 
     # One gather is kept in flight: step i's restored faces travel to rank 0 (RCCL, its own stream) while step i+1 computes.
     # Every gather of the timed steps is joined before the closing synchronize, so the K steps are complete inside the bracket.
+    parity = None
+    if rank == 0 and not args.no_parity_gate and args.precision in ('fp32', 'f16x2'):
+        parity = parity_gate(net, sd_cpu, weights, args.w)     # raises before anything is timed if the path does not match the reference
     pending = [None]
 
     def step():
@@ -259,13 +302,18 @@ def main():
                                                   'products on split operands: fp32 = hi + lo IEEE halves, 3 f16 MFMAs per product)'}.get(
                 args.precision, f'{args.precision} operands / f32 accumulate (3x3 convs of generator + CFT); encoder on split halves (hi + lo, fp32-grade); f32 (Transformer, 1x1, stride 2)'),
             'data': 'synthetic',
-            'config': {'workload': (('BASELINE config 2' if (args.precision in ('fp32', 'f16x2') and args.w == 0.5 and B == 16) else 'custom')
+            'config': {'workload': ({'fp32': 'BASELINE config 2 (IEEE fp32 arithmetic)',
+                                     'f16x2': "BASELINE config 2 shapes and tensors; 3x3 products on split-half f16 operands (fp32-grade: meets the config's "
+                                              "1e-3 pixel / exact-index gates, see `parity`; the IEEE-fp32 evaluation of the same step is `exact_fp32`)"}.get(
+                                        args.precision, 'custom') if (args.w == 0.5 and B == 16) else 'custom')
                                     + f': batch={B} aligned 512x512 faces per GPU, w={args.w}, adain=True, precision={args.precision}, '
-                                      f'CodeFormer(codebook 1024, 4 fuse levels), {weights} weights'), 'global_batch': total,
+                                      f'CodeFormer(codebook 1024, 4 fuse levels), {weights} weights', 'global_batch': total,
                        'parallelism': f'faces sharded x{world}, one gather to rank 0' if world > 1 else 'single GPU'},
             'whole_path': {'effective_tflops_reference_flop_count': round(faces_per_s * GFLOP_PER_FACE / 1e3, 2),
                            'frac_hbm_peak_fused_min_bytes': round(faces_per_s * FUSED_MIN_GB_PER_FACE / (HBM_PEAK_GBS * world), 4)},
         }
+        if parity is not None:
+            line['parity'] = parity
         if not args.no_roofline:
             roof, table = roofline_leg(net, x, args.w)
             line['roofline'] = roof

@@ -191,8 +191,9 @@ class CodeFormer(VQAutoEncoder):
         # Round 2 added the reference's own crops (three PNGs, one masked face) and an 8-face sweep to the gate: indices equal the
         # reference's on every token whose reference gap is >= 1e-5 (tests/test_gpu_real_images.py).
         self.winograd_encoder = os.environ.get('CODEFORMER_HIP_WINOGRAD_ENCODER', '1') != '0'
-        # Operand format of the ENCODER's 3x3 stride-1 convolutions: 'fp32' (exact fp32 MFMA, Winograd where eligible), 'f16x2' (the
-        # split-half kernel on every layer it covers: all but the first conv and the 16x16 latents) or 'auto' = 'fp32' when
+        # Operand format of the ENCODER's 3x3 stride-1 convolutions: 'fp32' (exact fp32 MFMA, Winograd where eligible), 'f16x2' (split
+        # halves on every layer but the first conv -- the 16x16 latents included, on the four-wave Winograd kernel with split-K; only with
+        # winograd = False do the latents stay on the exact direct kernel) or 'auto' = 'fp32' when
         # precision is 'fp32', 'f16x2' otherwise (a 16-bit generator does not ask for an exact-fp32 encoder at 0.54 of the fp32 MFMA peak).  The code indices hang on the encoder, so this was measured before it became the
         # default (tools/encoder_split_check.py, profiles/r02_encoder_split_check.txt): against the reference's logits on its own
         # crops the split encoder is as close as the exact one (max 6.7e-6 / 5.4e-6 / 5.7e-6 vs 7.6e-6 / 5.5e-6 / 6.0e-6; the

@@ -116,7 +116,9 @@ class FaceRestoreHelper(object):
         h, w = img.shape[:2]
         if min(h, w) < 512:
             f = 512.0 / min(h, w)
-            img = resize_bilinear(img, (int(round(w * f)), int(round(h * f))))
+            # cv2.resize(img, (0, 0), fx=f, fy=f, INTER_LINEAR) (face_restoration_helper.py:159-161): dsize = round(f * size), coordinates
+            # mapped with 1 / f on both axes
+            img = resize_bilinear(img, (int(round(w * f)), int(round(h * f))), inv_scale=(f, f))
         self.input_img = img
         if self.device.type == 'cuda':
             self._device_helper().read_image(img)

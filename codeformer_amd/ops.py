@@ -82,7 +82,10 @@ def winograd_ok(cin, cout, hout, wout):
     return cin % 16 == 0 and cout % 64 == 0 and hout % 8 == 0 and wout % 16 == 0
 
 
-SPLIT_MIN_PIXELS = 32 * 32   # below this input size (the 16x16 latents) the layer stays on fp32 Winograd: too few 8x16 tiles per image
+# Smallest per-image input of the DIRECT split-half kernel and of the eight-wave Winograd kernel.  The 16x16 latents are below it: with
+# SPLIT they run the four-wave Winograd kernel on split halves with split-K (conv_code -> WSPLIT: measured on the reference's crops
+# before it became the default, profiles/r02_encoder_split_check.txt), with SPLIT_DIRECT they stay on the exact fp32 kernel.
+SPLIT_MIN_PIXELS = 32 * 32
 
 
 def wsingle_ok(cin, cout, h, w):

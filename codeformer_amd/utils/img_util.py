@@ -20,8 +20,10 @@ def imread_bgr(path):
     return np.ascontiguousarray(rgb[:, :, ::-1])
 
 
-def resize_bilinear(img, size):
+def resize_bilinear(img, size, inv_scale=None):
     """cv2.resize(img, size, interpolation=cv2.INTER_LINEAR) for uint8 HWC images (identity when the size already matches).
+    inv_scale=(fx, fy): the call form cv2.resize(img, (0, 0), fx=fx, fy=fy) -- OpenCV then maps coordinates with 1 / fx and 1 / fy
+    instead of src / dst (they differ when fx * src is not an integer), `size` being (round(fx * w), round(fy * h)).
 
     cv2's rule, restated: half-pixel centres (src = (dst + 0.5) * scale - 0.5), the two nearest source samples per axis with NO
     antialiasing even when shrinking, source coordinates clamped to the image, and -- for uint8 -- fixed-point arithmetic: the
@@ -34,8 +36,8 @@ def resize_bilinear(img, size):
     if img.dtype != np.uint8:
         raise TypeError('resize_bilinear restates the uint8 path of cv2.resize')
 
-    def axis(n_src, n_dst):
-        scale = n_src / n_dst
+    def axis(n_src, n_dst, inv=None):
+        scale = n_src / n_dst if inv is None else 1.0 / float(inv)
         f = (np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5
         i0 = np.floor(f).astype(np.int64)
         frac = (f - i0).astype(np.float32)
@@ -49,8 +51,8 @@ def resize_bilinear(img, size):
         w1 = np.rint(frac.astype(np.float64) * 2048.0).astype(np.int64)     # cvRound: half to even
         return i0, i1, 2048 - w1, w1
 
-    x0, x1, wx0, wx1 = axis(w, dw)
-    y0, y1, wy0, wy1 = axis(h, dh)
+    x0, x1, wx0, wx1 = axis(w, dw, inv_scale[0] if inv_scale else None)
+    y0, y1, wy0, wy1 = axis(h, dh, inv_scale[1] if inv_scale else None)
     src = img.astype(np.int64).reshape(h, w, -1)
     rows0, rows1 = src[y0], src[y1]                                        # (dh, w, c)
     top = rows0[:, x0] * wx0[None, :, None] + rows0[:, x1] * wx1[None, :, None]

@@ -66,6 +66,8 @@ def parse_args(argv=None):
                         "MIOpen: 193 frames/s for RetinaFace-ResNet50 at 640x1138 on an MI355X), 'cpu' = the host cores (2 frames/s on 64 threads)")
     p.add_argument('--io_workers', type=int, default=None, help='PNG decode / encode worker threads of the GPU pipeline')
     p.add_argument('--strict', action='store_true', help='Raise on inference errors instead of returning the input face')
+    p.add_argument('--frame_window', type=int, default=32, help='Whole-image / video path: images restored, pasted back and written per window '
+                   '(bounds host memory; faces are batched 16 per forward across the images of a window)')
     return p.parse_args(argv)
 
 
@@ -150,8 +152,37 @@ def restore_whole_images(args, input_img_list, result_root, w):
     # kernels instead of a host-side resize; crops and paste-back are the VideoRestorer's)
     helper = FaceRestoreHelper(args.upscale, face_size=512, crop_ratio=(1, 1), det_model=args.detection_model, save_ext='png',
                                use_parse=False, device=device, face_detector=build_detector(args, device) if table is None else False)
+    vr = VideoRestorer(net, device, upscale=args.upscale, batch_size=args.batch_size or 16, bg_upsampler=bg,
+                       use_parse=parser is not None, face_parse=parser)
+    totals = {'frames': 0, 'faces': 0, 'forward_calls': 0}
+    failed = []
+
+    def flush(frames, affs, names, grays):
+        """Restore, paste and write one window of frames, then let go of it: host memory is bounded by the window, not by the
+        length of the clip (the reference streams one image at a time; a window keeps the 16-face forwards full across images)."""
+        try:
+            outs = vr.restore(frames, affs, w=w, keep_faces=True, gray=grays)
+            per_frame = vr.faces_out
+        except Exception as error:   # the reference's per-image fallback (inference_codeformer.py:207-209): keep going, report at the end
+            if args.strict:
+                raise
+            print(f'\tFailed inference for CodeFormer: {error}')
+            failed.extend(names)
+            return
+        for name, img, (crops, faces) in zip(names, outs, per_frame):
+            for idx, (crop, face) in enumerate(zip(crops, faces)):
+                imwrite(crop, os.path.join(result_root, 'cropped_faces', f'{name}_{idx:02d}.png'))
+                face_name = f'{name}_{idx:02d}.png' if args.suffix is None else f'{name}_{idx:02d}_{args.suffix}.png'
+                imwrite(face, os.path.join(result_root, 'restored_faces', face_name))
+            out_name = name if args.suffix is None else f'{name}_{args.suffix}'
+            imwrite(img, os.path.join(result_root, 'final_results', f'{out_name}.png'))
+        for k in totals:
+            totals[k] += vr.stats.get(k, 0)
+        vr.faces_out = None
+
+    window = max(1, int(getattr(args, 'frame_window', 32) or 32))
     frames, affs, names, grays = [], [], [], []
-    for p in mine:
+    for n_done, p in enumerate(mine, 1):
         name = os.path.splitext(os.path.basename(p))[0]
         helper.clean_all()
         helper.read_image(p)                                       # (short side below 512: enlarged, as the reference does)
@@ -166,18 +197,15 @@ def restore_whole_images(args, input_img_list, result_root, w):
         grays.append(helper.is_gray)
         affs.append(a)
         names.append(name)
-        print(f'[{len(names)}/{len(mine)}] Processing: {os.path.basename(p)}\n\tdetect {a.shape[0]} faces')
-    vr = VideoRestorer(net, device, upscale=args.upscale, batch_size=args.batch_size or 16, bg_upsampler=bg,
-                       use_parse=parser is not None, face_parse=parser)
-    outs = vr.restore(frames, affs, w=w, keep_faces=True, gray=grays)
-    for name, img, (crops, faces) in zip(names, outs, vr.faces_out):
-        for idx, (crop, face) in enumerate(zip(crops, faces)):
-            imwrite(crop, os.path.join(result_root, 'cropped_faces', f'{name}_{idx:02d}.png'))
-            face_name = f'{name}_{idx:02d}.png' if args.suffix is None else f'{name}_{idx:02d}_{args.suffix}.png'
-            imwrite(face, os.path.join(result_root, 'restored_faces', face_name))
-        out_name = name if args.suffix is None else f'{name}_{args.suffix}'
-        imwrite(img, os.path.join(result_root, 'final_results', f'{out_name}.png'))
-    print(f"{vr.stats['faces']} faces of {vr.stats['frames']} images in {vr.stats['forward_calls']} forward calls")
+        print(f'[{n_done}/{len(mine)}] Processing: {os.path.basename(p)}\n\tdetect {a.shape[0]} faces')
+        if len(frames) == window:
+            flush(frames, affs, names, grays)
+            frames, affs, names, grays = [], [], [], []
+    if frames:
+        flush(frames, affs, names, grays)
+    print(f"{totals['faces']} faces of {totals['frames']} images in {totals['forward_calls']} forward calls")
+    if failed:
+        print(f'{len(failed)} image(s) failed: {failed[:8]}{" ..." if len(failed) > 8 else ""}')
     print(f'\nAll results are saved in {result_root}')
     return 0
 

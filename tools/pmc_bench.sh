@@ -28,7 +28,14 @@ for k, d in agg.items():
     out[k] = {c: {'launches': len(v), 'mean': sum(v) / len(v), 'sum': sum(v)} for c, v in d.items()}
     if dur[k]:
         out[k]['mean_duration_ns'] = sum(dur[k]) / len(dur[k])
+# stamp the library the counters were taken from: bench.py only quotes `traffic` from a file whose build id equals the loaded library's
+import ctypes, os
+lib = ctypes.CDLL(os.path.join('codeformer_amd', 'libcodeformer_hip.so'))
+lib.cf_build_id.restype = ctypes.c_char_p
+out['_meta'] = {'cf_build_id': lib.cf_build_id().decode(), 'command': 'bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-exact-leg'}
 json.dump(out, open(f'gpurun_out/pmc_bench_{tag}.json', 'w'), indent=1, sort_keys=True)
 for k, d in out.items():
+    if k == '_meta':
+        continue
     print(k, {c: (round(v['mean'], 1) if isinstance(v, dict) else round(v)) for c, v in d.items()})
 PY

@@ -3,7 +3,7 @@
 // The arithmetic is that of winograd_kernel<., H2 = true> (cf_winograd.hip): the 16 transform-domain GEMMs
 //   M[xi,nu][tile][n] = sum_c V[xi,nu][tile][c] * U[xi,nu][c][n]
 // run on v_mfma_f32_32x32x16_f16 with U and V as hi + lo IEEE halves (hi*hi + lo*hi + hi*lo, fp32 accumulation; U pre-split and
-// scaled by a power of two at pack time, V split when a lane reads its A fragment), i.e. 4/9 of the MFMA work of the direct
+// scaled by a power of two at pack time, V split ONCE by the input transform, which writes it to LDS in operand format), i.e. 4/9 of the MFMA work of the direct
 // split-half kernel (cf_split.hip) at its accuracy -- measured against fp64 it is the most accurate of the three 3x3 kernels.
 //
 // With the matrix work cut to 3 x 8-pass MFMAs per 16-channel slab and MFMA tile, the four-wave form is bound by everything
@@ -23,9 +23,9 @@
 // cf_winograd.hip, one 64-channel half per four-wave group.
 //
 // OP = CF_OPERAND_F16 / CF_OPERAND_BF16 (precision 'fp16' / 'bf16' of the network: BASELINE configs 3 and 5): the same kernel with
-// SINGLE 16-bit operands -- U rounded once at pack time (the hi slot of the same fragment layout), V rounded when a lane reads its
-// fragment, one MFMA per transform-domain product instead of three, half the weight-fragment registers and L2 traffic, no lo
-// conversion.  fp32 tensors, transform, accumulation and epilogue are unchanged.
+// SINGLE 16-bit operands -- U rounded once at pack time (the hi slot of the same fragment layout), V rounded by the transform, one
+// MFMA per transform-domain product instead of three, half the weight-fragment registers and L2 traffic, no lo conversion.  fp32
+// tensors, transform arithmetic, accumulation and epilogue are unchanged.
 #include <type_traits>
 
 #include "cf_common.h"
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void wsplit_kernel(const WsArgs a) {
   const float t_s = t_xi == 1 ? 1.f : -1.f;
   const int t_off_q = ((2 * (t_tile >> 3) + t_q) * WS_PW + 2 * (t_tile & 7)) * CF_LDK + t_c4 * 4;
   const int t_off_p = ((2 * (t_tile >> 3) + t_p) * WS_PW + 2 * (t_tile & 7)) * CF_LDK + t_c4 * 4;
-  const int t_off_v = t_xi * 4 * WS_PS + t_tile * CF_LDK + t_c4 * 4;
+  const int t_off_v = t_xi * 4 * WS_PS + t_tile * CF_LDK + t_c4 * 2;  // (floats) this item's two words of the row's hi half; lo: + 8
   auto transform = [&](const float* patch, float* V) __attribute__((always_inline)) {
     f32x4 t[4];
 #pragma unroll
@@ -201,11 +201,30 @@ __global__ __launch_bounds__(WS_THREADS, 1) void wsplit_kernel(const WsArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) t[c][e] = __fmaf_rn(dp[e], t_s, dq[e]);
     }
+    // (.) B along columns, then the operand conversion -- ONCE per element, here: V rows hold the slab's 16 channels as
+    // [hi: 16 halves | lo: 16 halves] (the 64 bytes the fp32 values took), so a lane's A fragment is two 16-byte reads and the two
+    // channel-half waves that share it convert nothing (48 of the 161 VALU instructions of their slab loop went there).  Single-operand
+    // modes: the rounded value in the hi slot.
+    const f32x4 v4[4] = {t[0] - t[2], t[1] + t[2], t[2] - t[1], t[1] - t[3]};
+    typedef float ws_f32x2 __attribute__((ext_vector_type(2)));
     float* vo = V + t_off_v;
-    *reinterpret_cast<f32x4*>(vo + 0 * WS_PS) = t[0] - t[2];
-    *reinterpret_cast<f32x4*>(vo + 1 * WS_PS) = t[1] + t[2];
-    *reinterpret_cast<f32x4*>(vo + 2 * WS_PS) = t[2] - t[1];
-    *reinterpret_cast<f32x4*>(vo + 3 * WS_PS) = t[1] - t[3];
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) {
+      if constexpr (OP == CF_OPERAND_F16X2) {
+        float h0, l0, h1, l1;
+        cf_split_pair(v4[nu][0], v4[nu][1], h0, l0);
+        cf_split_pair(v4[nu][2], v4[nu][3], h1, l1);
+        *reinterpret_cast<ws_f32x2*>(vo + nu * WS_PS) = ws_f32x2{h0, h1};
+        *reinterpret_cast<ws_f32x2*>(vo + nu * WS_PS + 8) = ws_f32x2{l0, l1};
+      } else if constexpr (OP == CF_OPERAND_F16) {
+        const ws_f16x2 a0 = {(_Float16)v4[nu][0], (_Float16)v4[nu][1]}, a1 = {(_Float16)v4[nu][2], (_Float16)v4[nu][3]};
+        *reinterpret_cast<ws_f32x2*>(vo + nu * WS_PS) = ws_f32x2{__builtin_bit_cast(float, a0), __builtin_bit_cast(float, a1)};
+      } else {
+        typedef __bf16 ws_bf16x2 __attribute__((ext_vector_type(2)));
+        const ws_bf16x2 a0 = {(__bf16)v4[nu][0], (__bf16)v4[nu][1]}, a1 = {(__bf16)v4[nu][2], (__bf16)v4[nu][3]};
+        *reinterpret_cast<ws_f32x2*>(vo + nu * WS_PS) = ws_f32x2{__builtin_bit_cast(float, a0), __builtin_bit_cast(float, a1)};
+      }
+    }
   };
 
   // ---- MFMA stage: wave (xi, nh) owns positions (xi, 0..3) x 64 channels ----
@@ -226,30 +245,18 @@ __global__ __launch_bounds__(WS_THREADS, 1) void wsplit_kernel(const WsArgs a) {
 #pragma unroll
       for (int part = 0; part < NPART; ++part) bq[nu][ni][part] = *reinterpret_cast<const f32x4*>(wc + ni * 512 + part * 256);
   };
-  const int a_off = (xi * 4) * WS_PS + l31 * CF_LDK + half * 8;
-  // A fragments: this lane's 8 channels of the slab (row = tile l31, channels half*8 .. +7) of position (xi, nu); the reads for
-  // position nu + 1 are issued before the conversion + MFMAs of nu (the LDS latency of a position was exposed four times per slab)
-  f32x4 va[2][2];
+  const int a_off = (xi * 4) * WS_PS + l31 * CF_LDK + half * 4;
+  // A fragments: this lane's 8 channels of the slab (row = tile l31, channels half*8 .. +7) of position (xi, nu), already in operand
+  // format: [0] = the 8 hi halves (or the single rounded operand), [1] = the 8 lo halves; the reads for position nu + 1 are issued
+  // before the MFMAs of nu (the LDS latency of a position was exposed four times per slab)
+  f32x4 va[2][NPART];
   auto read_A = [&](const float* V, int nu) __attribute__((always_inline)) {
     va[nu & 1][0] = *reinterpret_cast<const f32x4*>(V + a_off + nu * WS_PS);
-    va[nu & 1][1] = *reinterpret_cast<const f32x4*>(V + a_off + nu * WS_PS + 4);
+    if constexpr (NPART == 2) va[nu & 1][1] = *reinterpret_cast<const f32x4*>(V + a_off + nu * WS_PS + 8);
   };
   auto mma = [&](int nu) __attribute__((always_inline)) {
-    const f32x4 v0 = va[nu & 1][0], v1 = va[nu & 1][1];
-    if constexpr (OP != CF_OPERAND_F16X2) {  // single 16-bit operands: round to nearest even, one MFMA per product
-      f32x4 as;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float x0 = e < 2 ? v0[2 * e] : v1[2 * e - 4], x1 = e < 2 ? v0[2 * e + 1] : v1[2 * e - 3];
-        if constexpr (OP == CF_OPERAND_F16) {
-          const ws_f16x2 h = {(_Float16)x0, (_Float16)x1};
-          as[e] = __builtin_bit_cast(float, h);
-        } else {
-          typedef __bf16 ws_bf16x2 __attribute__((ext_vector_type(2)));
-          const ws_bf16x2 h = {(__bf16)x0, (__bf16)x1};
-          as[e] = __builtin_bit_cast(float, h);
-        }
-      }
+    if constexpr (OP != CF_OPERAND_F16X2) {  // single 16-bit operands: one MFMA per product
+      const f32x4 as = va[nu & 1][0];
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         if constexpr (OP == CF_OPERAND_F16) {
@@ -263,15 +270,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void wsplit_kernel(const WsArgs a) {
       }
       return;
     } else {
-      f32x4 ah, al;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float x0 = e < 2 ? v0[2 * e] : v1[2 * e - 4], x1 = e < 2 ? v0[2 * e + 1] : v1[2 * e - 3];
-        float hh, ll;
-        cf_split_pair(x0, x1, hh, ll);
-        ah[e] = hh;
-        al[e] = ll;
-      }
+      const f32x4 ah = va[nu & 1][0], al = va[nu & 1][NPART - 1];
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
 #if WS_ABLATE & 1

@@ -57,3 +57,25 @@ def test_upsampler_flags_are_accepted_on_the_aligned_path(tmp_path):
                         '--face_upsample'], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
     assert r.returncode == 0, r.stdout + r.stderr
     assert os.listdir(tmp_path / 'o' / 'restored_faces') == ['a.png'] and 'upsampler' in r.stdout
+
+
+def test_operand_range_host_rules():
+    """Host-side range rules of the 16-bit-operand kernels (ops.gn_range_ok / exact_code) and the determinism of the range variants."""
+    import torch
+    from codeformer_amd import ops
+    from oracle.synth import range_variant
+    assert ops.gn_range_ok(1.2, 0.3, 4 * 512 * 512)            # reference-like gains on the largest layer: fine
+    assert not ops.gn_range_ok(20.0, 0.0, 4 * 512 * 512)       # 20 * 1024 > 16376
+    assert ops.gn_range_ok(20.0, 0.0, 16 * 16 * 16)            # ... but fine on a 16x16 latent (sqrt(n) = 64)
+    assert ops.exact_code(ops.SPLIT) == ops.WINOGRAD and ops.exact_code(ops.SPLIT_DIRECT) == 0 and ops.exact_code(2) == ops.WINOGRAD
+    assert ops.exact_code(1) == 1 and ops.exact_code(0) == 0 and ops.exact_code(ops.WINOGRAD) == ops.WINOGRAD
+    sd = {'generator.blocks.5.conv2.weight': torch.ones(4, 4, 3, 3), 'generator.blocks.5.conv2.bias': torch.ones(4),
+          'generator.blocks.5.norm1.weight': torch.ones(4), 'fuse_convs_dict.32.scale.2.weight': torch.ones(4, 4, 3, 3),
+          'fuse_convs_dict.32.scale.2.bias': torch.ones(4), 'fuse_convs_dict.32.encode_enc.conv2.weight': torch.ones(4, 4, 3, 3)}
+    big = range_variant(sd, 'big', calib={'fuse_convs_dict.32.scale.2.weight': 8.0})
+    assert float(big['generator.blocks.5.conv2.weight'][0, 0, 0, 0]) == 64.0 and float(big['generator.blocks.5.norm1.weight'][0]) == 1.0
+    assert float(big['fuse_convs_dict.32.scale.2.weight'][0, 0, 0, 0]) == 0.125 and float(big['fuse_convs_dict.32.scale.2.bias'][0]) == 1.0
+    small = range_variant(sd, 'small')
+    assert float(small['generator.blocks.5.conv2.bias'][0]) == 1.0 / 4096.0
+    h1, h2 = range_variant(sd, 'heavy'), range_variant(sd, 'heavy')
+    assert all(torch.equal(h1[k], h2[k]) for k in sd)

@@ -130,29 +130,44 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
 }
 
 // ---- per-image range scale for the 16-bit-operand convolutions (cf_conv_desc.act_scale) ----------------------------------------
-// One workgroup per image: A = a rigorous upper bound of max |x| (MODE 0: sqrt of the largest statistics partial sumsq; MODE 1: the
-// exact maximum of the tensor), then s = 2^k with growth * A * s in [2^13, 2^14).  max is order-independent: bitwise reproducible.
+// Two steps, both order-independent maxima (bitwise reproducible): ACT_CHUNKS workgroups per image reduce their share of the source
+// -- MODE 0: sqrt of the largest statistics partial sumsq, a rigorous upper bound of max |x|; MODE 1: the exact maximum of the tensor --
+// to one float each, then one wave per image turns the ACT_CHUNKS maxima into s = 2^k with growth * A * s in [2^13, 2^14).  (A single
+// workgroup per image needed 37 us for the 1 MB of partials a 128-channel 256x256 layer writes per image.)
+constexpr int ACT_CHUNKS = 32;
+
 template <int MODE>
-__global__ __launch_bounds__(256) void act_scale_kernel(const void* __restrict__ src, long n, float growth, float* __restrict__ act) {
+__global__ __launch_bounds__(256) void act_amax_kernel(const void* __restrict__ src, long n, float* __restrict__ chunk_max) {
   __shared__ float red[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.x;
+  const int b = blockIdx.y, ch = blockIdx.x;
+  const long per = (n + ACT_CHUNKS - 1) / ACT_CHUNKS;   // elements (MODE 0: partials; MODE 1: float4 groups) of this chunk
+  const long lo = ch * per, hi = lo + per < n ? lo + per : n;
   float m = 0.f;
   bool bad = false;
   if (MODE == 0) {
     const double2* p = reinterpret_cast<const double2*>(src) + (size_t)b * n;
-    double q = 0;
-    for (long j = tid; j < n; j += 256) {
-      const double v = p[j].y;
-      bad |= !(v == v) || v > 3.0e38;   // NaN / inf statistics: the image itself is not finite
-      q = v > q ? v : q;
+    double q[4] = {0, 0, 0, 0};
+    long j = lo + tid;
+    for (; j + 768 < hi; j += 1024) {   // four independent loads in flight per thread
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double v = p[j + 256 * u].y;
+        bad |= !(v == v) || v > 3.0e38;   // NaN / inf statistics: the image itself is not finite
+        q[u] = v > q[u] ? v : q[u];
+      }
     }
-    m = (float)sqrt(q) * 1.0000002f;    // (rounded up: the bound must not fall below the true maximum)
+    for (; j < hi; j += 256) {
+      const double v = p[j].y;
+      bad |= !(v == v) || v > 3.0e38;
+      q[0] = v > q[0] ? v : q[0];
+    }
+    const double qq = fmax(fmax(q[0], q[1]), fmax(q[2], q[3]));
+    m = (float)sqrt(qq) * 1.0000002f;    // (rounded up: the bound must not fall below the true maximum)
   } else {
-    const float* p = reinterpret_cast<const float*>(src) + (size_t)b * n;
-    long j = (long)tid * 4;
-    for (; j + 3 < n; j += 1024) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(p + j);
+    const f32x4* p = reinterpret_cast<const f32x4*>(src) + (size_t)b * n;
+    for (long j = lo + tid; j < hi; j += 256) {
+      const f32x4 v = p[j];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         bad |= !(v[e] == v[e]);
@@ -164,8 +179,14 @@ __global__ __launch_bounds__(256) void act_scale_kernel(const void* __restrict__
   m = cf_wave_max(m);
   if (lane == 0) red[wave] = m;
   __syncthreads();
-  if (tid == 0) {
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * growth;
+  if (tid == 0) chunk_max[b * ACT_CHUNKS + ch] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__global__ __launch_bounds__(64) void act_scale_finish_kernel(const float* __restrict__ chunk_max, float growth, float* __restrict__ act) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float m = lane < ACT_CHUNKS ? chunk_max[b * ACT_CHUNKS + lane] : 0.f;
+  m = cf_wave_max(m) * growth;
+  if (lane == 0) {
     int k = 0;
     if (m > 0.f && m < __builtin_inff()) {
       int e;
@@ -240,17 +261,19 @@ extern "C" int cf_groupnorm_stats(const float* x, int batch, int hw, int c, int 
   return CF_OK;
 }
 
-extern "C" int cf_act_scale_from_stats(const double* partial, int batch, int nper, float growth, float* act, cf_stream_t stream) {
-  CF_REQUIRE(partial && act && batch >= 1 && nper >= 1 && growth > 0.f, "cf_act_scale_from_stats: bad arguments");
-  hipLaunchKernelGGL(act_scale_kernel<0>, dim3(batch), dim3(256), 0, (hipStream_t)stream, (const void*)partial, (long)nper, growth, act);
+extern "C" int cf_act_scale_from_stats(const double* partial, int batch, int nper, float growth, float* scratch, float* act, cf_stream_t stream) {
+  CF_REQUIRE(partial && act && scratch && batch >= 1 && nper >= 1 && growth > 0.f, "cf_act_scale_from_stats: bad arguments");
+  hipLaunchKernelGGL(act_amax_kernel<0>, dim3(ACT_CHUNKS, batch), dim3(256), 0, (hipStream_t)stream, (const void*)partial, (long)nper, scratch);
+  hipLaunchKernelGGL(act_scale_finish_kernel, dim3(batch), dim3(64), 0, (hipStream_t)stream, (const float*)scratch, growth, act);
   CF_CHECK_LAUNCH("cf_act_scale_from_stats");
   return CF_OK;
 }
 
-extern "C" int cf_act_scale_from_tensor(const float* x, int batch, int64_t n_per_image, float growth, float* act, cf_stream_t stream) {
-  CF_REQUIRE(x && act && batch >= 1 && n_per_image >= 1 && growth > 0.f, "cf_act_scale_from_tensor: bad arguments");
+extern "C" int cf_act_scale_from_tensor(const float* x, int batch, int64_t n_per_image, float growth, float* scratch, float* act, cf_stream_t stream) {
+  CF_REQUIRE(x && act && scratch && batch >= 1 && n_per_image >= 1 && growth > 0.f, "cf_act_scale_from_tensor: bad arguments");
   CF_REQUIRE(n_per_image % 4 == 0, "cf_act_scale_from_tensor: n_per_image %lld must be a multiple of 4 (16-byte loads)", (long long)n_per_image);
-  hipLaunchKernelGGL(act_scale_kernel<1>, dim3(batch), dim3(256), 0, (hipStream_t)stream, (const void*)x, (long)n_per_image, growth, act);
+  hipLaunchKernelGGL(act_amax_kernel<1>, dim3(ACT_CHUNKS, batch), dim3(256), 0, (hipStream_t)stream, (const void*)x, (long)(n_per_image / 4), scratch);
+  hipLaunchKernelGGL(act_scale_finish_kernel, dim3(batch), dim3(64), 0, (hipStream_t)stream, (const float*)scratch, growth, act);
   CF_CHECK_LAUNCH("cf_act_scale_from_tensor");
   return CF_OK;
 }

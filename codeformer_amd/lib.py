@@ -69,8 +69,8 @@ SIGNATURES = {
     'cf_pack_conv_weight_up2x_f16': (_I, [_P, _I, _I, _I, _I, _P, _P]),
     'cf_pack_conv_weight_f16x2': (_I, [_P, _I, _I, _I, _I, _I, _F, _P, _P]),
     'cf_groupnorm_stats': (_I, [_P, _I, _I, _I, _I, _P, _I, _P]),
-    'cf_act_scale_from_stats': (_I, [_P, _I, _I, _F, _P, _P]),
-    'cf_act_scale_from_tensor': (_I, [_P, _I, _L, _F, _P, _P]),
+    'cf_act_scale_from_stats': (_I, [_P, _I, _I, _F, _P, _P, _P]),
+    'cf_act_scale_from_tensor': (_I, [_P, _I, _L, _F, _P, _P, _P]),
     'cf_groupnorm_finalize': (_I, [_P, _I, _I, _I, _I, _I, _L, _P, _P, _F, _P, _P, _I, _P]),
     'cf_layernorm': (_I, [_P, _I, _I, _P, _P, _F, _P, _I, _P, _P, _P]),
     'cf_attention': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P]),

@@ -144,15 +144,16 @@ def act_scale(x, growth=4.0):
     lib = L.load()
     B = x.shape[0]
     act = torch.empty(B, 2, dtype=torch.float32, device=x.device)
+    scratch = torch.empty(B * 32, dtype=torch.float32, device=x.device)   # 32 partial maxima per image (see cf_act_scale_from_stats)
     st = getattr(x, '_cf_stats', None)
     if st is not None:
         nper = st.part.numel() // (2 * B)
-        L.check(lib.cf_act_scale_from_stats(L.ptr(st.part, dtype=torch.float64), B, nper, float(growth), L.ptr(act), L.stream_ptr()),
+        L.check(lib.cf_act_scale_from_stats(L.ptr(st.part, dtype=torch.float64), B, nper, float(growth), L.ptr(scratch), L.ptr(act), L.stream_ptr()),
                 'cf_act_scale_from_stats')
     else:
         if not x.is_contiguous() or (x.numel() // B) % 4:
             raise ValueError('act_scale: expected a dense tensor with a multiple of 4 elements per image')
-        L.check(lib.cf_act_scale_from_tensor(L.ptr(_f32(x)), B, x.numel() // B, float(growth), L.ptr(act), L.stream_ptr()),
+        L.check(lib.cf_act_scale_from_tensor(L.ptr(_f32(x)), B, x.numel() // B, float(growth), L.ptr(scratch), L.ptr(act), L.stream_ptr()),
                 'cf_act_scale_from_tensor')
     x._cf_act = act
     return act

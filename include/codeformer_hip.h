@@ -239,9 +239,10 @@ int cf_groupnorm_stats(const float* x, int batch, int hw, int c, int cpg, double
  *              (each partial covers at most a few hundred elements, so it is loose by at most ~5 bits: harmless, the split operands
  *              keep 22 bits over 18 binades) that costs no pass over the tensor: the partials are the ones cf_conv_desc.stats_out
  *              of the PRODUCING launch wrote, layout [batch][nper][2] doubles.
- * from_tensor: A_b = max |x| exactly, one pass over x [batch][n_per_image] (small tensors: the 16x16 quantised feature). */
-int cf_act_scale_from_stats(const double* partial, int batch, int nper, float growth, float* act, cf_stream_t stream);
-int cf_act_scale_from_tensor(const float* x, int batch, int64_t n_per_image, float growth, float* act, cf_stream_t stream);
+ * from_tensor: A_b = max |x| exactly, one pass over x [batch][n_per_image] (small tensors: the 16x16 quantised feature).
+ * scratch: batch * 32 floats (32 partial maxima per image: the reduction runs on 32 workgroups per image, then one wave per image). */
+int cf_act_scale_from_stats(const double* partial, int batch, int nper, float growth, float* scratch, float* act, cf_stream_t stream);
+int cf_act_scale_from_tensor(const float* x, int batch, int64_t n_per_image, float growth, float* scratch, float* act, cf_stream_t stream);
 int cf_groupnorm_finalize(const double* partial, int batch, int parts, int c, int cpg, int gmerge, int64_t count,
                           const float* gamma, const float* beta, float eps, float* scale, float* shift, int ld,
                           cf_stream_t stream);

@@ -109,7 +109,7 @@ __device__ __forceinline__ f32x4 v4sub(f32x4 a, f32x4 b) { return a - b; }
 // register accumulator spilled into the main loop (+36 %).
 // H2 = true ("split halves", the scheme of cf_split.hip in the Winograd domain): the 16 GEMMs run on v_mfma_f32_32x32x16_f16 with both
 // operands as hi + lo IEEE halves -- U pre-split at pack time (scaled by a power of two so that the lo halves stay normal), V split
-// when a wave reads its A fragment (each element of V is read by exactly one lane, so nothing is converted twice) -- and
+// once by the input transform, which writes it to LDS in operand format -- and
 // hi*hi + lo*hi + hi*lo accumulated in fp32: 3 MFMAs of 8 passes per 16-channel slab and MFMA tile instead of 8 of 16 passes.
 // Gather, transform, epilogue and the split-K protocol are shared with the fp32 form.
 typedef _Float16 wg_f16x8 __attribute__((ext_vector_type(8)));
@@ -258,11 +258,28 @@ __global__ __launch_bounds__(256, 2) void winograd_kernel(const std::conditional
         for (int e = 0; e < 4; ++e) t[c][e] = __fmaf_rn(db[e], sb, da[e] * sa);
       }
       // (.) B along columns: nu0 = t0 - t2, nu1 = t1 + t2, nu2 = t2 - t1, nu3 = t1 - t3
-      float* vo = V + t_xi * 4 * WG_PS + t_tile * CF_LDK + t_c4 * 4;  // position (xi, nu = 0)
-      *reinterpret_cast<f32x4*>(vo + 0 * WG_PS) = v4sub(t[0], t[2]);
-      *reinterpret_cast<f32x4*>(vo + 1 * WG_PS) = v4add(t[1], t[2]);
-      *reinterpret_cast<f32x4*>(vo + 2 * WG_PS) = v4sub(t[2], t[1]);
-      *reinterpret_cast<f32x4*>(vo + 3 * WG_PS) = v4sub(t[1], t[3]);
+      if constexpr (H2) {
+        // operand format, written ONCE here: a V row holds the slab's 16 channels as [hi: 16 halves | lo: 16 halves] (the 64 bytes the
+        // fp32 values took); the conversion leaves the MMA stage's LDS-read -> MFMA chain for the transform phase, which the co-resident
+        // workgroup's MFMAs overlap
+        typedef float wg_f32x2 __attribute__((ext_vector_type(2)));
+        const f32x4 v4[4] = {v4sub(t[0], t[2]), v4add(t[1], t[2]), v4sub(t[2], t[1]), v4sub(t[1], t[3])};
+        float* vo = V + t_xi * 4 * WG_PS + t_tile * CF_LDK + t_c4 * 2;  // position (xi, nu = 0): this item's two words of the hi half
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+          float h0, l0, h1, l1;
+          cf_split_pair(v4[nu][0], v4[nu][1], h0, l0);
+          cf_split_pair(v4[nu][2], v4[nu][3], h1, l1);
+          *reinterpret_cast<wg_f32x2*>(vo + nu * WG_PS) = wg_f32x2{h0, h1};
+          *reinterpret_cast<wg_f32x2*>(vo + nu * WG_PS + 8) = wg_f32x2{l0, l1};
+        }
+      } else {
+        float* vo = V + t_xi * 4 * WG_PS + t_tile * CF_LDK + t_c4 * 4;  // position (xi, nu = 0)
+        *reinterpret_cast<f32x4*>(vo + 0 * WG_PS) = v4sub(t[0], t[2]);
+        *reinterpret_cast<f32x4*>(vo + 1 * WG_PS) = v4add(t[1], t[2]);
+        *reinterpret_cast<f32x4*>(vo + 2 * WG_PS) = v4sub(t[2], t[1]);
+        *reinterpret_cast<f32x4*>(vo + 3 * WG_PS) = v4sub(t[1], t[3]);
+      }
     }
   };
 
@@ -290,18 +307,9 @@ __global__ __launch_bounds__(256, 2) void winograd_kernel(const std::conditional
   };
   auto mma = [&](int nu) {
     if constexpr (H2) {
-      // this lane's 8 channels of the slab (row = tile l31, channels half*8 .. +7), split into hi / lo halves in registers
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(alane + nu * WG_PS + half * 4);  // (alane already holds half*4)
-      const f32x4 v1 = *reinterpret_cast<const f32x4*>(alane + nu * WG_PS + half * 4 + 4);
-      f32x4 ah, al;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float x0 = e < 2 ? v0[2 * e] : v1[2 * e - 4], x1 = e < 2 ? v0[2 * e + 1] : v1[2 * e - 3];
-        float hh, ll;
-      cf_split_pair(x0, x1, hh, ll);
-      ah[e] = hh;
-      al[e] = ll;
-      }
+      // this lane's 8 channels of the slab (row = tile l31, channels half*8 .. +7), already in operand format (alane holds half*4)
+      const f32x4 ah = *reinterpret_cast<const f32x4*>(alane + nu * WG_PS);      // 8 hi halves
+      const f32x4 al = *reinterpret_cast<const f32x4*>(alane + nu * WG_PS + 8);  // 8 lo halves
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         acc[nu][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wg_f16x8, al), __builtin_bit_cast(wg_f16x8, bq[nu][ni][0]),

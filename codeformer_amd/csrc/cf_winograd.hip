@@ -340,22 +340,23 @@ __global__ __launch_bounds__(256, 2) void winograd_kernel(const std::conditional
   const int e_n4 = gtid & 7;  // (the item stride is a multiple of 8: both items of a thread have the same channel quad)
   auto to_output = [&](int pass, f32x4(&o)[4]) __attribute__((always_inline)) {
     __syncthreads();
+    // staging addresses: one base per thread plus compile-time offsets (DS immediate fields) -- written with the row term inside the
+    // index expression hipcc kept thirty-odd separate addresses alive (18 / 24 spilled registers in the split-K instantiations)
+    const int wb = (xi * 2 * WG_NT + 4 * half) * WG_RLD + l31;   // R[xi][0][row = 4 half + ..][channel]
+    const int rb = (((gtid >> 3) & 1) * WG_NT + (gtid >> 4)) * WG_RLD + e_n4 * 4;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float m0 = acc[0][pass][r], m1 = acc[1][pass][r], m2 = acc[2][pass][r], m3 = acc[3][pass][r];
-      const int row = cf_acc_row(r, lane);
-      R[((xi * 2 + 0) * WG_NT + row) * WG_RLD + l31] = (m0 + m1) + m2;  // nu axis: R[xi][0] = M0 + M1 + M2
-      R[((xi * 2 + 1) * WG_NT + row) * WG_RLD + l31] = (m1 - m2) - m3;  //          R[xi][1] = M1 - M2 - M3
+      const int roff = ((r & 3) + 8 * (r >> 2)) * WG_RLD;  // (cf_acc_row without its lane term)
+      R[wb + roff] = (m0 + m1) + m2;                    // nu axis: R[xi][0] = M0 + M1 + M2
+      R[wb + WG_NT * WG_RLD + roff] = (m1 - m2) - m3;   //          R[xi][1] = M1 - M2 - M3
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int it = gtid + k * GT;
-      const int e_bb = (it >> 3) & 1, e_tile = it >> 4;
+    for (int k = 0; k < 2; ++k) {  // item (tile = gtid / 16 + 16 k, output column bb, channel quad)
       f32x4 x[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        x[q] = *reinterpret_cast<const f32x4*>(R + ((q * 2 + e_bb) * WG_NT + e_tile) * WG_RLD + e_n4 * 4);
+      for (int q = 0; q < 4; ++q) x[q] = *reinterpret_cast<const f32x4*>(R + rb + (q * 2 * WG_NT + 16 * k) * WG_RLD);
       o[k * 2 + 0] = v4add(v4add(x[0], x[1]), x[2]);  // xi axis: Y[0][bb] = R0 + R1 + R2 ; Y[1][bb] = R1 - R2 - R3
       o[k * 2 + 1] = v4sub(v4sub(x[1], x[2]), x[3]);
     }

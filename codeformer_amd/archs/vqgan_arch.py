@@ -108,7 +108,14 @@ class Downsample(HipModule):
         super().__init__()
         self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=2, padding=0)
 
-    def forward_nhwc(self, x):
+    def forward_nhwc(self, x, bf16=False):
+        # split-half operands: the stride-2 form of cf_split.hip (a 2x2 convolution of the space-to-depth view of x); the input is the
+        # un-normalised residual stream, so it carries a range scale.  The single-operand modes keep the exact kernel (as Upsample does).
+        cin, cout = self.conv.in_channels, self.conv.out_channels
+        if int(bf16) in (2, ops.SPLIT, ops.SPLIT_DIRECT) and ops.split_s2_ok(cin, cout, x.shape[1], x.shape[2]):
+            pw = self._packed(('conv', 's2'), lambda: ops.pack_weight(self.conv.weight, self.conv.bias, bf16=ops.SPLIT, stride2=True),
+                              self.conv.weight, self.conv.bias)
+            return ops.conv2d(x, pw, stride=2, emit_stats=True, act=ops.act_scale(x))
         return ops.conv2d(x, self._pw_conv('conv'), stride=2, emit_stats=True)
 
     def forward_host(self, x):
@@ -286,7 +293,7 @@ def _run_blocks_nhwc(blocks, x, taps=None, first_nchw=False, last_nchw=False, bf
         else:
             if pending is not None:
                 raise RuntimeError('GroupNorm must be followed by a conv in the block list')
-            x = blk.forward_nhwc(x, bf16=bf16) if isinstance(blk, (ResBlock, Upsample)) else blk.forward_nhwc(x)
+            x = blk.forward_nhwc(x, bf16=bf16) if isinstance(blk, (ResBlock, Upsample, Downsample)) else blk.forward_nhwc(x)
         if taps and i in taps:
             r = taps[i](x)
             if r is not None:

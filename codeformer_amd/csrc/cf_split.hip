@@ -30,6 +30,10 @@
 //     ds_read_b128 of operand fragments;
 //   * nearest-x2 + 3x3 (Upsample, vqgan_arch.py:134-138) runs in the folded sub-pixel form of cf_igemm.hip (TAPS = 4: one output
 //     parity class per workgroup, a 17x17 source patch, taps pre-summed at pack time);
+//   * 3x3 stride 2 with a zero row / column appended bottom / right (Downsample, vqgan_arch.py:117-126) also runs as TAPS = 4: the input is
+//     read as its space-to-depth view X[i][j][(p, q, c)] = x[2i + p][2j + q][c] -- two pointers (even / odd tensor rows), 2C-channel
+//     "pixels", no copy -- and the conv is the 2x2 stride-1 convolution of X with the taps scattered into 4C channels at pack time
+//     (SplitArgs.s2; 7 of the 16 tap x parity blocks are zero: 16/9 of the necessary MFMAs, still 1/3 of the fp32 pipe's time);
 //   * epilogue as in cf_igemm.hip: per-wave LDS transpose, 16-byte stores, bias / residual / SFT, fp64 GroupNorm partials.
 #include <type_traits>
 
@@ -99,6 +103,7 @@ struct SplitArgs {
   double* stats_out;
   int stats_cpg, nparts;
   int tiles_x, tiles_per_img, ntn;
+  int s2;  // TAPS == 4 only: the stride-2 form (see the header comment): one weight class, tiles on the output grid, row-pair addressing
 };
 
 template <int TAPS, int NI, int WM>
@@ -156,12 +161,17 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 ? SP_NARROW_OCC : 2) :
   const int b = mt / a.tiles_per_img;
   int rt = mt - b * a.tiles_per_img;
   int sub_y = 0, sub_x = 0;  // TAPS == 4: output parity class of this workgroup; y0 / x0 are SOURCE coordinates
+  const bool s2 = TAPS == 4 && a.s2;
   if (TAPS == 4) {
-    const int src_tiles = a.tiles_per_img >> 2;
-    const int cls = rt / src_tiles;
-    rt -= cls * src_tiles;
-    sub_y = cls >> 1;
-    sub_x = cls & 1;
+    if (s2) {
+      sub_y = sub_x = 1;  // patch rows y0 .. y0 + TH, columns x0 .. x0 + 16: the geometry of parity class (1, 1)
+    } else {
+      const int src_tiles = a.tiles_per_img >> 2;
+      const int cls = rt / src_tiles;
+      rt -= cls * src_tiles;
+      sub_y = cls >> 1;
+      sub_x = cls & 1;
+    }
   }
   const int tyw = rt / a.tiles_x;
   const int y0 = tyw * C::TH;
@@ -180,7 +190,8 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 ? SP_NARROW_OCC : 2) :
       const int hx = p - hy * C::HW;
       const int iy = y0 - 1 + (TAPS == 4 ? sub_y : 0) + hy;
       const int ix = x0 - 1 + (TAPS == 4 ? sub_x : 0) + hx;
-      if (iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win) v = (b * a.hin + iy) * a.win + ix;
+      // (stride-2 form: a "pixel" is the 2C-channel pair (2 ix, 2 ix + 1) of tensor row 2 iy [in0] or 2 iy + 1 [in1 = in0 + one row])
+      if (iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win) v = s2 ? (b * a.hin + iy) * 2 * a.win + ix : (b * a.hin + iy) * a.win + ix;
       off = (hy * SP_PW + hx) * 32 + ((k8 ^ ((hx >> 1) & 7)) << 2);
     }
     pix[j] = v;
@@ -275,7 +286,7 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 ? SP_NARROW_OCC : 2) :
 
   // weight slabs: consecutive steps (slab-major, tap-minor) are consecutive [cout_pad][32] blocks of the packed tensor
   const size_t wstride = (size_t)a.cout_pad * 32;
-  const float* const wbase = a.weight + (TAPS == 4 ? (size_t)(sub_y * 2 + sub_x) * a.nchunks * TAPS * wstride : 0) + (size_t)n0 * 32;
+  const float* const wbase = a.weight + (TAPS == 4 && !s2 ? (size_t)(sub_y * 2 + sub_x) * a.nchunks * TAPS * wstride : 0) + (size_t)n0 * 32;
   int boff[C::BPT];  // LDS float offset inside a ring slot
 #pragma unroll
   for (int j = 0; j < C::BPT; ++j) {
@@ -502,7 +513,7 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 ? SP_NARROW_OCC : 2) :
       for (int p = 0; p < PASSES; ++p) {
         const int row = wm * 64 + mi * 32 + p * RPP + rl;
         unsigned pixel;
-        if (TAPS == 4)
+        if (TAPS == 4 && !s2)
           pixel = ((unsigned)b * a.hout + (2 * (y0 + (row >> 4)) + sub_y)) * a.wout + (2 * (x0 + (row & 15)) + sub_x);
         else
           pixel = ((unsigned)b * a.hout + (y0 + (row >> 4))) * a.wout + (x0 + (row & 15));
@@ -607,6 +618,7 @@ __device__ __forceinline__ float split_weight_value(const float* __restrict__ w,
   if (n >= cout || c >= cin) return 0.f;
   const float* wk = w + ((long)n * cin + c) * 9;
   if (!fold) return wk[slab];
+  if (fold == 2) return 0.f;  // (stride-2 form: handled by split_weight_value_s2)
   const int cls = slab >> 2, t2 = slab & 3;
   const int sy = cls >> 1, sx = cls & 1, ty = t2 >> 1, tx = t2 & 1;
   const int ky0 = sy == 0 ? (ty == 0 ? 0 : 1) : (ty == 0 ? 0 : 2), ky1 = sy == 0 ? (ty == 0 ? 0 : 2) : (ty == 0 ? 1 : 2);
@@ -617,7 +629,19 @@ __device__ __forceinline__ float split_weight_value(const float* __restrict__ w,
   return v;
 }
 
-// [class][cin/32][tap][cout_pad][32 words] (class = 1 plain / 4 folded): words 0..15 = hi halves of channels (2k, 2k+1), 16..31 = lo
+// Stride-2 form (Downsample: zero row / column appended bottom / right, 3x3 stride 2 -- vqgan_arch.py:117-126): the input is read as the
+// space-to-depth tensor X[i][j][(p, q, c)] = x[2i + p][2j + q][c] (4C channels, no copy: see the row-pair addressing of the gather) and
+// the convolution becomes a 2x2 stride-1 one, out[i][j] = sum_{ty,tx} W'[ty][tx] . X[i + ty][j + tx], with
+// W'[ty][tx][(p, q, c)] = w[2ty + p][2tx + q][c] where that tap exists and 0 elsewhere (7 of the 16 blocks are zero).
+__device__ __forceinline__ float split_weight_value_s2(const float* __restrict__ w, int cout, int cin, int tap, int n, int c4) {
+  if (n >= cout || c4 >= 4 * cin) return 0.f;
+  const int p = c4 / (2 * cin), q = (c4 / cin) & 1, c = c4 % cin;
+  const int ky = 2 * (tap >> 1) + p, kx = 2 * (tap & 1) + q;
+  if (ky > 2 || kx > 2) return 0.f;
+  return w[((long)n * cin + c) * 9 + ky * 3 + kx];
+}
+
+// [class][cin/32][tap][cout_pad][32 words] (class = 1 plain / 4 folded / 1 stride-2 form with 4 cin channels): words 0..15 = hi halves of channels (2k, 2k+1), 16..31 = lo
 __global__ void pack_weight_f16x2_kernel(const float* __restrict__ w, int cout, int cin, int fold, int cout_pad, int nchunks,
                                          float scale, unsigned* __restrict__ packed, long total_words) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -634,7 +658,8 @@ __global__ void pack_weight_f16x2_kernel(const float* __restrict__ w, int cout, 
   unsigned out = 0;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    const float v = split_weight_value(w, cout, cin, fold, slab, n, chunk * 32 + k2 * 2 + h) * scale;  // exact: power of two
+    const int c = chunk * 32 + k2 * 2 + h;
+    const float v = (fold == 2 ? split_weight_value_s2(w, cout, cin, tap, n, c) : split_weight_value(w, cout, cin, fold, slab, n, c)) * scale;  // exact: power of two
     const _Float16 hi = (_Float16)v;
     const _Float16 hv = part ? (_Float16)(v - (float)hi) : hi;
     out |= (unsigned)__builtin_bit_cast(unsigned short, hv) << (16 * h);
@@ -669,26 +694,34 @@ int split_launch(SplitArgs& k, int batch, hipStream_t stream) {
 extern "C" int cf_pack_conv_weight_f16x2(const float* w, int cout, int cin, int up2x, int cout_pad, int cin_pad, float scale,
                                          void* packed, cf_stream_t stream) {
   CF_REQUIRE(w && packed, "cf_pack_conv_weight_f16x2: null pointer");
-  CF_REQUIRE(cin_pad % 32 == 0 && cin_pad >= cin && cout_pad >= cout && cout_pad % 64 == 0,
+  CF_REQUIRE((up2x == 2 ? 4 * cin_pad : cin_pad) % 32 == 0 && cin_pad >= cin && cout_pad >= cout && cout_pad % 64 == 0,
              "cf_pack_conv_weight_f16x2: bad padding cin %d->%d cout %d->%d", cin, cin_pad, cout, cout_pad);
   int ex = 0;
   CF_REQUIRE(scale > 0.f && frexpf(scale, &ex) == 0.5f, "cf_pack_conv_weight_f16x2: scale %g is not a power of two", (double)scale);
+  CF_REQUIRE(up2x >= 0 && up2x <= 2, "cf_pack_conv_weight_f16x2: form %d (0 plain, 1 nearest-x2 folded, 2 stride 2)", up2x);
+  CF_REQUIRE(up2x != 2 || (cin_pad == cin && cin % 16 == 0), "cf_pack_conv_weight_f16x2: the stride-2 form needs cin %% 16 == 0, unpadded");
   const long words = (long)(up2x ? 16 : 9) * cin_pad * cout_pad;  // two halves per word, hi + lo per channel: one word per weight
   hipLaunchKernelGGL(pack_weight_f16x2_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, cout, cin,
-                     up2x ? 1 : 0, cout_pad, cin_pad / 32, scale, reinterpret_cast<unsigned*>(packed), words);
+                     up2x, cout_pad, (up2x == 2 ? 4 * cin_pad : cin_pad) / 32, scale, reinterpret_cast<unsigned*>(packed), words);
   CF_CHECK_LAUNCH("cf_pack_conv_weight_f16x2");
   return CF_OK;
 }
 
 // Called by cf_conv2d (cf_igemm.hip) for descriptors with bf16_mfma == CF_OPERAND_F16X2; the common argument checks have run.
 int cf_split_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query) {
-  CF_REQUIRE(d->taps == 9 && d->stride == 1 && !d->in_nchw && !d->out_nchw && !d->winograd,
-             "cf_conv2d: f16x2 operands cover 3x3 stride-1 NHWC convolutions (plain or nearest-x2 folded)");
-  CF_REQUIRE(d->c0 % 32 == 0 && d->c1 % 32 == 0, "cf_conv2d(f16x2): input channels (%d, %d) must be multiples of 32", d->c0, d->c1);
+  const bool s2 = d->stride == 2;
+  CF_REQUIRE(d->taps == 9 && (d->stride == 1 || s2) && !d->in_nchw && !d->out_nchw && !d->winograd,
+             "cf_conv2d: f16x2 operands cover 3x3 NHWC convolutions (stride 1 plain or nearest-x2 folded, stride 2)");
+  if (s2)
+    CF_REQUIRE(!d->upsample && d->c1 == 0 && d->c0 % 16 == 0 && d->pad_lo == 0 && d->hin % 2 == 0 && d->win % 2 == 0,
+               "cf_conv2d(f16x2): stride 2 needs one dense input with c0 %% 16 == 0 (got %d), even size, padding bottom / right", d->c0);
+  else
+    CF_REQUIRE(d->c0 % 32 == 0 && d->c1 % 32 == 0, "cf_conv2d(f16x2): input channels (%d, %d) must be multiples of 32", d->c0, d->c1);
   CF_REQUIRE(d->cout % 64 == 0 && d->cout_pad == d->cout, "cf_conv2d(f16x2): cout %d / cout_pad %d must be one multiple of 64", d->cout,
              d->cout_pad);
   constexpr int TH = SP_WM * 4;
-  CF_REQUIRE(d->hin % TH == 0 && d->win % 16 == 0, "cf_conv2d(f16x2): %dx%d input is not a multiple of the %dx16 tile", d->hin, d->win, TH);
+  const int gh = s2 ? d->hin / 2 : d->hin, gw = s2 ? d->win / 2 : d->win;  // the grid the tiles live on
+  CF_REQUIRE(gh % TH == 0 && gw % 16 == 0, "cf_conv2d(f16x2): %dx%d %s is not a multiple of the %dx16 tile", gh, gw, s2 ? "output" : "input", TH);
   CF_REQUIRE(d->epilogue == CF_EPI_NONE || d->epilogue == CF_EPI_RESIDUAL || d->epilogue == CF_EPI_SFT,
              "cf_conv2d(f16x2): epilogues are none / residual / SFT");
   CF_REQUIRE(d->pad_mode == CF_PAD_ZERO && (d->ld_in0 == 0 || d->ld_in0 == d->c0) && (d->ld_in1 == 0 || d->ld_in1 == d->c1) &&
@@ -701,11 +734,18 @@ int cf_split_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query)
   a.in1 = d->in1;
   a.c0 = d->c0;
   a.c1 = d->c1;
-  a.cin = d->c0 + d->c1;
-  a.nchunks = a.cin / SP_KC;
-  a.batch = d->batch;
   a.hin = d->hin;
   a.win = d->win;
+  a.s2 = s2 ? 1 : 0;
+  if (s2) {  // space-to-depth view: even tensor rows through in0, odd rows through in1, 2C channels (two pixels) each
+    a.in1 = d->in0 + (size_t)d->win * d->c0;
+    a.c0 = a.c1 = 2 * d->c0;
+    a.hin = gh;
+    a.win = gw;
+  }
+  a.cin = a.c0 + a.c1;
+  a.nchunks = a.cin / SP_KC;
+  a.batch = d->batch;
   a.hout = d->hout;
   a.wout = d->wout;
   a.cout = d->cout;
@@ -724,8 +764,8 @@ int cf_split_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query)
   a.out = d->out;
   a.stats_out = d->stats_out;
   a.stats_cpg = d->stats_cpg > 0 ? d->stats_cpg : 1;
-  a.tiles_x = d->win / 16;  // tiles live on the SOURCE grid (== the output grid unless upsample)
-  a.tiles_per_img = (d->upsample ? 4 : 1) * a.tiles_x * (d->hin / TH);
+  a.tiles_x = gw / 16;  // tiles live on the SOURCE grid (== the output grid unless upsample; stride 2: the space-to-depth grid)
+  a.tiles_per_img = (d->upsample ? 4 : 1) * a.tiles_x * (gh / TH);
   a.nparts = a.tiles_per_img * SP_WM;
   a.ntn = 0;
   if (parts_query) {
@@ -741,7 +781,7 @@ int cf_split_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query)
     return e ? atoi(e) : SP_NARROW_MAX_WGS;
   }();
   const bool wide = d->cout_pad % 128 == 0 && (long)a.tiles_per_img * (d->cout_pad / 128) > narrow_max_wgs;
-  if (d->upsample) return wide ? split_launch<4, 2>(a, d->batch, stream) : split_launch<4, 1>(a, d->batch, stream);
+  if (d->upsample || s2) return wide ? split_launch<4, 2>(a, d->batch, stream) : split_launch<4, 1>(a, d->batch, stream);
   return wide ? split_launch<9, 2>(a, d->batch, stream) : split_launch<9, 1>(a, d->batch, stream);
 }
 

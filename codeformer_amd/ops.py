@@ -42,11 +42,12 @@ class PackedWeight:
     """A conv / linear weight in the kernel layout [tap][cin_pad/16][cout_pad][16] (+ bias).
     `bf16` is the operand code of cf_conv_desc.bf16_mfma: 0 / False fp32, 1 / True bf16, 2 IEEE half."""
 
-    __slots__ = ('w', 'bias', 'cout', 'cin', 'taps', 'cout_pad', 'cin_pad', 'bf16', 'up2x', 'wino', 'scale')
+    __slots__ = ('w', 'bias', 'cout', 'cin', 'taps', 'cout_pad', 'cin_pad', 'bf16', 'up2x', 'wino', 'scale', 's2')
 
-    def __init__(self, w, bias, cout, cin, taps, cout_pad, cin_pad, bf16=False, up2x=False, wino=False, scale=1.0):
+    def __init__(self, w, bias, cout, cin, taps, cout_pad, cin_pad, bf16=False, up2x=False, wino=False, scale=1.0, s2=False):
         self.w, self.bias, self.cout, self.cin, self.taps = w, bias, cout, cin, taps
         self.cout_pad, self.cin_pad, self.bf16, self.up2x, self.wino = cout_pad, cin_pad, bf16, up2x, wino
+        self.s2 = s2         # f16x2 packing in the stride-2 (space-to-depth) form: only conv2d(stride=2) takes it
         self.scale = scale   # f16x2 packing: the power of two the weights were multiplied by (cf_conv_desc.acc_scale = 1 / scale)
 
 
@@ -75,6 +76,12 @@ def split_ok(cin, cout, hin, win, c_split=None):
     """Shapes the split-half kernel covers (3x3 stride-1 dense NHWC, plain or folded upsample): 32-channel K slabs (also at a
     concat boundary), 64-wide channel tiles, whole 16x16 tiles of the conv's INPUT grid."""
     return cin % 32 == 0 and cout % 64 == 0 and hin % 16 == 0 and win % 16 == 0 and (c_split is None or c_split % 32 == 0)
+
+
+def split_s2_ok(cin, cout, hin, win):
+    """Shapes the split-half kernel covers at stride 2 (Downsample: one dense input, zero row / column bottom / right): 32-channel
+    slabs of the space-to-depth view (2 * cin % 32 == 0), 64-wide channel tiles, whole 8x16 tiles of the OUTPUT grid."""
+    return cin % 16 == 0 and cout % 64 == 0 and hin % 16 == 0 and win % 32 == 0
 
 
 def winograd_ok(cin, cout, hout, wout):
@@ -170,11 +177,12 @@ def exact_code(code):
     return {SPLIT: WINOGRAD, SPLIT_DIRECT: 0, 2: WINOGRAD}.get(code, code)
 
 
-def pack_weight(weight, bias=None, bf16=False, up2x=False, f16=False):
+def pack_weight(weight, bias=None, bf16=False, up2x=False, f16=False, stride2=False):
     """weight: (cout, cin, 3, 3) | (cout, cin, 1, 1) | (cout, cin) CUDA fp32 -> PackedWeight.
     bf16=True (3x3 only, cin % 32 == 0): bf16 operands for the v_mfma_f32_32x32x16_bf16 path of cf_conv2d.
     f16=True (3x3 only, cin % 32 == 0): IEEE-half operands (general instantiations; RRDBNet's half mode).
-    up2x=True (3x3 only): taps folded for conv2d(upsample=True) -- nearest x2 + 3x3 as four 2x2 sub-pixel convolutions."""
+    up2x=True (3x3 only): taps folded for conv2d(upsample=True) -- nearest x2 + 3x3 as four 2x2 sub-pixel convolutions.
+    stride2=True (code SPLIT only): the stride-2 form of the split-half kernel -- a 2x2 convolution of the space-to-depth input."""
     lib = L.load()
     code = 2 if f16 else int(bf16)   # callers may pass the operand code (0 fp32 / 1 bf16 / 2 f16 / 3 winograd) through `bf16`
     w = _f32(weight.detach()).contiguous()
@@ -212,16 +220,19 @@ def pack_weight(weight, bias=None, bf16=False, up2x=False, f16=False):
         L.check(getattr(lib, fn)(L.ptr(w), cout, cin, cout, cin, scale, L.ptr(packed, dtype=None), L.stream_ptr()), fn)
         operand = {WSPLIT: OPERAND_F16X2, WF16: 2, WBF16: 1}[code]
         return PackedWeight(packed, b, cout, cin, 9, cout, cin, bf16=operand, wino=True, scale=scale)
+    if stride2 and (code != SPLIT or up2x):
+        raise ValueError('stride2 packing exists for the split-half kernel (bf16=SPLIT) only')
     if code == SPLIT:
-        if w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or cin % 32 or cout % 64:
-            raise ValueError('f16x2 packing needs a 3x3 weight with cin % 32 == 0 and cout % 64 == 0')
+        if w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or cin % (16 if stride2 else 32) or cout % 64:
+            raise ValueError('f16x2 packing needs a 3x3 weight with cin % 32 == 0 (stride 2: % 16) and cout % 64 == 0')
         # power-of-two scale that puts max|w'| (folded taps: at most 4 summed) into [2^14, 2^15): lo halves stay normal
         wmax = float(w.abs().max()) * (4.0 if up2x else 1.0)
         scale = 1.0 if wmax == 0.0 or not math.isfinite(wmax) else 2.0 ** (14 - math.frexp(wmax)[1] + 1)
-        packed = torch.empty((16 if up2x else 9) * cin * cout, dtype=torch.float32, device=w.device)
-        L.check(lib.cf_pack_conv_weight_f16x2(L.ptr(w), cout, cin, int(bool(up2x)), cout, cin, scale, L.ptr(packed, dtype=None), L.stream_ptr()),
+        packed = torch.empty((16 if (up2x or stride2) else 9) * cin * cout, dtype=torch.float32, device=w.device)
+        form = 2 if stride2 else int(bool(up2x))
+        L.check(lib.cf_pack_conv_weight_f16x2(L.ptr(w), cout, cin, form, cout, cin, scale, L.ptr(packed, dtype=None), L.stream_ptr()),
                 'cf_pack_conv_weight_f16x2')
-        return PackedWeight(packed, b, cout, cin, 9, cout, cin, bf16=OPERAND_F16X2, up2x=bool(up2x), scale=scale)
+        return PackedWeight(packed, b, cout, cin, 9, cout, cin, bf16=OPERAND_F16X2, up2x=bool(up2x), scale=scale, s2=bool(stride2))
     if w.dim() == 4:
         if w.shape[2] != w.shape[3] or w.shape[2] not in (1, 3):
             raise ValueError(f'unsupported kernel size {tuple(w.shape[2:])}')
@@ -290,9 +301,13 @@ def splitk_for(pw, ho, wo, cin, batch=1):
         tiles = batch * (ho * wo // 64) * (pw.cout_pad // 64)
     else:
         return 0
+    # Workgroups a split launch may occupy (tools/sk_probe2.py, MI355X): the four-wave Winograd kernel runs two workgroups per CU, but
+    # a second round of chain + finish costs more than the shorter chain saves (16 faces: 1 workgroup per tile 73 us, 2 -> 99 us);
+    # the Linear kernel's finish outweighs its short K chain beyond 128 workgroups (8 faces, 512 -> 512: 1 -> 21 us, 2 -> 34 us).
+    cap = 256 if pw.wino else 128
     v = cin // 128
     for ns in (8, 4, 2):
-        if ns <= SPLITK_MAX and v % ns == 0 and tiles * ns <= 512:
+        if ns <= SPLITK_MAX and v % ns == 0 and tiles * ns <= cap:
             return ns
     return 1
 
@@ -339,6 +354,8 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
         raise ValueError(f'input channels {c0}+{c1} != weight cin {pw.cin}')
     if bool(upsample) != bool(pw.up2x):
         raise ValueError('conv2d(upsample=True) needs a weight packed with up2x=True (and vice versa)')
+    if bool(pw.s2) != (stride == 2 and int(pw.bf16) == OPERAND_F16X2):
+        raise ValueError('a weight packed with stride2=True serves conv2d(stride=2) only (and f16x2 operands at stride 2 need it)')
     if stride == 2:
         Ho, Wo = H // 2, W // 2
     else:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 16
+#define CF_ABI_VERSION 17
 
 typedef void* cf_stream_t; /* hipStream_t */
 
@@ -82,8 +82,9 @@ enum cf_operand {
                            (22 significant bits) and a product is hi*hi + hi*lo + lo*hi -- three v_mfma_f32_32x32x16_f16 with fp32
                            accumulation (cf_split.hip).  Weight from cf_pack_conv_weight_f16x2, acc_scale = 1 / its scale.  3x3
                            stride-1 NHWC convolutions (plain or `upsample`), channels % 32 == 0, cout % 64 == 0, 16x16-tile sizes;
-                           prologues as the fp32 kernels, epilogues none / residual / SFT, statistics supported.  The host uses it
-                           for the generator / CFT convolutions (never encoder or Transformer: code indices stay exact) */
+                           prologues as the fp32 kernels, epilogues none / residual / SFT, statistics supported.  Since ABI v17 also
+                           stride 2 (Downsample, vqgan_arch.py:117-126: pad_lo == 0, one dense input, c0 % 16 == 0, output a multiple
+                           of 8x16): a 2x2 convolution of the space-to-depth view of the input, weight packed with form 2 */
 };
 
 /* Border handling of the 3x3 gather (general instantiations; CodeFormer itself only uses zero padding) */
@@ -214,7 +215,9 @@ int cf_pack_conv_weight_f16(const float* w, int cout, int cin, int taps, int cou
 int cf_pack_conv_weight_up2x_f16(const float* w, int cout, int cin, int cout_pad, int cin_pad, void* packed,
                                  cf_stream_t stream);
 /* Split-half weights for CF_OPERAND_F16X2: [slab][cin_pad/32][cout_pad][hi 32 | lo 32] IEEE halves (4 bytes per weight, slab = 9
- * taps or, with up2x != 0, the 16 folded class x tap slabs of cf_pack_conv_weight_up2x).  Each (folded) fp32 weight is multiplied
+ * taps or, with up2x == 1, the 16 folded class x tap slabs of cf_pack_conv_weight_up2x; up2x == 2 (ABI v17) selects the STRIDE-2
+ * form for cf_conv_desc.stride == 2: 4 taps x 4*cin channels, W'[ty][tx][(p, q, c)] = w[2ty + p][2tx + q][c] or 0 -- 16 * cin *
+ * cout_pad words, cin % 16 == 0, cin_pad == cin).  Each (folded) fp32 weight is multiplied
  * by `scale` -- a power of two, exact; choose it so that max|w*scale| lies in [2^14, 2^15) -- then hi = half(w'), lo = half(w' - hi)
  * (round-to-nearest-even).  cin_pad % 32 == 0, cout_pad % 64 == 0; cf_conv_desc.acc_scale must be 1 / scale. */
 int cf_pack_conv_weight_f16x2(const float* w, int cout, int cin, int up2x, int cout_pad, int cin_pad, float scale, void* packed,

@@ -86,8 +86,8 @@ def test_split_conv_refusals_and_overflow_is_loud(sc):
     assert float((y - x).abs().max()) <= 2e-7 * float(x.abs().max())      # identity kernel: only the 22-bit operand split is visible
     with pytest.raises(RuntimeError, match='f16x2'):
         ops.conv2d(torch.zeros(1, 20, 16, 64, device='cuda'), pw)            # 20 rows: not a whole number of 8x16 tiles
-    with pytest.raises(RuntimeError, match='f16x2'):
-        ops.conv2d(x, pw, stride=2)
+    with pytest.raises(ValueError, match='stride2'):
+        ops.conv2d(x, pw, stride=2)                                          # stride 2 has its own packed form (pack_weight(stride2=True))
     with pytest.raises(ValueError):
         ops.pack_weight(torch.zeros(64, 48, 3, 3, device='cuda'), None, bf16=ops.SPLIT)   # cin % 32
     # activations beyond the IEEE-half range (|x| > 65504) do not produce a silently wrong finite value
@@ -253,3 +253,45 @@ def test_winograd_single_16bit_operands(sc):
     pw64 = ops.pack_weight(torch.randn(64, 64, 3, 3, device='cuda') * 0.05, None, bf16=ops.WF16)
     with pytest.raises(RuntimeError):
         ops.conv2d(torch.zeros(1, 32, 32, 64, device='cuda'), pw64)
+
+
+def test_split_conv_stride2_against_fp64_and_the_exact_kernel(sc):
+    """Downsample (vqgan_arch.py:117-126: zero row / column bottom / right, 3x3 stride 2) on split halves: the space-to-depth 2x2 form
+    of cf_split.hip against an fp64 convolution and against the exact-fp32 kernel -- every encoder shape class (64-wide and 128-wide
+    channel tiles, a 16x16 output), large un-normalised inputs through the range scale, statistics partials, batch invariance."""
+    import torch
+    import torch.nn.functional as F
+    from codeformer_amd import ops
+    g = torch.Generator().manual_seed(1234)
+    for (B, C, H, W, mag) in ((2, 64, 64, 64, 1.0), (3, 128, 32, 64, 300.0), (2, 256, 32, 32, 1e-3), (1, 16, 16, 32, 1.0), (2, 128, 128, 128, 5e4)):
+        cout = max(C, 64) if C != 16 else 128
+        x = (torch.randn(B, H, W, C, generator=g) * mag).cuda()
+        w = (torch.randn(cout, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5).cuda()
+        b = (torch.randn(cout, generator=g) * 0.1 * mag).cuda()
+        ref = F.conv2d(F.pad(x.permute(0, 3, 1, 2).double(), (0, 1, 0, 1)), w.double(), b.double(), stride=2).permute(0, 2, 3, 1)
+        pw = ops.pack_weight(w, b, bf16=ops.SPLIT, stride2=True)
+        y = ops.conv2d(x, pw, stride=2, emit_stats=True, act=ops.act_scale(x))
+        yf = ops.conv2d(x, ops.pack_weight(w, b), stride=2, emit_stats=True)
+        rmax = float(ref.abs().max())
+        es, ef = float((y.double() - ref).abs().max()), float((yf.double() - ref).abs().max())
+        assert es <= 2e-5 * mag + 1e-5 * rmax and es <= 5.0 * ef + 1e-7 * rmax, (B, C, H, W, es, ef, rmax)
+        # the epilogue's GroupNorm partials describe the tensor that was written
+        if cout // 32 >= 2:
+            sc_, sh_ = ops.groupnorm_tables([y], torch.ones(cout, device='cuda'), torch.zeros(cout, device='cuda'))
+            yn = y.double().view(B, -1, 32, cout // 32)
+            mean = yn.mean(dim=(1, 3))
+            rstd = 1.0 / torch.sqrt(yn.var(dim=(1, 3), unbiased=False) + 1e-6)
+            assert float((sc_.double().view(B, 32, -1)[:, :, 0] - rstd).abs().max() / rstd.abs().max()) <= 1e-5
+            assert float((sh_.double().view(B, 32, -1)[:, :, 0] + mean * rstd).abs().max()) <= 1e-4 * max(1.0, float((mean * rstd).abs().max()))
+        # bitwise: repeatable, and an image alone equals the image inside the batch
+        y2 = ops.conv2d(x, pw, stride=2, emit_stats=True, act=ops.act_scale(x))
+        assert torch.equal(y, y2) and torch.equal(y._cf_stats.part, y2._cf_stats.part)
+        x1 = x[B - 1:B].contiguous()
+        y1 = ops.conv2d(x1, pw, stride=2, emit_stats=True, act=ops.act_scale(x1))
+        assert torch.equal(y[B - 1:B], y1)
+    # refusals: the stride-2 form and the stride-2 descriptor belong together
+    pw9 = ops.pack_weight(w, b, bf16=ops.SPLIT)
+    with pytest.raises(ValueError):
+        ops.conv2d(x, pw9, stride=2)
+    with pytest.raises(ValueError):
+        ops.conv2d(x, pw)

@@ -141,6 +141,7 @@ def roofline_leg(net, x, w):
         'conv3x3_s2': ('igemm_kernel<9,2,...> (3x3 stride 2, fp32 MFMA)', 1.0, FP32_MFMA_PEAK_TFLOPS, ('igemm_kernel<9, 2',)),
         'conv3x3_s2_f16x2': ('split_conv_kernel<4,...> (3x3 stride 2 as a 2x2 convolution of the space-to-depth input, split halves: 16 of which 9 tap blocks are non-zero)', 3.0 * 16.0 / 9.0, F16_MFMA_PEAK_TFLOPS, ('split_conv_kernel<4',)),
         'gemm1x1': ('igemm_kernel<1,1,...> (1x1 conv / Linear, fp32 MFMA)', 1.0, FP32_MFMA_PEAK_TFLOPS, ('igemm_kernel<1, 1',)),
+        'gemm1x1_f16x2': ('split_conv_kernel<1,...> (1x1 skip convolutions on images of more than 1024 pixels, split halves: read-once / write-once streaming)', 0.0, HBM_PEAK_GBS, ('split_conv_kernel<1',)),
     }
 
     def entry(kind):
@@ -230,7 +231,7 @@ def main():
     ap.add_argument('--batch-per-gpu', type=int, default=16)
     ap.add_argument('--w', type=float, default=0.5)
     ap.add_argument('--precision', choices=['fp32', 'f16x2', 'bf16', 'fp16'], default='f16x2',
-                    help="operand format of the 3x3 stride-1 convolutions (Transformer, 1x1 / stride-2 convs, statistics and the code argmax are "
+                    help="operand format of the convolutions (Transformer, small 1x1 layers, statistics and the code argmax are "
                          "exact fp32 in every mode): f16x2 = fp32 operands split into hi+lo IEEE halves, fp32-grade accuracy, encoder included "
                          "(default); fp32 = exact fp32 MFMA everywhere; bf16 / fp16 = single 16-bit operands in generator + CFT (BASELINE configs "
                          "3/5), encoder on split halves")
@@ -299,9 +300,9 @@ def main():
             'metric': 'aligned 512x512 faces/sec (whole node) at w=0.5', 'value': round(faces_per_s, 2), 'unit': 'faces/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': {'fp32': 'f32', 'f16x2': 'f32 (tensors, accumulation, Transformer / 1x1 / stride-2 convs / argmax on exact fp32 MFMA; 3x3 stride-1 '
+            'dtype': {'fp32': 'f32', 'f16x2': 'f32 (tensors, accumulation; Transformer / token-sized 1x1 / argmax on exact fp32 MFMA; 3x3 (stride 1, 2) and image-sized 1x1 '
                                                   'products on split operands: fp32 = hi + lo IEEE halves, 3 f16 MFMAs per product)'}.get(
-                args.precision, f'{args.precision} operands / f32 accumulate (3x3 convs of generator + CFT); encoder on split halves (hi + lo, fp32-grade); f32 (Transformer, 1x1, stride 2)'),
+                args.precision, f'{args.precision} operands / f32 accumulate (3x3 convs of generator + CFT); encoder on split halves (hi + lo, fp32-grade); f32 (Transformer, token-sized 1x1)'),
             'data': 'synthetic',
             'config': {'workload': ({'fp32': 'BASELINE config 2 (IEEE fp32 arithmetic)',
                                      'f16x2': "BASELINE config 2 shapes and tensors; 3x3 products on split-half f16 operands (fp32-grade: meets the config's "

@@ -170,11 +170,27 @@ class ResBlock(HipModule):
         h = ops.conv2d(x, self._pw_conv('conv1', code1, hw=hw, c_split=None if x2 is None else x.shape[3]), x2=x2, prologue=PRO_AFFINE_SWISH, scale=sc, shift=sh, emit_stats=True)
         sc, sh = _gn_tables(self.norm2, h)
         if self.in_channels != self.out_channels:
-            skip = ops.conv2d(x, self._pw_conv('conv_out'), x2=x2)
+            skip = self._skip_nhwc(x, x2, bf16)
         else:
             skip = x
         return ops.conv2d(h, self._pw_conv('conv2', code2, hw=hw), prologue=PRO_AFFINE_SWISH, scale=sc, shift=sh,
                           epilogue=EPI_RESIDUAL, res=skip, emit_stats=True)
+
+    def _skip_nhwc(self, x, x2, code):
+        """The 1x1 skip convolution.  With split-half operands requested and an image of more than ops.TOKEN_IMAGE_MAX pixels it streams
+        through the split-half convolution kernel (these layers are HBM-bound; the fp32 MFMA GEMM holds them at 2-4 TB/s); the input
+        is the un-normalised block input, so it carries a range scale -- one table for both halves of a concatenated input."""
+        c_split = None if x2 is None else x.shape[3]
+        if int(code) in (2, ops.SPLIT, ops.SPLIT_DIRECT) and ops.RANGE_SCALE and \
+                ops.split_1x1_ok(self.in_channels, self.out_channels, x.shape[1], x.shape[2], c_split):
+            pw = self._packed(('conv_out', 'f16x2'), lambda: ops.pack_weight(self.conv_out.weight, self.conv_out.bias, bf16=ops.SPLIT),
+                              self.conv_out.weight, self.conv_out.bias)
+            act = ops.act_scale(x)
+            if x2 is not None:
+                a2 = ops.act_scale(x2)
+                act = torch.stack((torch.minimum(act[:, 0], a2[:, 0]), torch.maximum(act[:, 1], a2[:, 1])), dim=1)
+            return ops.conv2d(x, pw, x2=x2, act=act)
+        return ops.conv2d(x, self._pw_conv('conv_out'), x2=x2)
 
     def forward_host(self, x_in):
         x = self.conv1(swish(self.norm1(x_in)))

@@ -99,6 +99,7 @@ __device__ __forceinline__ float cf_wave_sum(float v) {
 // stores -> every wave drains vmcnt -> barrier -> one lane: release fence, drained, relaxed agent-scope ticket; the last arriver: one
 // acquire fence -> barrier -> plain loads.  The counter is reset by the last arriver, so a zero-initialised counter buffer stays valid
 // launch after launch.   ws layout: [tile][V][NV][nthreads] float4;  flag: one LDS dword inside the kernel's single LDS array.
+constexpr int CF_TOKEN_IMAGE_MAX = 1024;  // 1x1 with split-half operands: larger images take the streaming convolution kernel, not the token GEMM
 constexpr int CF_SK_SLABS = 8;  // 16-channel slabs per virtual chunk (128 K values)
 
 template <int NV>

@@ -1404,12 +1404,16 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
   if (d->act_scale) {
     CF_REQUIRE(d->prologue == CF_PRO_NONE || d->prologue == CF_PRO_LEAKY,
                "cf_conv2d: act_scale is for un-normalised inputs (prologue none / leaky), got prologue %d", d->prologue);
-    CF_REQUIRE(d->taps == 9 && (d->bf16_mfma == CF_OPERAND_F32 || d->winograd || d->bf16_mfma == CF_OPERAND_F16X2),
-               "cf_conv2d: act_scale is applied by the Winograd / split-half 3x3 kernels only (operand %d, winograd %d, taps %d)",
+    const bool conv1x1_split = d->taps == 1 && d->bf16_mfma == CF_OPERAND_F16X2 && (long)d->hout * d->wout > CF_TOKEN_IMAGE_MAX;
+    CF_REQUIRE((d->taps == 9 && (d->bf16_mfma == CF_OPERAND_F32 || d->winograd || d->bf16_mfma == CF_OPERAND_F16X2)) || conv1x1_split,
+               "cf_conv2d: act_scale is applied by the Winograd / split-half convolution kernels only (operand %d, winograd %d, taps %d)",
                d->bf16_mfma, d->winograd, d->taps);
   }
-  if (d->taps == 1 && d->bf16_mfma == CF_OPERAND_F16X2) {  // token GEMM on split-half operands
+  if (d->taps == 1 && d->bf16_mfma == CF_OPERAND_F16X2) {
     CF_REQUIRE(!pq, "cf_conv2d(1x1, f16x2): no statistics epilogue");
+    // images of more than CF_TOKEN_IMAGE_MAX pixels: the streaming 1x1 form of the split-half convolution kernel (weight: form 3 of
+    // cf_pack_conv_weight_f16x2); token matrices (the Transformer's 16x16 "images"): the token GEMM (cf_pack_linear_weight_f16x2)
+    if ((long)d->hout * d->wout > CF_TOKEN_IMAGE_MAX) return cf_split_launch(d, stream, pq);
     return cf_gemm_split_launch(d, stream);
   }
   if (d->winograd) return cf_winograd_launch(d, stream, pq);  // fp32 or split-half operands

@@ -63,6 +63,9 @@
 #ifndef SP_WEAVE
 #define SP_WEAVE 1
 #endif
+#ifndef SP_S2_OCC2
+#define SP_S2_OCC2 1  // the 64-wide-tile instantiation of the stride-2 form is compiled for two workgroups per CU (at three it spills 20 registers)
+#endif
 
 namespace {
 
@@ -103,7 +106,6 @@ struct SplitArgs {
   double* stats_out;
   int stats_cpg, nparts;
   int tiles_x, tiles_per_img, ntn;
-  int s2;  // TAPS == 4 only: the stride-2 form (see the header comment): one weight class, tiles on the output grid, row-pair addressing
 };
 
 template <int TAPS, int NI, int WM>
@@ -111,8 +113,8 @@ struct SplitCfg {
   static constexpr int NT = WM * 128;
   static constexpr int BN = 2 * NI * 32;
   static constexpr int TH = WM * 4;                       // tile rows (16 columns)
-  static constexpr int HH = TAPS == 9 ? TH + 2 : TH + 1;  // halo patch rows
-  static constexpr int HW = TAPS == 9 ? 18 : 17;          // halo patch columns
+  static constexpr int HH = TAPS == 9 ? TH + 2 : TAPS == 4 ? TH + 1 : TH;  // halo patch rows (1x1: the tile itself)
+  static constexpr int HW = TAPS == 9 ? 18 : TAPS == 4 ? 17 : 16;          // halo patch columns
   static constexpr int NPIX = HH * HW;
   static constexpr int PPR = NT / 4;                      // pixels gathered per round
   static constexpr int APT = (NPIX + PPR - 1) / PPR;      // gather items (pixel, channel octet) per thread
@@ -133,8 +135,9 @@ __device__ __forceinline__ void split2(float x0, float x1, float& hi, float& lo)
   lo = __builtin_bit_cast(float, l);
 }
 
-template <int TAPS, int NI, int WM>
-__global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 ? SP_NARROW_OCC : 2) : 1) void split_conv_kernel(const SplitArgs a) {
+template <int TAPS, int NI, int WM, bool S2 = false>
+__global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 && TAPS != 1 && !(S2 && SP_S2_OCC2) ? SP_NARROW_OCC : 2) : 1) void split_conv_kernel(const SplitArgs a) {
+  static_assert(!S2 || TAPS == 4, "the stride-2 form is a 2x2 convolution");
   using C = SplitCfg<TAPS, NI, WM>;
   constexpr int MI = 2;
   constexpr int NT = C::NT;
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 ? SP_NARROW_OCC : 2) :
   const int b = mt / a.tiles_per_img;
   int rt = mt - b * a.tiles_per_img;
   int sub_y = 0, sub_x = 0;  // TAPS == 4: output parity class of this workgroup; y0 / x0 are SOURCE coordinates
-  const bool s2 = TAPS == 4 && a.s2;
+  constexpr bool s2 = S2;
   if (TAPS == 4) {
     if (s2) {
       sub_y = sub_x = 1;  // patch rows y0 .. y0 + TH, columns x0 .. x0 + 16: the geometry of parity class (1, 1)
@@ -188,8 +191,8 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 ? SP_NARROW_OCC : 2) :
     if (p < C::NPIX) {
       const int hy = p / C::HW;
       const int hx = p - hy * C::HW;
-      const int iy = y0 - 1 + (TAPS == 4 ? sub_y : 0) + hy;
-      const int ix = x0 - 1 + (TAPS == 4 ? sub_x : 0) + hx;
+      const int iy = y0 - (TAPS == 1 ? 0 : 1) + (TAPS == 4 ? sub_y : 0) + hy;
+      const int ix = x0 - (TAPS == 1 ? 0 : 1) + (TAPS == 4 ? sub_x : 0) + hx;
       // (stride-2 form: a "pixel" is the 2C-channel pair (2 ix, 2 ix + 1) of tensor row 2 iy [in0] or 2 iy + 1 [in1 = in0 + one row])
       if (iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win) v = s2 ? (b * a.hin + iy) * 2 * a.win + ix : (b * a.hin + iy) * a.win + ix;
       off = (hy * SP_PW + hx) * 32 + ((k8 ^ ((hx >> 1) & 7)) << 2);
@@ -210,16 +213,19 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 ? SP_NARROW_OCC : 2) :
   const float* const tab_sh = affine ? a.pro_shift + (size_t)b * a.cin : a.in0;
 
   // raw fp32 activations of the next slab (fetched a slab ahead), then -- converted in place -- their hi / lo halves
-  f32x4 ra[C::APT][2];
-  f32x4 rsc[2], rsh[2];
+  struct ASet {
+    f32x4 v[C::APT][2];
+    f32x4 sc[2], sh[2];
+  };
+  ASet ra;
   // Loads are issued unconditionally from clamped addresses (a load under a divergent branch is waited for on the spot);
   // out-of-image items are zeroed at conversion time.
-  auto load_A = [&](int chunk) __attribute__((always_inline)) {
+  auto load_A = [&](ASet& r, int chunk) __attribute__((always_inline)) {
     const int c = chunk * SP_KC;  // (uniform) first channel of the slab
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      rsc[u] = *reinterpret_cast<const f32x4*>(tab_sc + (affine ? c + k8 * 8 + 4 * u : 0));
-      rsh[u] = *reinterpret_cast<const f32x4*>(tab_sh + (affine ? c + k8 * 8 + 4 * u : 0));
+      r.sc[u] = *reinterpret_cast<const f32x4*>(tab_sc + (affine ? c + k8 * 8 + 4 * u : 0));
+      r.sh[u] = *reinterpret_cast<const f32x4*>(tab_sh + (affine ? c + k8 * 8 + 4 * u : 0));
     }
     const bool first = c < a.c0;  // a slab never straddles the concat boundary (c0 % 32 == 0)
     const float* src = (first ? a.in0 : a.in1) + (first ? c : c - a.c0);
@@ -229,12 +235,12 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 ? SP_NARROW_OCC : 2) :
       const unsigned pj = pix[j] < 0 ? 0u : (unsigned)pix[j];
       const float* q = src + (size_t)(pj * cs + k8 * 8);  // (element offsets fit 32 bits: tensors < 16 GiB)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) ra[j][u] = *reinterpret_cast<const f32x4*>(q + 4 * u);
+      for (int u = 0; u < 2; ++u) r.v[j][u] = *reinterpret_cast<const f32x4*>(q + 4 * u);
     }
   };
   // prologue (GroupNorm apply / swish / LeakyReLU) + split: ra[j][0] <- 8 hi halves, ra[j][1] <- 8 lo halves.
   // Zero padding stays exactly zero: it pads the conv INPUT, i.e. the post-activation tensor.
-  auto convert_mode = [&](auto mode) __attribute__((always_inline)) {
+  auto convert_mode = [&](ASet& r, auto mode) __attribute__((always_inline)) {
     constexpr int PRO = decltype(mode)::value;
 #pragma unroll
     for (int j = 0; j < C::APT; ++j) {
@@ -244,10 +250,10 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 ? SP_NARROW_OCC : 2) :
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float v = ra[j][u][e];
-          if (PRO == CF_PRO_AFFINE) v = v * rsc[u][e] + rsh[u][e];
+          float v = r.v[j][u][e];
+          if (PRO == CF_PRO_AFFINE) v = v * r.sc[u][e] + r.sh[u][e];
           if (PRO == CF_PRO_AFFINE_SWISH) {
-            v = v * rsc[u][e] + rsh[u][e];
+            v = v * r.sc[u][e] + r.sh[u][e];
             v = SP_FAST_RCP ? v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)) : v * __frcp_rn(1.0f + __expf(-v));  // hardware exp / rcp swish
           }
           if (PRO == CF_PRO_LEAKY) v = v * (v > 0.f ? act_s : act_s02);
@@ -262,24 +268,24 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 ? SP_NARROW_OCC : 2) :
         hi[h] = ph;
         lo[h] = pl;
       }
-      ra[j][0] = hi;
-      ra[j][1] = lo;
+      r.v[j][0] = hi;
+      r.v[j][1] = lo;
     }
   };
-  auto convert = [&]() __attribute__((always_inline)) {
+  auto convert = [&](ASet& r) __attribute__((always_inline)) {
     switch (a.prologue) {
-      case CF_PRO_AFFINE: convert_mode(std::integral_constant<int, CF_PRO_AFFINE>{}); break;
-      case CF_PRO_AFFINE_SWISH: convert_mode(std::integral_constant<int, CF_PRO_AFFINE_SWISH>{}); break;
-      case CF_PRO_LEAKY: convert_mode(std::integral_constant<int, CF_PRO_LEAKY>{}); break;
-      default: convert_mode(std::integral_constant<int, CF_PRO_NONE>{}); break;
+      case CF_PRO_AFFINE: convert_mode(r, std::integral_constant<int, CF_PRO_AFFINE>{}); break;
+      case CF_PRO_AFFINE_SWISH: convert_mode(r, std::integral_constant<int, CF_PRO_AFFINE_SWISH>{}); break;
+      case CF_PRO_LEAKY: convert_mode(r, std::integral_constant<int, CF_PRO_LEAKY>{}); break;
+      default: convert_mode(r, std::integral_constant<int, CF_PRO_NONE>{}); break;
     }
   };
-  auto store_A = [&]() __attribute__((always_inline)) {
+  auto store_A = [&](const ASet& r) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < C::APT; ++j) {
       if ((j + 1) * C::PPR <= C::NPIX || aoff[j] >= 0) {
-        *reinterpret_cast<f32x4*>(As + aoff[j]) = ra[j][0];
-        *reinterpret_cast<f32x4*>(As + (aoff[j] ^ 16)) = ra[j][1];  // chunk c + 4: bit 2 of the chunk index = bit 4 of the float offset
+        *reinterpret_cast<f32x4*>(As + aoff[j]) = r.v[j][0];
+        *reinterpret_cast<f32x4*>(As + (aoff[j] ^ 16)) = r.v[j][1];  // chunk c + 4: bit 2 of the chunk index = bit 4 of the float offset
       }
     }
   };
@@ -335,7 +341,7 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 ? SP_NARROW_OCC : 2) :
     f32x4 ah[MI], al[MI], bh[NI], bl[NI];
   };
   auto read_frags = [&](Frags& f, int tap, int slot, int kk) __attribute__((always_inline)) {  // kk: 16-wide K block of the slab
-    const int ty = TAPS == 4 ? (tap >> 1) : tap / 3, tx = TAPS == 4 ? (tap & 1) : tap % 3;
+    const int ty = TAPS == 4 ? (tap >> 1) : TAPS == 1 ? 0 : tap / 3, tx = TAPS == 4 ? (tap & 1) : TAPS == 1 ? 0 : tap % 3;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       f.ah[mi] = *reinterpret_cast<const f32x4*>(As + a_adr[tx][kk] + (mi * 2 + ty) * (SP_PW * 32));
@@ -387,15 +393,17 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 ? SP_NARROW_OCC : 2) :
     for (int i = 0; i < units * nsteps * SP_DESYNC / 64; ++i) __builtin_amdgcn_s_sleep(13);  // 13 x 64 cycles per iteration
   }
 #endif
-  load_A(0);
+  [[maybe_unused]] ASet rn;  // 1x1: the second activation set (slabs alternate between ra and rn, two slabs in flight)
+  load_A(ra, 0);
   load_B(0);
+  if constexpr (TAPS == 1) load_A(rn, 1 < a.nchunks ? 1 : 0);
   {
     f32x4 rb0[C::BPT];
 #pragma unroll
     for (int j = 0; j < C::BPT; ++j) rb0[j] = rb[j];
     load_B(1 < nsteps ? 1 : 0);
-    convert();
-    store_A();
+    convert(ra);
+    store_A(ra);
 #pragma unroll
     for (int j = 0; j < C::BPT; ++j) *reinterpret_cast<f32x4*>(Bs + boff[j]) = rb0[j];
     store_B(1);
@@ -406,6 +414,7 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 ? SP_NARROW_OCC : 2) :
   int slot = 0;
   int step = 0;
   constexpr int CONV_TAP = TAPS == 9 ? 4 : 2;
+  if constexpr (TAPS != 1)
   for (int chunk = 0; chunk < a.nchunks; ++chunk) {
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap, ++step) {
@@ -415,7 +424,7 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 ? SP_NARROW_OCC : 2) :
       load_B(step + 2 < nsteps ? step + 2 : nsteps - 1);  // clamped: the tail prefetches are harmless re-reads
 #endif
 #if !(SP_ABLATE & 64)
-      if (tap == 0) load_A(chunk + 1 < a.nchunks ? chunk + 1 : chunk);
+      if (tap == 0) load_A(ra, chunk + 1 < a.nchunks ? chunk + 1 : chunk);
 #endif
 #if !(SP_ABLATE & 8)
       read_frags(fy, tap, slot, 1);
@@ -427,7 +436,7 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 ? SP_NARROW_OCC : 2) :
       mma(fx);
 #endif
 #if !(SP_ABLATE & (64 | 128))
-      if (tap == CONV_TAP) convert();
+      if (tap == CONV_TAP) convert(ra);
 #endif
       if (weave) {
         // MFMA-first: frags(s, k 0..15) are in registers, so the half step opens with an MFMA and every LDS read / fetch issues in
@@ -476,7 +485,7 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 ? SP_NARROW_OCC : 2) :
 #endif
       if (tap == TAPS - 1 && chunk + 1 < a.nchunks) {
 #if !(SP_ABLATE & 64)
-        store_A();
+        store_A(ra);
         __syncthreads();
 #endif
 #if !(SP_ABLATE & 8)
@@ -484,6 +493,36 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 ? SP_NARROW_OCC : 2) :
 #endif
       }
       slot = slot1;
+    }
+  }
+  if constexpr (TAPS == 1) {
+    // 1x1 (the ResBlock skip convolutions on large images: HBM-bound streaming): one step per 32-channel slab -- 12 NI MFMAs between
+    // the patch rewrite -- so the activations of TWO slabs are in flight: slab c + 2 is requested at the top of step c into the set
+    // slab c left, slab c + 1 (requested a step ago) is converted in the shadow of step c's MFMAs and written behind its barrier.
+    auto step1 = [&](int chunk, ASet& rl, ASet& rc) __attribute__((always_inline)) {
+      const int slot1 = slot == 2 ? 0 : slot + 1;
+      const int slot2 = slot1 == 2 ? 0 : slot1 + 1;
+      load_B(chunk + 2 < nsteps ? chunk + 2 : nsteps - 1);
+      load_A(rl, chunk + 2 < a.nchunks ? chunk + 2 : a.nchunks - 1);
+      read_frags(fy, 0, slot, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(fx);
+      if (chunk + 1 < a.nchunks) convert(rc);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(fy);
+      __builtin_amdgcn_sched_barrier(0);
+      store_B(slot2);
+      __syncthreads();
+      if (chunk + 1 < a.nchunks) {
+        store_A(rc);
+        __syncthreads();
+        read_frags(fx, 0, slot1, 0);
+      }
+      slot = slot1;
+    };
+    for (int chunk = 0; chunk < a.nchunks; chunk += 2) {
+      step1(chunk, ra, rn);
+      if (chunk + 1 < a.nchunks) step1(chunk + 1, rn, ra);
     }
   }
 
@@ -617,6 +656,7 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 ? SP_NARROW_OCC : 2) :
 __device__ __forceinline__ float split_weight_value(const float* __restrict__ w, int cout, int cin, int fold, int slab, int n, int c) {
   if (n >= cout || c >= cin) return 0.f;
   const float* wk = w + ((long)n * cin + c) * 9;
+  if (fold == 3) return w[(long)n * cin + c];  // 1x1 weight [cout][cin]
   if (!fold) return wk[slab];
   if (fold == 2) return 0.f;  // (stride-2 form: handled by split_weight_value_s2)
   const int cls = slab >> 2, t2 = slab & 3;
@@ -650,7 +690,7 @@ __global__ void pack_weight_f16x2_kernel(const float* __restrict__ w, int cout, 
   long r = i >> 5;
   const int n = (int)(r % cout_pad);
   r /= cout_pad;
-  const int taps = fold ? 4 : 9;
+  const int taps = fold == 3 ? 1 : fold ? 4 : 9;
   const int tap = (int)(r % taps);
   r /= taps;
   const int chunk = (int)(r % nchunks);
@@ -667,11 +707,11 @@ __global__ void pack_weight_f16x2_kernel(const float* __restrict__ w, int cout, 
   packed[i] = out;
 }
 
-template <int TAPS, int NI>
+template <int TAPS, int NI, bool S2 = false>
 int split_launch(SplitArgs& k, int batch, hipStream_t stream) {
   using C = SplitCfg<TAPS, NI, SP_WM>;
   k.ntn = k.cout_pad / C::BN;
-  auto kern = split_conv_kernel<TAPS, NI, SP_WM>;
+  auto kern = split_conv_kernel<TAPS, NI, SP_WM, S2>;
   constexpr size_t lds = C::LDS_FLOATS * sizeof(float);
   static unsigned long long attr_devs = 0;  // bit d: the LDS attribute has been set on device d (it is a per-device property)
   int dev = 0;
@@ -698,9 +738,9 @@ extern "C" int cf_pack_conv_weight_f16x2(const float* w, int cout, int cin, int 
              "cf_pack_conv_weight_f16x2: bad padding cin %d->%d cout %d->%d", cin, cin_pad, cout, cout_pad);
   int ex = 0;
   CF_REQUIRE(scale > 0.f && frexpf(scale, &ex) == 0.5f, "cf_pack_conv_weight_f16x2: scale %g is not a power of two", (double)scale);
-  CF_REQUIRE(up2x >= 0 && up2x <= 2, "cf_pack_conv_weight_f16x2: form %d (0 plain, 1 nearest-x2 folded, 2 stride 2)", up2x);
+  CF_REQUIRE(up2x >= 0 && up2x <= 3, "cf_pack_conv_weight_f16x2: form %d (0 plain 3x3, 1 nearest-x2 folded, 2 stride 2, 3 1x1)", up2x);
   CF_REQUIRE(up2x != 2 || (cin_pad == cin && cin % 16 == 0), "cf_pack_conv_weight_f16x2: the stride-2 form needs cin %% 16 == 0, unpadded");
-  const long words = (long)(up2x ? 16 : 9) * cin_pad * cout_pad;  // two halves per word, hi + lo per channel: one word per weight
+  const long words = (long)(up2x == 3 ? 1 : up2x ? 16 : 9) * cin_pad * cout_pad;  // two halves per word, hi + lo per channel: one word per weight
   hipLaunchKernelGGL(pack_weight_f16x2_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, cout, cin,
                      up2x, cout_pad, (up2x == 2 ? 4 * cin_pad : cin_pad) / 32, scale, reinterpret_cast<unsigned*>(packed), words);
   CF_CHECK_LAUNCH("cf_pack_conv_weight_f16x2");
@@ -710,8 +750,10 @@ extern "C" int cf_pack_conv_weight_f16x2(const float* w, int cout, int cin, int 
 // Called by cf_conv2d (cf_igemm.hip) for descriptors with bf16_mfma == CF_OPERAND_F16X2; the common argument checks have run.
 int cf_split_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query) {
   const bool s2 = d->stride == 2;
-  CF_REQUIRE(d->taps == 9 && (d->stride == 1 || s2) && !d->in_nchw && !d->out_nchw && !d->winograd,
-             "cf_conv2d: f16x2 operands cover 3x3 NHWC convolutions (stride 1 plain or nearest-x2 folded, stride 2)");
+  const bool one = d->taps == 1;
+  CF_REQUIRE((d->taps == 9 || one) && (d->stride == 1 || s2) && !d->in_nchw && !d->out_nchw && !d->winograd,
+             "cf_conv2d: f16x2 operands cover 3x3 NHWC convolutions (stride 1 plain or nearest-x2 folded, stride 2) and 1x1 on images");
+  CF_REQUIRE(!one || (d->stride == 1 && !d->upsample && !d->stats_out), "cf_conv2d(f16x2): 1x1 convolutions are stride 1, no upsample, no statistics");
   if (s2)
     CF_REQUIRE(!d->upsample && d->c1 == 0 && d->c0 % 16 == 0 && d->pad_lo == 0 && d->hin % 2 == 0 && d->win % 2 == 0,
                "cf_conv2d(f16x2): stride 2 needs one dense input with c0 %% 16 == 0 (got %d), even size, padding bottom / right", d->c0);
@@ -736,7 +778,6 @@ int cf_split_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query)
   a.c1 = d->c1;
   a.hin = d->hin;
   a.win = d->win;
-  a.s2 = s2 ? 1 : 0;
   if (s2) {  // space-to-depth view: even tensor rows through in0, odd rows through in1, 2C channels (two pixels) each
     a.in1 = d->in0 + (size_t)d->win * d->c0;
     a.c0 = a.c1 = 2 * d->c0;
@@ -781,7 +822,9 @@ int cf_split_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query)
     return e ? atoi(e) : SP_NARROW_MAX_WGS;
   }();
   const bool wide = d->cout_pad % 128 == 0 && (long)a.tiles_per_img * (d->cout_pad / 128) > narrow_max_wgs;
-  if (d->upsample || s2) return wide ? split_launch<4, 2>(a, d->batch, stream) : split_launch<4, 1>(a, d->batch, stream);
+  if (s2) return wide ? split_launch<4, 2, true>(a, d->batch, stream) : split_launch<4, 1, true>(a, d->batch, stream);
+  if (one) return wide ? split_launch<1, 2>(a, d->batch, stream) : split_launch<1, 1>(a, d->batch, stream);
+  if (d->upsample) return wide ? split_launch<4, 2>(a, d->batch, stream) : split_launch<4, 1>(a, d->batch, stream);
   return wide ? split_launch<9, 2>(a, d->batch, stream) : split_launch<9, 1>(a, d->batch, stream);
 }
 

@@ -42,12 +42,13 @@ class PackedWeight:
     """A conv / linear weight in the kernel layout [tap][cin_pad/16][cout_pad][16] (+ bias).
     `bf16` is the operand code of cf_conv_desc.bf16_mfma: 0 / False fp32, 1 / True bf16, 2 IEEE half."""
 
-    __slots__ = ('w', 'bias', 'cout', 'cin', 'taps', 'cout_pad', 'cin_pad', 'bf16', 'up2x', 'wino', 'scale', 's2')
+    __slots__ = ('w', 'bias', 'cout', 'cin', 'taps', 'cout_pad', 'cin_pad', 'bf16', 'up2x', 'wino', 'scale', 's2', 'conv1')
 
-    def __init__(self, w, bias, cout, cin, taps, cout_pad, cin_pad, bf16=False, up2x=False, wino=False, scale=1.0, s2=False):
+    def __init__(self, w, bias, cout, cin, taps, cout_pad, cin_pad, bf16=False, up2x=False, wino=False, scale=1.0, s2=False, conv1=False):
         self.w, self.bias, self.cout, self.cin, self.taps = w, bias, cout, cin, taps
         self.cout_pad, self.cin_pad, self.bf16, self.up2x, self.wino = cout_pad, cin_pad, bf16, up2x, wino
         self.s2 = s2         # f16x2 packing in the stride-2 (space-to-depth) form: only conv2d(stride=2) takes it
+        self.conv1 = conv1   # f16x2 1x1 weight in the convolution kernel's layout (images of more than TOKEN_IMAGE_MAX pixels), not the token GEMM's
         self.scale = scale   # f16x2 packing: the power of two the weights were multiplied by (cf_conv_desc.acc_scale = 1 / scale)
 
 
@@ -84,6 +85,11 @@ def split_s2_ok(cin, cout, hin, win):
     return cin % 16 == 0 and cout % 64 == 0 and hin % 16 == 0 and win % 32 == 0
 
 
+def split_1x1_ok(cin, cout, h, w, c_split=None):
+    """1x1 convolutions the split-half kernel streams (ResBlock skips on images): 32-channel slabs, 64-wide channel tiles, 8x16 tiles."""
+    return cin % 32 == 0 and cout % 64 == 0 and h % 8 == 0 and w % 16 == 0 and h * w > TOKEN_IMAGE_MAX and (c_split is None or c_split % 32 == 0)
+
+
 def winograd_ok(cin, cout, hout, wout):
     """Shapes the Winograd kernel covers (3x3 stride-1 dense NHWC): whole 8x16 output patches, 64-wide channel tiles."""
     return cin % 16 == 0 and cout % 64 == 0 and hout % 8 == 0 and wout % 16 == 0
@@ -93,6 +99,7 @@ def winograd_ok(cin, cout, hout, wout):
 # SPLIT they run the four-wave Winograd kernel on split halves with split-K (conv_code -> WSPLIT: measured on the reference's crops
 # before it became the default, profiles/r02_encoder_split_check.txt), with SPLIT_DIRECT they stay on the exact fp32 kernel.
 SPLIT_MIN_PIXELS = 32 * 32
+TOKEN_IMAGE_MAX = 1024   # CF_TOKEN_IMAGE_MAX of cf_common.h: f16x2 1x1 layers on larger images run the streaming convolution kernel
 
 
 def wsingle_ok(cin, cout, h, w):
@@ -138,6 +145,8 @@ HALF_LIMIT = 65504.0 / 4.0    # largest |activation| a Winograd-domain IEEE-half
 
 def needs_act_scale(pw):
     """True when `pw` runs on a kernel with 16-bit MFMA operands that applies cf_conv_desc.act_scale."""
+    if pw.conv1:
+        return RANGE_SCALE
     return RANGE_SCALE and pw.taps == 9 and int(pw.bf16) in (1, 2, OPERAND_F16X2) and (bool(pw.wino) or int(pw.bf16) == OPERAND_F16X2)
 
 
@@ -222,6 +231,16 @@ def pack_weight(weight, bias=None, bf16=False, up2x=False, f16=False, stride2=Fa
         return PackedWeight(packed, b, cout, cin, 9, cout, cin, bf16=operand, wino=True, scale=scale)
     if stride2 and (code != SPLIT or up2x):
         raise ValueError('stride2 packing exists for the split-half kernel (bf16=SPLIT) only')
+    if code == SPLIT and (w.dim() == 2 or tuple(w.shape[2:]) == (1, 1)):
+        # 1x1 on images (the ResBlock skip convolutions): the streaming form of the split-half convolution kernel
+        if up2x or cin % 32 or cout % 64:
+            raise ValueError('f16x2 1x1 packing needs cin % 32 == 0 and cout % 64 == 0')
+        wmax = float(w.abs().max())
+        scale = 1.0 if wmax == 0.0 or not math.isfinite(wmax) else 2.0 ** (14 - math.frexp(wmax)[1] + 1)
+        packed = torch.empty(cin * cout, dtype=torch.float32, device=w.device)
+        L.check(lib.cf_pack_conv_weight_f16x2(L.ptr(w), cout, cin, 3, cout, cin, scale, L.ptr(packed, dtype=None), L.stream_ptr()),
+                'cf_pack_conv_weight_f16x2')
+        return PackedWeight(packed, b, cout, cin, 1, cout, cin, bf16=OPERAND_F16X2, scale=scale, conv1=True)
     if code == SPLIT:
         if w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or cin % (16 if stride2 else 32) or cout % 64:
             raise ValueError('f16x2 packing needs a 3x3 weight with cin % 32 == 0 (stride 2: % 16) and cout % 64 == 0')
@@ -354,6 +373,9 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
         raise ValueError(f'input channels {c0}+{c1} != weight cin {pw.cin}')
     if bool(upsample) != bool(pw.up2x):
         raise ValueError('conv2d(upsample=True) needs a weight packed with up2x=True (and vice versa)')
+    if pw.taps == 1 and int(pw.bf16) == OPERAND_F16X2 and bool(pw.conv1) != (H * W > TOKEN_IMAGE_MAX):
+        raise ValueError(f'1x1 with f16x2 operands: images of more than {TOKEN_IMAGE_MAX} pixels take a weight packed with bf16=SPLIT, '
+                         'token matrices one packed with bf16=GSPLIT')
     if bool(pw.s2) != (stride == 2 and int(pw.bf16) == OPERAND_F16X2):
         raise ValueError('a weight packed with stride2=True serves conv2d(stride=2) only (and f16x2 operands at stride 2 need it)')
     if stride == 2:

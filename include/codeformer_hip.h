@@ -217,7 +217,10 @@ int cf_pack_conv_weight_up2x_f16(const float* w, int cout, int cin, int cout_pad
 /* Split-half weights for CF_OPERAND_F16X2: [slab][cin_pad/32][cout_pad][hi 32 | lo 32] IEEE halves (4 bytes per weight, slab = 9
  * taps or, with up2x == 1, the 16 folded class x tap slabs of cf_pack_conv_weight_up2x; up2x == 2 (ABI v17) selects the STRIDE-2
  * form for cf_conv_desc.stride == 2: 4 taps x 4*cin channels, W'[ty][tx][(p, q, c)] = w[2ty + p][2tx + q][c] or 0 -- 16 * cin *
- * cout_pad words, cin % 16 == 0, cin_pad == cin).  Each (folded) fp32 weight is multiplied
+ * cout_pad words, cin % 16 == 0, cin_pad == cin); up2x == 3 (ABI v17): a 1x1 weight [cout][cin] for cf_conv_desc.taps == 1 on images of
+ * more than 1024 pixels (the streaming 1x1 form of the same kernel: the ResBlock skip convolutions, vqgan_arch.py:150-164; two-pointer
+ * concat, act_scale, epilogues none / residual / SFT, no statistics) -- token matrices of at most 1024 rows per image keep
+ * cf_pack_linear_weight_f16x2 and the token GEMM.  Each (folded) fp32 weight is multiplied
  * by `scale` -- a power of two, exact; choose it so that max|w*scale| lies in [2^14, 2^15) -- then hi = half(w'), lo = half(w' - hi)
  * (round-to-nearest-even).  cin_pad % 32 == 0, cout_pad % 64 == 0; cf_conv_desc.acc_scale must be 1 / scale. */
 int cf_pack_conv_weight_f16x2(const float* w, int cout, int cin, int up2x, int cout_pad, int cin_pad, float scale, void* packed,

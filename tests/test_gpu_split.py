@@ -295,3 +295,37 @@ def test_split_conv_stride2_against_fp64_and_the_exact_kernel(sc):
         ops.conv2d(x, pw9, stride=2)
     with pytest.raises(ValueError):
         ops.conv2d(x, pw)
+
+
+def test_split_conv_1x1_streaming_against_fp64_and_the_exact_kernel(sc):
+    """ResBlock skip convolutions (vqgan_arch.py:150-164) on images: the 1x1 form of cf_split.hip (two activation slabs in flight)
+    against fp64 and the exact-fp32 GEMM -- single and concatenated inputs, odd and even slab counts, both tile widths, un-normalised
+    magnitudes through the range scale, residual epilogue, bitwise batch invariance; token-sized images keep the token GEMM."""
+    import torch
+    from codeformer_amd import ops
+    g = torch.Generator().manual_seed(4321)
+    for (B, c0, c1, cout, H, W, mag) in ((2, 128, 0, 64, 64, 64, 1.0), (2, 128, 128, 128, 64, 48, 400.0), (1, 96, 0, 128, 40, 64, 1e-3),
+                                         (3, 32, 0, 64, 32, 64, 1.0), (2, 256, 256, 256, 32, 64, 3e4)):
+        x = (torch.randn(B, H, W, c0, generator=g) * mag).cuda()
+        x2 = (torch.randn(B, H, W, c1, generator=g) * mag * 0.1).cuda() if c1 else None
+        cin = c0 + c1
+        w = (torch.randn(cout, cin, 1, 1, generator=g) * (1.0 / cin) ** 0.5).cuda()
+        b = (torch.randn(cout, generator=g) * 0.1 * mag).cuda()
+        res = (torch.randn(B, H, W, cout, generator=g) * mag).cuda()
+        xa = x if x2 is None else torch.cat((x, x2), dim=3)
+        ref = xa.double() @ w.double().view(cout, cin).t() + b.double() + res.double()
+        pw = ops.pack_weight(w, b, bf16=ops.SPLIT)
+        assert pw.conv1 and pw.taps == 1
+        act = ops.act_scale(xa.contiguous())
+        y = ops.conv2d(x, pw, x2=x2, act=act, epilogue=ops.EPI_RESIDUAL, res=res)
+        yf = ops.conv2d(x, ops.pack_weight(w, b), x2=x2, epilogue=ops.EPI_RESIDUAL, res=res)
+        rmax = float(ref.abs().max())
+        es, ef = float((y.double() - ref).abs().max()), float((yf.double() - ref).abs().max())
+        assert es <= 2e-5 * mag + 1e-5 * rmax and es <= 5.0 * ef + 1e-7 * rmax, (c0, c1, cout, H, W, es, ef, rmax)
+        assert torch.equal(y, ops.conv2d(x, pw, x2=x2, act=act, epilogue=ops.EPI_RESIDUAL, res=res))
+        y1 = ops.conv2d(x[-1:].contiguous(), pw, x2=None if x2 is None else x2[-1:].contiguous(), act=act[-1:].contiguous(),
+                        epilogue=ops.EPI_RESIDUAL, res=res[-1:].contiguous())
+        assert torch.equal(y[-1:], y1)
+    # a token-sized image with this weight form is refused on the host (the C ABI would read it as a token-GEMM weight)
+    with pytest.raises(ValueError, match='1x1'):
+        ops.conv2d(torch.zeros(1, 16, 16, 512, device='cuda'), pw)

@@ -185,11 +185,7 @@ class ResBlock(HipModule):
                 ops.split_1x1_ok(self.in_channels, self.out_channels, x.shape[1], x.shape[2], c_split):
             pw = self._packed(('conv_out', 'f16x2'), lambda: ops.pack_weight(self.conv_out.weight, self.conv_out.bias, bf16=ops.SPLIT),
                               self.conv_out.weight, self.conv_out.bias)
-            act = ops.act_scale(x)
-            if x2 is not None:
-                a2 = ops.act_scale(x2)
-                act = torch.stack((torch.minimum(act[:, 0], a2[:, 0]), torch.maximum(act[:, 1], a2[:, 1])), dim=1)
-            return ops.conv2d(x, pw, x2=x2, act=act)
+            return ops.conv2d(x, pw, x2=x2, act=ops.act_scale(x, x2))
         return ops.conv2d(x, self._pw_conv('conv_out'), x2=x2)
 
     def forward_host(self, x_in):

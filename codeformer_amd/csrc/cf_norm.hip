@@ -261,6 +261,97 @@ extern "C" int cf_groupnorm_stats(const float* x, int batch, int hw, int c, int 
   return CF_OK;
 }
 
+// One launch: 32 workgroups per image reduce their slices of the statistics partials of up to TWO tensors (the halves of a concatenated
+// input) -- or of a tensor itself -- and meet in two zero-initialised words per image: cells[2b] takes atomic maxima of the (non-negative)
+// float bit patterns, cells[2b + 1] tickets; the workgroup drawing the last ticket turns the maximum into (s, 1 / s) and leaves both words
+// at zero for the next launch.  The ticket is drawn only after the workgroup's own maximum has RETURNED from the memory-side atomic unit,
+// so the last arriver's read sees every contribution without a cache write-back.
+__global__ __launch_bounds__(256) void act_scale_fused_kernel(const double2* __restrict__ pa, long na, const double2* __restrict__ pb, long nb,
+                                                              const f32x4* __restrict__ x, long nx, float growth, unsigned* __restrict__ cells,
+                                                              float* __restrict__ act) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y, ch = blockIdx.x;
+  float m = 0.f;
+  bool bad = false;
+  double q[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int src = 0; src < 2; ++src) {
+    const double2* p = src ? pb : pa;
+    const long n = src ? nb : na;
+    if (!p) continue;
+    p += (size_t)b * n;
+    const long per = (n + ACT_CHUNKS - 1) / ACT_CHUNKS;
+    const long lo = ch * per, hi = lo + per < n ? lo + per : n;
+    long j = lo + tid;
+    for (; j + 768 < hi; j += 1024) {  // four independent loads in flight per thread
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double v = p[j + 256 * u].y;
+        bad |= !(v == v) || v > 3.0e38;  // NaN / inf statistics: the image itself is not finite
+        q[u] = v > q[u] ? v : q[u];
+      }
+    }
+    for (; j < hi; j += 256) {
+      const double v = p[j].y;
+      bad |= !(v == v) || v > 3.0e38;
+      q[0] = v > q[0] ? v : q[0];
+    }
+  }
+  m = (float)sqrt(fmax(fmax(q[0], q[1]), fmax(q[2], q[3]))) * 1.0000002f;  // (rounded up: the bound must not fall below the true maximum)
+  if (x) {
+    const f32x4* p = x + (size_t)b * nx;
+    const long per = (nx + ACT_CHUNKS - 1) / ACT_CHUNKS;
+    const long lo = ch * per, hi = lo + per < nx ? lo + per : nx;
+    for (long j = lo + tid; j < hi; j += 256) {
+      const f32x4 v = p[j];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        bad |= !(v[e] == v[e]);
+        m = fmaxf(m, fabsf(v[e]));
+      }
+    }
+  }
+  if (bad) m = __builtin_inff();
+  m = cf_wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  if (tid == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const unsigned before = __hip_atomic_fetch_max(cells + 2 * b, __builtin_bit_cast(unsigned, m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::"v"(before) : "memory");  // the maximum has been applied before the ticket is drawn
+    const unsigned ticket = __hip_atomic_fetch_add(cells + 2 * b + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ticket == ACT_CHUNKS - 1) {
+      const unsigned bits = __hip_atomic_exchange(cells + 2 * b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(cells + 2 * b + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float mm = __builtin_bit_cast(float, bits) * growth;
+      int k = 0;
+      if (mm > 0.f && mm < __builtin_inff()) {
+        int e;
+        (void)frexpf(mm, &e);  // mm = f * 2^e, f in [0.5, 1)  ->  mm * 2^(14 - e) in [2^13, 2^14)
+        k = 14 - e;
+        k = k < -100 ? -100 : (k > 100 ? 100 : k);
+      }
+      act[2 * b] = ldexpf(1.f, k);
+      act[2 * b + 1] = ldexpf(1.f, -k);
+    }
+  }
+}
+
+extern "C" int cf_act_scale_fused(const double* partial_a, int nper_a, const double* partial_b, int nper_b, const float* x, int64_t n_per_image,
+                                  int batch, float growth, uint32_t* cells, float* act, cf_stream_t stream) {
+  CF_REQUIRE(act && cells && batch >= 1 && growth > 0.f, "cf_act_scale_fused: bad arguments");
+  CF_REQUIRE((partial_a != nullptr) != (x != nullptr), "cf_act_scale_fused: give statistics partials (one or two tensors) or a tensor, not both");
+  CF_REQUIRE(!partial_a || nper_a >= 1, "cf_act_scale_fused: nper_a");
+  CF_REQUIRE(!partial_b || (partial_a && nper_b >= 1), "cf_act_scale_fused: the second statistics array needs the first (and nper_b >= 1)");
+  CF_REQUIRE(!x || (n_per_image >= 4 && n_per_image % 4 == 0), "cf_act_scale_fused: n_per_image %lld must be a positive multiple of 4", (long long)n_per_image);
+  hipLaunchKernelGGL(act_scale_fused_kernel, dim3(ACT_CHUNKS, batch), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const double2*>(partial_a),
+                     (long)nper_a, reinterpret_cast<const double2*>(partial_b), (long)nper_b, reinterpret_cast<const f32x4*>(x), (long)(n_per_image / 4),
+                     growth, cells, act);
+  CF_CHECK_LAUNCH("cf_act_scale_fused");
+  return CF_OK;
+}
+
 extern "C" int cf_act_scale_from_stats(const double* partial, int batch, int nper, float growth, float* scratch, float* act, cf_stream_t stream) {
   CF_REQUIRE(partial && act && scratch && batch >= 1 && nper >= 1 && growth > 0.f, "cf_act_scale_from_stats: bad arguments");
   hipLaunchKernelGGL(act_amax_kernel<0>, dim3(ACT_CHUNKS, batch), dim3(256), 0, (hipStream_t)stream, (const void*)partial, (long)nper, scratch);

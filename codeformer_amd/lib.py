@@ -71,6 +71,7 @@ SIGNATURES = {
     'cf_groupnorm_stats': (_I, [_P, _I, _I, _I, _I, _P, _I, _P]),
     'cf_act_scale_from_stats': (_I, [_P, _I, _I, _F, _P, _P, _P]),
     'cf_act_scale_from_tensor': (_I, [_P, _I, _L, _F, _P, _P, _P]),
+    'cf_act_scale_fused': (_I, [_P, _I, _P, _I, _P, _L, _I, _F, _P, _P, _P]),
     'cf_groupnorm_finalize': (_I, [_P, _I, _I, _I, _I, _I, _L, _P, _P, _F, _P, _P, _I, _P]),
     'cf_layernorm': (_I, [_P, _I, _I, _P, _P, _F, _P, _I, _P, _P, _P]),
     'cf_attention': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P]),

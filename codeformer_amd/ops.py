@@ -150,28 +150,60 @@ def needs_act_scale(pw):
     return RANGE_SCALE and pw.taps == 9 and int(pw.bf16) in (1, 2, OPERAND_F16X2) and (bool(pw.wino) or int(pw.bf16) == OPERAND_F16X2)
 
 
-def act_scale(x, growth=4.0):
+_ACT_CELLS = {}
+ACT_FUSED = os.environ.get('CODEFORMER_HIP_ACT_FUSED', '1') != '0'   # 0: two launches per table (A/B only)
+
+
+def _act_cells(device, batch):
+    """2 * batch zero-initialised words per (device, stream) for cf_act_scale_fused; every launch leaves them at zero."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    t = _ACT_CELLS.get(key)
+    if t is None or t.numel() < 2 * batch:
+        t = torch.zeros(max(2 * batch, 256), dtype=torch.int32, device=device)
+        _ACT_CELLS[key] = t
+    return t
+
+
+def act_scale(x, x2=None, growth=4.0):
     """(B, 2) float32 table (s_b, 1 / s_b): power-of-two scale that puts growth * max|x_b| into [2^13, 2^14) -- from the statistics
     partials the producing conv wrote (no pass over x; the bound is loose by a few bits, which is harmless) or, for tensors without
-    them, from x itself.  Cached on the tensor (one table serves every conv that reads it)."""
-    act = getattr(x, '_cf_act', None)
-    if act is not None:
-        return act
+    them, from x itself; one launch (cf_act_scale_fused).  x2: the second half of a concatenated input -- the table then covers both.
+    Cached on the tensor (one table serves every conv that reads it; pairs are not cached)."""
+    if x2 is None:
+        act = getattr(x, '_cf_act', None)
+        if act is not None:
+            return act
     lib = L.load()
     B = x.shape[0]
     act = torch.empty(B, 2, dtype=torch.float32, device=x.device)
-    scratch = torch.empty(B * 32, dtype=torch.float32, device=x.device)   # 32 partial maxima per image (see cf_act_scale_from_stats)
+    cells = L.ptr(_act_cells(x.device, B), dtype=torch.int32)
     st = getattr(x, '_cf_stats', None)
+    st2 = None if x2 is None else getattr(x2, '_cf_stats', None)
+    if x2 is not None and (st is None or st2 is None or not ACT_FUSED):
+        # a half without statistics partials: two single tables combined on the host side of the stream (rare: every conv that feeds a
+        # concatenation writes partials)
+        a1, a2 = act_scale(x, growth=growth), act_scale(x2, growth=growth)
+        return torch.stack((torch.minimum(a1[:, 0], a2[:, 0]), torch.maximum(a1[:, 1], a2[:, 1])), dim=1)
+    if not ACT_FUSED and x2 is None:   # A/B only: the two-launch entry points of ABI v16
+        scratch = torch.empty(B * 32, dtype=torch.float32, device=x.device)
+        if st is not None:
+            L.check(lib.cf_act_scale_from_stats(L.ptr(st.part, dtype=torch.float64), B, st.part.numel() // (2 * B), float(growth), L.ptr(scratch), L.ptr(act), L.stream_ptr()), 'cf_act_scale_from_stats')
+        else:
+            L.check(lib.cf_act_scale_from_tensor(L.ptr(_f32(x)), B, x.numel() // B, float(growth), L.ptr(scratch), L.ptr(act), L.stream_ptr()), 'cf_act_scale_from_tensor')
+        x._cf_act = act
+        return act
     if st is not None:
         nper = st.part.numel() // (2 * B)
-        L.check(lib.cf_act_scale_from_stats(L.ptr(st.part, dtype=torch.float64), B, nper, float(growth), L.ptr(scratch), L.ptr(act), L.stream_ptr()),
-                'cf_act_scale_from_stats')
+        p2, n2 = (L.ptr(st2.part, dtype=torch.float64), st2.part.numel() // (2 * B)) if st2 is not None else (None, 0)
+        L.check(lib.cf_act_scale_fused(L.ptr(st.part, dtype=torch.float64), nper, p2, n2, None, 0, B, float(growth), cells, L.ptr(act), L.stream_ptr()),
+                'cf_act_scale_fused')
     else:
         if not x.is_contiguous() or (x.numel() // B) % 4:
             raise ValueError('act_scale: expected a dense tensor with a multiple of 4 elements per image')
-        L.check(lib.cf_act_scale_from_tensor(L.ptr(_f32(x)), B, x.numel() // B, float(growth), L.ptr(scratch), L.ptr(act), L.stream_ptr()),
-                'cf_act_scale_from_tensor')
-    x._cf_act = act
+        L.check(lib.cf_act_scale_fused(None, 0, None, 0, L.ptr(_f32(x)), x.numel() // B, B, float(growth), cells, L.ptr(act), L.stream_ptr()),
+                'cf_act_scale_fused')
+    if x2 is None:
+        x._cf_act = act
     return act
 
 

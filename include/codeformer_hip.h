@@ -249,6 +249,11 @@ int cf_groupnorm_stats(const float* x, int batch, int hw, int c, int cpg, double
  * scratch: batch * 32 floats (32 partial maxima per image: the reduction runs on 32 workgroups per image, then one wave per image). */
 int cf_act_scale_from_stats(const double* partial, int batch, int nper, float growth, float* scratch, float* act, cf_stream_t stream);
 int cf_act_scale_from_tensor(const float* x, int batch, int64_t n_per_image, float growth, float* scratch, float* act, cf_stream_t stream);
+/* The same table in ONE launch (ABI v17), for the statistics partials of one or two tensors -- the halves of a concatenated input share
+ * one scale: A_b = the larger bound -- or (partial_a == NULL) for a tensor x.  cells: 2 * batch zero-initialised uint32 that every launch
+ * leaves at zero again (an atomic maximum and a ticket per image: the workgroup drawing the last of the 32 tickets writes act[b]). */
+int cf_act_scale_fused(const double* partial_a, int nper_a, const double* partial_b, int nper_b, const float* x, int64_t n_per_image, int batch,
+                       float growth, uint32_t* cells, float* act, cf_stream_t stream);
 int cf_groupnorm_finalize(const double* partial, int batch, int parts, int c, int cpg, int gmerge, int64_t count,
                           const float* gamma, const float* beta, float eps, float* scale, float* shift, int ld,
                           cf_stream_t stream);

@@ -124,6 +124,25 @@ def test_act_scale_kernels():
         m = 4.0 * float(y[b].abs().max())
         s = float(a_stats[b, 0])
         assert m * s < 2.0 ** 14 and m * s >= 2.0 ** 7, (b, m * s)       # never above the range, at most 6 bits below the tight scale
+    # two tensors (the halves of a concatenated input) share one table: the scale of the larger bound; repeated launches reuse the cells
+    y2 = ops.conv2d(xin * 37.0, ops.pack_weight(w.cuda(), None), emit_stats=True)
+    for _ in range(3):
+        pair = ops.act_scale(y, y2).cpu()
+    a2 = ops.act_scale(y2).cpu()
+    assert torch.equal(pair[:, 0], torch.minimum(a_stats[:, 0], a2[:, 0])) and torch.equal(pair[:, 1], torch.maximum(a_stats[:, 1], a2[:, 1]))
+    assert not ops._act_cells(xd.device, 2).any()
+    # the two-launch entry points of ABI v16 give the same tables
+    from codeformer_amd import lib as L
+    lib = L.load()
+    old = torch.empty(2, 2, device='cuda')
+    scratch = torch.empty(64, device='cuda')
+    st = y._cf_stats
+    L.check(lib.cf_act_scale_from_stats(L.ptr(st.part, dtype=torch.float64), 2, st.part.numel() // 4, 4.0, L.ptr(scratch), L.ptr(old), L.stream_ptr()), 'from_stats')
+    assert torch.equal(old.cpu(), a_stats)
+    old6 = torch.empty(6, 2, device='cuda')
+    scratch = torch.empty(6 * 32, device='cuda')
+    L.check(lib.cf_act_scale_from_tensor(L.ptr(xd), 6, xd.numel() // 6, 4.0, L.ptr(scratch), L.ptr(old6), L.stream_ptr()), 'from_tensor')
+    assert torch.equal(old6.cpu(), act)
 
 
 @pytest.mark.parametrize('mag', [1.0e9, 3.0e-9])

@@ -120,7 +120,7 @@ def conv_code(code, cin, cout, h, w, up2x=False, c_split=None, plain=True):
     if code in (SPLIT, SPLIT_DIRECT):
         if code == SPLIT and SPLIT_WINOGRAD and plain and not up2x and winograd_ok(cin, cout, h, w):
             return WSPLIT
-        if plain and split_ok(cin, cout, h, w, c_split) and h * w >= SPLIT_MIN_PIXELS:
+        if plain and split_ok(cin, cout, h, w, c_split) and (up2x or h * w >= SPLIT_MIN_PIXELS):   # (the folded upsample has no Winograd form: the direct split kernel beats the fp32 one from 16x16 up, tools/up16_probe.py)
             return SPLIT
         code = WINOGRAD if code == SPLIT else 0
     if code == WINOGRAD:

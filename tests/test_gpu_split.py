@@ -98,7 +98,7 @@ def test_split_conv_refusals_and_overflow_is_loud(sc):
     assert ops.SPLIT_WINOGRAD     # (default; CODEFORMER_HIP_SPLIT_WINOGRAD=0 keeps eligible layers on the direct split-half kernel)
     assert ops.conv_code(ops.SPLIT, 128, 128, 256, 256) == ops.WSPLIT and ops.conv_code(ops.SPLIT, 512, 512, 16, 16) == ops.WSPLIT
     assert ops.conv_code(ops.SPLIT_DIRECT, 512, 512, 16, 16) == 0 and ops.conv_code(ops.SPLIT, 48, 64, 64, 64) == ops.WSPLIT
-    assert ops.conv_code(ops.SPLIT, 512, 512, 16, 16, up2x=True) == 0 and ops.conv_code(ops.SPLIT, 128, 128, 256, 256, up2x=True) == ops.SPLIT
+    assert ops.conv_code(ops.SPLIT, 512, 512, 16, 16, up2x=True) == ops.SPLIT and ops.conv_code(ops.SPLIT, 128, 128, 256, 256, up2x=True) == ops.SPLIT
 
 
 def test_split_half_token_gemm(sc):

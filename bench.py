@@ -127,7 +127,7 @@ def roofline_leg(net, x, w):
     # kind -> (kernel, MFMA FLOPs executed per algorithmic FLOP booked by ops.conv2d, dense MFMA peak of the type it issues)
     KINDS = {
         'conv3x3_f16x2': ('split_conv_kernel<9,...> (3x3 s1, fp32 operands as hi+lo halves: 3 f16 MFMAs per product, fp32 accumulate)', 3.0, F16_MFMA_PEAK_TFLOPS, ('split_conv_kernel<9',)),
-        'conv_up2x_f16x2': ('split_conv_kernel<4,...> (nearest-x2 + 3x3 folded to 2x2 sub-pixel taps, split halves)', 3.0, F16_MFMA_PEAK_TFLOPS, ('split_conv_kernel<4',)),
+        'conv_up2x_f16x2': ('split_conv_kernel<4,...> (nearest-x2 + 3x3 folded to 2x2 sub-pixel taps, split halves)', 3.0, F16_MFMA_PEAK_TFLOPS, ('split_conv_kernel<4, 2, 2, false', 'split_conv_kernel<4, 1, 2, false')),
         'conv3x3_wino': ('winograd_kernel<.,false> (3x3 s1 as Winograd F(2x2,3x3), fp32 MFMA)', 4.0 / 9.0, FP32_MFMA_PEAK_TFLOPS, ('winograd_kernel<false, false', 'winograd_kernel<true, false')),
         'conv3x3_wino_f16x2_8w': ('wsplit_kernel (3x3 s1 as Winograd F(2x2,3x3), 128 channels per 8-wave workgroup; U and V as hi+lo halves: 3 f16 '
                                   'MFMAs per transform-domain product, fp32 accumulate)', 3.0 * 4.0 / 9.0, F16_MFMA_PEAK_TFLOPS, ('wsplit_kernel',)),
@@ -139,7 +139,7 @@ def roofline_leg(net, x, w):
         'conv3x3_io': ('conv3x3_few_cin / conv3x3_few_cout (3->64 and 64->3 at 512x512 on the vector ALU: write- / read-bound)', 0.0, HBM_PEAK_GBS, ('conv3x3_few_c',)),
         'conv_up2x': ('igemm_kernel<4,1,...> (folded nearest-x2 + 3x3, fp32 MFMA)', 1.0, FP32_MFMA_PEAK_TFLOPS, ('igemm_kernel<4, 1',)),
         'conv3x3_s2': ('igemm_kernel<9,2,...> (3x3 stride 2, fp32 MFMA)', 1.0, FP32_MFMA_PEAK_TFLOPS, ('igemm_kernel<9, 2',)),
-        'conv3x3_s2_f16x2': ('split_conv_kernel<4,...> (3x3 stride 2 as a 2x2 convolution of the space-to-depth input, split halves: 16 of which 9 tap blocks are non-zero)', 3.0 * 16.0 / 9.0, F16_MFMA_PEAK_TFLOPS, ('split_conv_kernel<4',)),
+        'conv3x3_s2_f16x2': ('split_conv_kernel<4,...> (3x3 stride 2 as a 2x2 convolution of the space-to-depth input, split halves: 16 of which 9 tap blocks are non-zero)', 3.0 * 16.0 / 9.0, F16_MFMA_PEAK_TFLOPS, ('split_conv_kernel<4, 2, 2, true', 'split_conv_kernel<4, 1, 2, true')),
         'gemm1x1': ('igemm_kernel<1,1,...> (1x1 conv / Linear, fp32 MFMA)', 1.0, FP32_MFMA_PEAK_TFLOPS, ('igemm_kernel<1, 1',)),
         'gemm1x1_f16x2': ('split_conv_kernel<1,...> (1x1 skip convolutions on images of more than 1024 pixels, split halves: read-once / write-once streaming)', 0.0, HBM_PEAK_GBS, ('split_conv_kernel<1',)),
     }

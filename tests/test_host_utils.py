@@ -79,3 +79,32 @@ def test_operand_range_host_rules():
     assert float(small['generator.blocks.5.conv2.bias'][0]) == 1.0 / 4096.0
     h1, h2 = range_variant(sd, 'heavy'), range_variant(sd, 'heavy')
     assert all(torch.equal(h1[k], h2[k]) for k in sd)
+
+
+def test_kernel_selection_host_rules():
+    """Which kernel a layer takes is decided on the host from its per-image shape (never the batch): the split-K counts, the stride-2 and
+    1x1 forms of the split-half kernel, the folded upsample from 16x16 up.  No GPU: PackedWeight objects are built by hand."""
+    from codeformer_amd import ops
+    lin = ops.PackedWeight(None, None, 512, 512, 1, 512, 512)
+    lin1024 = ops.PackedWeight(None, None, 512, 1024, 1, 512, 1024)
+    # Linear layers: the largest split with at most 128 workgroups in flight; eligibility by the per-image shape only
+    assert [ops.splitk_for(lin, 16, 16, 512, b) for b in (1, 2, 4, 8, 16)] == [4, 2, 1, 1, 1]
+    assert [ops.splitk_for(lin1024, 16, 16, 1024, b) for b in (1, 2, 4, 16)] == [4, 2, 1, 1]
+    assert ops.splitk_for(lin, 64, 64, 512, 1) == 0 and ops.splitk_for(lin, 16, 16, 320, 1) == 0
+    # Winograd latents: at most 256 workgroups; 16 faces -> one workgroup per tile
+    wino = ops.PackedWeight(None, None, 512, 512, 9, 512, 512, bf16=ops.OPERAND_F16X2, wino=True)
+    assert [ops.splitk_for(wino, 16, 16, 512, b) for b in (1, 2, 4, 8, 16, 32)] == [4, 4, 4, 2, 1, 1]
+    assert ops.splitk_for(wino, 32, 32, 512, 1) == 0
+    # shapes of the stride-2 and 1x1 forms
+    assert ops.split_s2_ok(64, 64, 512, 512) and ops.split_s2_ok(256, 256, 32, 32) and ops.split_s2_ok(16, 64, 16, 32)
+    assert not ops.split_s2_ok(24, 64, 64, 64) and not ops.split_s2_ok(64, 96, 64, 64) and not ops.split_s2_ok(64, 64, 24, 32)
+    assert ops.split_1x1_ok(128, 64, 512, 512) and ops.split_1x1_ok(512, 256, 64, 64, c_split=256)
+    assert not ops.split_1x1_ok(512, 256, 32, 32)              # 1024 pixels: token-sized, stays on the GEMM
+    assert not ops.split_1x1_ok(128, 64, 36, 64) and not ops.split_1x1_ok(128, 48, 64, 64) and not ops.split_1x1_ok(96, 64, 64, 64, c_split=48)
+    # operand codes: the folded upsample takes the direct split kernel from 16x16 up, plain 3x3 below 32x32 the Winograd form
+    assert ops.conv_code(ops.SPLIT, 512, 512, 16, 16, up2x=True) == ops.SPLIT and ops.conv_code(ops.SPLIT, 512, 512, 16, 16) == ops.WSPLIT
+    assert ops.conv_code(ops.SPLIT_DIRECT, 512, 512, 16, 16) == 0 and ops.conv_code(ops.SPLIT, 128, 128, 24, 16, up2x=True) == 0
+    # a stride-2 / 1x1 weight form is tied to its descriptor
+    s2 = ops.PackedWeight(None, None, 64, 64, 9, 64, 64, bf16=ops.OPERAND_F16X2, s2=True)
+    c1 = ops.PackedWeight(None, None, 64, 128, 1, 64, 128, bf16=ops.OPERAND_F16X2, conv1=True)
+    assert ops.needs_act_scale(s2) == ops.RANGE_SCALE and ops.needs_act_scale(c1) == ops.RANGE_SCALE and not ops.needs_act_scale(lin)

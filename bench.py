@@ -231,7 +231,7 @@ def main():
     ap.add_argument('--batch-per-gpu', type=int, default=16)
     ap.add_argument('--w', type=float, default=0.5)
     ap.add_argument('--precision', choices=['fp32', 'f16x2', 'bf16', 'fp16'], default='f16x2',
-                    help="operand format of the convolutions (Transformer, small 1x1 layers, statistics and the code argmax are "
+                    help="operand format of the convolutions (attention, AttnBlock 1x1, statistics and the code argmax are "
                          "exact fp32 in every mode): f16x2 = fp32 operands split into hi+lo IEEE halves, fp32-grade accuracy, encoder included "
                          "(default); fp32 = exact fp32 MFMA everywhere; bf16 / fp16 = single 16-bit operands in generator + CFT (BASELINE configs "
                          "3/5), encoder on split halves")
@@ -300,9 +300,9 @@ def main():
             'metric': 'aligned 512x512 faces/sec (whole node) at w=0.5', 'value': round(faces_per_s, 2), 'unit': 'faces/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': {'fp32': 'f32', 'f16x2': 'f32 (tensors, accumulation; Transformer / token-sized 1x1 / argmax on exact fp32 MFMA; 3x3 (stride 1, 2) and image-sized 1x1 '
+            'dtype': {'fp32': 'f32', 'f16x2': 'f32 (tensors, accumulation; attention, AttnBlock 1x1, out-proj / MLP-down / feat_emb Linear layers and argmax on exact fp32 MFMA; 3x3 (stride 1, 2), image-sized 1x1 and the LayerNorm-fed Linear layers '
                                                   'products on split operands: fp32 = hi + lo IEEE halves, 3 f16 MFMAs per product)'}.get(
-                args.precision, f'{args.precision} operands / f32 accumulate (3x3 convs of generator + CFT); encoder on split halves (hi + lo, fp32-grade); f32 (Transformer, token-sized 1x1)'),
+                args.precision, f'{args.precision} operands / f32 accumulate (3x3 convs of generator + CFT); encoder and LayerNorm-fed Linear layers on split halves (hi + lo, fp32-grade); f32 (other Linear layers, AttnBlock 1x1)'),
             'data': 'synthetic',
             'config': {'workload': ({'fp32': 'BASELINE config 2 (IEEE fp32 arithmetic)',
                                      'f16x2': "BASELINE config 2 shapes and tensors; 3x3 products on split-half f16 operands (fp32-grade: meets the config's "

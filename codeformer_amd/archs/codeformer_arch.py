@@ -14,6 +14,8 @@ codeformer_amd/csrc with channels-last activations:
 """
 import os
 
+import math
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -69,14 +71,18 @@ class TransformerSALayer(HipModule):
     def with_pos_embed(self, tensor, pos):
         return tensor if pos is None else tensor + pos
 
-    def forward_tokens(self, X, pos, batch, code=0):
+    def forward_tokens(self, X, pos, batch, code=0, code_ln=None):
         """X: (batch*256, E) tokens, pos: (256, E) or None.  Returns the layer output, same shape.
-        code: operand code of the five GEMMs (0 exact fp32 MFMA, ops.GSPLIT split-half operands)."""
+        code: operand code of the five GEMMs (0 exact fp32 MFMA, ops.GSPLIT split-half operands); code_ln: the code of the three that
+        read a LayerNorm output (q|k, v, MLP-up; default: `code`) -- their inputs are bounded by the norm's parameters (ln_code)."""
         E, H = self.embed_dim, self.nhead
         sa = self.self_attn
         w, b = sa.in_proj_weight, sa.in_proj_bias
-        pw_qk = self._packed(('qk', code), lambda: ops.pack_weight(w[:2 * E], b[:2 * E], bf16=code), w, b)
-        pw_v = self._packed(('v', code), lambda: ops.pack_weight(w[2 * E:], b[2 * E:], bf16=code), w, b)
+        code_ln = code if code_ln is None else code_ln
+        c1 = ln_code(self, self.norm1, code_ln, pos)
+        c2 = ln_code(self, self.norm2, code_ln)
+        pw_qk = self._packed(('qk', c1), lambda: ops.pack_weight(w[:2 * E], b[:2 * E], bf16=c1), w, b)
+        pw_v = self._packed(('v', c1), lambda: ops.pack_weight(w[2 * E:], b[2 * E:], bf16=c1), w, b)
         pw_o = self._pw_conv(sa.out_proj, bf16=code)
         if pos is not None:
             t2, t2p = ops.layernorm(X, self.norm1.weight, self.norm1.bias, self.norm1.eps, pos=pos)
@@ -88,7 +94,7 @@ class TransformerSALayer(HipModule):
         a = ops.attention(qk[:, :E], qk[:, E:], v, batch, H, hd, float(hd) ** -0.5)
         X = ops.linear(a, pw_o, epilogue=EPI_RESIDUAL, res=X)
         t2 = ops.layernorm(X, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        h = ops.linear(t2, self._pw_conv('linear1', bf16=code), epilogue=EPI_GELU)
+        h = ops.linear(t2, self._pw_conv('linear1', bf16=c2), epilogue=EPI_GELU)
         return ops.linear(h, self._pw_conv('linear2', bf16=code), epilogue=EPI_RESIDUAL, res=X)
 
     def forward(self, tgt, tgt_mask=None, tgt_key_padding_mask=None, query_pos=None):
@@ -111,6 +117,19 @@ class TransformerSALayer(HipModule):
         tgt2 = self.norm2(tgt)
         tgt2 = self.linear2(self.dropout(F.gelu(self.linear1(tgt2))))
         return tgt + self.dropout2(tgt2)
+
+
+def ln_code(module, norm, code, pos=None):
+    """Operand code of a Linear layer that reads LayerNorm `norm`'s output (+ the position table): `code`, or 0 (exact fp32) when the bound
+    max_i(|gamma_i| sqrt(C - 1) + |beta_i|) + max|pos| could leave the IEEE-half range of the split-half token GEMM, which has no range
+    scale.  The maxima are read back once per parameter version (HipModule._packed)."""
+    if int(code) != ops.GSPLIT:
+        return int(code)
+    params = (norm.weight, norm.bias) + (() if pos is None else (pos,))
+    bound = module._packed(('ln_range', id(norm), pos is not None),
+                           lambda: float((norm.weight.detach().abs() * math.sqrt(norm.weight.numel() - 1) + norm.bias.detach().abs()).max())
+                           + (0.0 if pos is None else float(pos.detach().abs().max())), *params)
+    return ops.GSPLIT if bound < 32768.0 else 0
 
 
 class Fuse_sft_block(HipModule):
@@ -201,8 +220,12 @@ class CodeFormer(VQAutoEncoder):
         # is 9.1 (exact: 8.8), and every index of every golden agrees.  Set 'fp32' to keep logits bitwise equal across precisions.
         self.encoder_precision = os.environ.get('CODEFORMER_HIP_ENCODER_PRECISION', 'auto')
         # Operand format of the Transformer's Linear layers (feat_emb, q|k / v / out projections, MLP, logits head): 'fp32' = exact fp32
-        # MFMA GEMM, 'f16x2' = split-half operands (cf_gemm_split.hip).
-        self.gemm_precision = os.environ.get('CODEFORMER_HIP_GEMM_PRECISION', 'fp32')
+        # MFMA GEMM; 'f16x2' = split-half operands (cf_gemm_split.hip) everywhere -- opt-in: the token GEMM has no range scale and the
+        # inputs of out-proj / MLP-down / feat_emb are not bounded by anything the host can check; 'auto' (default) = split halves for the
+        # Linear layers that read a LayerNorm output (q|k, v, MLP-up, the logits head: 28 of 47 launches) when their bound
+        # |gamma| sqrt(C - 1) + |beta| (+ |pos|) stays inside the half range (ln_code) and `precision` is not 'fp32', exact fp32 elsewhere.
+        # Against fp64 the split-half GEMM is closer than the fp32-MFMA one (1.2e-6 vs 2.0e-6); logits / indices vs the reference unchanged.
+        self.gemm_precision = os.environ.get('CODEFORMER_HIP_GEMM_PRECISION', 'auto')
         # Optional HIP-graph replay of the whole forward (one graph per input shape / w / flags): takes the ~250 host launches
         # per call off the critical path.  Measured: no gain at B=1..16 on an otherwise idle host (the kernels, not the launches,
         # bound even B=1), so it is off by default; useful when the host thread is busy (decode / encode of PNGs).
@@ -249,14 +272,15 @@ class CodeFormer(VQAutoEncoder):
         T = lq.shape[1] * lq.shape[2]
         tokens = lq.view(B * T, lq.shape[3])
 
-        if self.gemm_precision not in ('fp32', 'f16x2'):
-            raise ValueError(f"gemm_precision must be 'fp32' or 'f16x2', got {self.gemm_precision!r}")
+        if self.gemm_precision not in ('auto', 'fp32', 'f16x2'):
+            raise ValueError(f"gemm_precision must be 'auto', 'fp32' or 'f16x2', got {self.gemm_precision!r}")
         gcode = ops.GSPLIT if self.gemm_precision == 'f16x2' else 0
+        gcode_ln = ops.GSPLIT if (self.gemm_precision == 'f16x2' or (self.gemm_precision == 'auto' and self.precision != 'fp32')) else 0
         X = ops.linear(tokens, self._pw_conv('feat_emb', bf16=gcode))
         for layer in self.ft_layers:
-            X = layer.forward_tokens(X, self.position_emb, B, code=gcode)
+            X = layer.forward_tokens(X, self.position_emb, B, code=gcode, code_ln=gcode_ln)
         ln, head = self.idx_pred_layer[0], self.idx_pred_layer[1]
-        logits2d = ops.linear(ops.layernorm(X, ln.weight, ln.bias, ln.eps), self._pw_conv(head, bf16=gcode))
+        logits2d = ops.linear(ops.layernorm(X, ln.weight, ln.bias, ln.eps), self._pw_conv(head, bf16=ln_code(self, ln, gcode_ln)))
         logits = logits2d.view(B, T, -1)
         lq_feat = ops.to_nchw(lq)
         if code_only:

@@ -108,3 +108,20 @@ def test_kernel_selection_host_rules():
     s2 = ops.PackedWeight(None, None, 64, 64, 9, 64, 64, bf16=ops.OPERAND_F16X2, s2=True)
     c1 = ops.PackedWeight(None, None, 64, 128, 1, 64, 128, bf16=ops.OPERAND_F16X2, conv1=True)
     assert ops.needs_act_scale(s2) == ops.RANGE_SCALE and ops.needs_act_scale(c1) == ops.RANGE_SCALE and not ops.needs_act_scale(lin)
+
+
+def test_layernorm_bound_decides_the_operands_of_the_transformer_gemms():
+    """ln_code: a Linear layer behind a LayerNorm takes split-half operands only while |gamma| sqrt(C - 1) + |beta| (+ |pos|) stays inside
+    the IEEE-half range; the bound follows the parameters (in-place edits bump their version)."""
+    import torch
+    from codeformer_amd import ops
+    from codeformer_amd.archs.codeformer_arch import TransformerSALayer, ln_code
+    layer = TransformerSALayer(embed_dim=512, nhead=8, dim_mlp=1024)
+    pos = torch.zeros(256, 512)
+    assert ln_code(layer, layer.norm1, ops.GSPLIT, pos) == ops.GSPLIT and ln_code(layer, layer.norm2, ops.GSPLIT) == ops.GSPLIT
+    assert ln_code(layer, layer.norm1, 0, pos) == 0
+    with torch.no_grad():
+        layer.norm2.weight.mul_(2000.0)                    # 2000 * sqrt(511) > 32768
+    assert ln_code(layer, layer.norm2, ops.GSPLIT) == 0 and ln_code(layer, layer.norm1, ops.GSPLIT, pos) == ops.GSPLIT
+    pos2 = torch.full((256, 512), 4.0e4)
+    assert ln_code(layer, layer.norm1, ops.GSPLIT, pos2) == 0

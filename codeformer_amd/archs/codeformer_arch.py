@@ -229,6 +229,10 @@ class CodeFormer(VQAutoEncoder):
         # Optional HIP-graph replay of the whole forward (one graph per input shape / w / flags): takes the ~250 host launches
         # per call off the critical path.  Measured: no gain at B=1..16 on an otherwise idle host (the kernels, not the launches,
         # bound even B=1), so it is off by default; useful when the host thread is busy (decode / encode of PNGs).
+        # Round 3 re-measurement: with the faster kernels a one-face call is host-bound in places when run eagerly (the Transformer section:
+        # 1.6 ms of host enqueue for 0.9 ms of GPU work), and replay takes the whole call from 6.76 to 6.55 ms on a box where the host is the
+        # slower side; it stays opt-in because a replayed graph cannot notice in-place parameter updates (only load_state_dict / .to() /
+        # invalidate_packed_weights() drop it) and pins the activations of every captured shape.
         self.use_hip_graphs = os.environ.get('CODEFORMER_HIP_GRAPHS', '0') == '1'
         self._graphs = {}
         self.connect_list = connect_list

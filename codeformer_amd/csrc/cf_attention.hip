@@ -12,6 +12,10 @@
 // k-major in LDS as the B operand; output columns are processed 128 at a time (32 per wave).
 #include "cf_common.h"
 
+#ifndef CF_ATTN64_GENERIC
+#define CF_ATTN64_GENERIC 0  // 1: timing builds with the generic kernel for head_dim 64
+#endif
+
 namespace {
 
 constexpr int NKEY = 256;
@@ -118,6 +122,130 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ Q, 
       for (int r = 0; r < 16; ++r)
         O[(rowbase + q0 + cf_acc_row(r, lane)) * ldo + colbase + col0 + wave * 32 + l31] = o[r];
     }
+  }
+}
+
+// ---- head_dim 64 (the Transformer's nn.MultiheadAttention core) -------------------------------------------------------------------
+// The generic kernel walks 4 + 16 barrier-separated slabs, each opening with a fetch it waits for, and half its waves idle in phase 3:
+// 19 us per workgroup whatever the batch (21 us per launch for one face, nine launches per forward).  Here every operand is requested
+// up front -- the four K slabs and the Q tile before phase 1, all of V (sixteen float4 per thread) before the softmax, which hides its
+// latency -- the K slabs alternate between two LDS buffers (one barrier per slab), V is staged in two 128-key halves, and all four
+// waves work in phase 3: wave w owns output columns 32 (w & 1) .. +31 and, of each half, keys 64 (w >> 1) .. +63; the two key groups
+// meet through LDS.  Summation order of an output: keys [0, 64) + [128, 192) in one accumulator, [64, 128) + [192, 256) in the other,
+// then their sum (fixed: results do not depend on batch or grid).
+constexpr int A6_STAGE = (BQ + NKEY) * CF_LDK;                 // floats of one Q|K slab buffer
+constexpr int A6_VLD = 72;                                     // V row stride: the two lane halves of a B read (4 keys apart) land 32 banks apart
+constexpr int A6_VHALF = 128 * A6_VLD;                         // floats of a 128-key half of V
+constexpr int A6_LDS_FLOATS = BQ * PS + (2 * A6_STAGE > A6_VHALF ? 2 * A6_STAGE : A6_VHALF);
+constexpr size_t A6_LDS_BYTES = (size_t)A6_LDS_FLOATS * sizeof(float);
+
+__global__ __launch_bounds__(256, 2) void attn64_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ K, int ldk,
+                                                        const float* __restrict__ V, int ldv, float* __restrict__ O, int ldo, float scale) {
+  constexpr int DH = 64;
+  extern __shared__ __attribute__((aligned(16))) float a6_smem[];
+  float* const Ps = a6_smem;                 // [32][PS] scores, then probabilities
+  float* const stage = a6_smem + BQ * PS;    // two Q|K slab buffers; later a V half; last the partial outputs of waves 2, 3
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int q0 = blockIdx.x * BQ;
+  const int h = blockIdx.y;
+  const int b = blockIdx.z;
+  const size_t rowbase = (size_t)b * NKEY;
+  const int colbase = h * DH;
+
+  // ---- all of K (four 16-channel slabs) and the Q tile: one exposed latency ----
+  f32x4 kr[4][4];
+  f32x4 qr[4];
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int f = tid + 256 * j, row = f >> 2, k4 = f & 3;
+      kr[sl][j] = *reinterpret_cast<const f32x4*>(K + (rowbase + row) * ldk + colbase + sl * CF_BK + k4 * 4);
+    }
+    const int row = (tid & 127) >> 2, k4 = tid & 3;  // (threads 128..255 fetch duplicates they never store: no divergent load)
+    qr[sl] = *reinterpret_cast<const f32x4*>(Q + (rowbase + q0 + row) * ldq + colbase + sl * CF_BK + k4 * 4);
+  }
+  auto store_slab = [&](int sl, float* buf) __attribute__((always_inline)) {
+    if (tid < BQ * 4) *reinterpret_cast<f32x4*>(buf + (tid >> 2) * CF_LDK + (tid & 3) * 4) = qr[sl];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int f = tid + 256 * j;
+      *reinterpret_cast<f32x4*>(buf + (BQ + (f >> 2)) * CF_LDK + (f & 3) * 4) = kr[sl][j];
+    }
+  };
+  // ---- phase 1: S[32][256] = Q K^T; wave w owns keys [64w, 64w + 64) ----
+  f32x16 acc[1][2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[0][0][r] = acc[0][1][r] = 0.f;
+  store_slab(0, stage);
+  __syncthreads();
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl) {
+    float* const buf = stage + (sl & 1) * A6_STAGE;
+    if (sl + 1 < 4) store_slab(sl + 1, stage + ((sl + 1) & 1) * A6_STAGE);  // (its last readers left at the previous barrier)
+    const float* ap[1] = {buf + l31 * CF_LDK + half * 4};
+    const float* bp[2] = {buf + (BQ + wave * 64 + l31) * CF_LDK + half * 4, buf + (BQ + wave * 64 + 32 + l31) * CF_LDK + half * 4};
+    cf_mma_slab<1, 2>(acc, ap, bp);
+    __syncthreads();
+  }
+  // ---- all of V: 256 keys x 64 columns = sixteen float4 per thread, in flight across the score write-out and the softmax ----
+  f32x4 vr[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int f = tid + 256 * j, key = f >> 4, c4 = f & 15;
+    vr[j] = *reinterpret_cast<const f32x4*>(V + (rowbase + key) * ldv + colbase + c4 * 4);
+  }
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Ps[cf_acc_row(r, lane) * PS + wave * 64 + ni * 32 + l31] = acc[0][ni][r] * scale;
+  __syncthreads();
+  // ---- phase 2: row softmax (F.softmax over keys), 8 rows per wave ----
+#pragma unroll
+  for (int i = 0; i < BQ / 4; ++i) {
+    float* pr = Ps + (wave * (BQ / 4) + i) * PS + lane * 4;
+    f32x4 v = *reinterpret_cast<f32x4*>(pr);
+    const float m = cf_wave_max(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = expf(v[e] - m);
+    const float sum = cf_wave_sum((v[0] + v[1]) + (v[2] + v[3]));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = v[e] / sum;
+    *reinterpret_cast<f32x4*>(pr) = v;
+  }
+  // ---- phase 3: O[32][64] = P V ----
+  const int nt = wave & 1, kgp = wave >> 1;
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+  for (int vh = 0; vh < 2; ++vh) {
+    if (vh) __syncthreads();  // every wave is done with the first half
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int f = tid + 256 * j;  // (key within the half, column quad) = (f >> 4, f & 15)
+      *reinterpret_cast<f32x4*>(stage + (f >> 4) * A6_VLD + (f & 15) * 4) = vr[vh * 8 + j];
+    }
+    __syncthreads();  // (the first one also publishes the probabilities)
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg) {
+      const int kl = kgp * 64 + kg * 8 + half * 4;  // this lane half's four keys of the group (the k permutation of cf_mma_slab)
+      const f32x4 af = *reinterpret_cast<const f32x4*>(Ps + l31 * PS + vh * 128 + kl);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], stage[(kl + j) * A6_VLD + nt * 32 + l31], o, 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  if (kgp == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) stage[(nt * 32 + cf_acc_row(r, lane)) * 33 + l31] = o[r];
+  }
+  __syncthreads();
+  if (kgp == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      O[(rowbase + q0 + cf_acc_row(r, lane)) * ldo + colbase + nt * 32 + l31] = o[r] + stage[(nt * 32 + cf_acc_row(r, lane)) * 33 + l31];
   }
 }
 
@@ -240,7 +368,21 @@ extern "C" int cf_attention(const float* q, int ldq, const float* k, int ldk, co
              "cf_attention: bad dims");
   const dim3 grid(NKEY / BQ, heads, batch), block(256);
   if (head_dim == 64) {
-    hipLaunchKernelGGL(attn_kernel<64>, grid, block, 0, (hipStream_t)stream, q, ldq, k, ldk, v, ldv, out, ldo, scale);
+    static unsigned long long attr6_devs = 0;  // bit d: LDS attribute set on device d
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 64 || !((attr6_devs >> dev) & 1ull)) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)A6_LDS_BYTES);
+      if (e != hipSuccess) {
+        cf_set_error("cf_attention: hipFuncSetAttribute(%zu B LDS): %s", A6_LDS_BYTES, hipGetErrorString(e));
+        return CF_ERR_LAUNCH;
+      }
+      if (dev < 64) attr6_devs |= 1ull << dev;  // benign race: the attribute call is idempotent
+    }
+    if (CF_ATTN64_GENERIC)
+      hipLaunchKernelGGL(attn_kernel<64>, grid, block, 0, (hipStream_t)stream, q, ldq, k, ldk, v, ldv, out, ldo, scale);
+    else
+      hipLaunchKernelGGL(attn64_kernel, grid, block, A6_LDS_BYTES, (hipStream_t)stream, q, ldq, k, ldk, v, ldv, out, ldo, scale);
   } else if (head_dim == 512) {
     static unsigned long long attr_devs = 0;  // bit d: LDS attribute set on device d
     int dev = 0;

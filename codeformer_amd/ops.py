@@ -483,6 +483,8 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
         kind = 'conv3x3_io'   # the network's first / last conv: vector-ALU kernels, HBM-bound (conv3x3_few_cin / few_cout)
     if pw.bf16:
         kind += ('', '_bf16', '_f16', '_f16x2')[int(pw.bf16)]
+    if pw.conv1:
+        kind = 'conv1x1_stream_f16x2'   # 1x1 on images through the split-half convolution kernel (HBM-bound), not the token GEMM
     if pw.wino and pw.bf16 and pw.cout % 128 == 0 and Ho * Wo >= 1024 and not split_k:
         kind += '_8w'      # the eight-wave 128-channel kernel (cf_wsplit.hip; the rule of cf_wsplit_covers)
     PROFILE.append((kind, flops, nbytes, e0, e1, (B, H, W, cin, pw.cout)))

@@ -125,3 +125,33 @@ def test_layernorm_bound_decides_the_operands_of_the_transformer_gemms():
     assert ln_code(layer, layer.norm2, ops.GSPLIT) == 0 and ln_code(layer, layer.norm1, ops.GSPLIT, pos) == ops.GSPLIT
     pos2 = torch.full((256, 512), 4.0e4)
     assert ln_code(layer, layer.norm1, ops.GSPLIT, pos2) == 0
+
+
+def test_stride2_space_to_depth_identity():
+    """The algebra the stride-2 form of the split-half kernel rests on (cf_split.hip, split_weight_value_s2): Downsample's
+    pad(0,1,0,1) + 3x3 stride-2 conv (vqgan_arch.py:117-126) equals a 2x2 stride-1 conv of the space-to-depth view
+    X[(p,q,c)][i][j] = x[c][2i+p][2j+q] (zero row / column appended bottom / right) with W'[n][(p,q,c)][ty][tx] = w[n][c][2ty+p][2tx+q]
+    where that tap exists and 0 elsewhere -- checked in fp64 on CPU, with the channel order (p, q, c) the gather uses."""
+    import torch
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(11)
+    B, C, Co, H, W = 2, 5, 7, 12, 16
+    x = torch.randn(B, C, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(Co, C, 3, 3, generator=g, dtype=torch.float64)
+    b = torch.randn(Co, generator=g, dtype=torch.float64)
+    ref = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, b, stride=2)
+    X = torch.stack([x[:, :, p::2, q::2] for p in (0, 1) for q in (0, 1)], dim=1).reshape(B, 4 * C, H // 2, W // 2)   # channel = (p*2+q)*C + c
+    Wp = torch.zeros(Co, 4 * C, 2, 2, dtype=torch.float64)
+    zero_blocks = 0
+    for ty in (0, 1):
+        for tx in (0, 1):
+            for p in (0, 1):
+                for q in (0, 1):
+                    ky, kx = 2 * ty + p, 2 * tx + q
+                    if ky > 2 or kx > 2:
+                        zero_blocks += 1
+                        continue
+                    Wp[:, (p * 2 + q) * C:(p * 2 + q + 1) * C, ty, tx] = w[:, :, ky, kx]
+    assert zero_blocks == 7                                     # 16 tap x parity blocks, 9 taps
+    got = F.conv2d(F.pad(X, (0, 1, 0, 1)), Wp, b)               # 2x2 taps at (i + ty, j + tx); beyond the last row / column: zero
+    assert got.shape == ref.shape and float((got - ref).abs().max()) < 1e-12

@@ -142,7 +142,7 @@ def roofline_leg(net, x, w):
         'conv3x3_s2_f16x2': ('split_conv_kernel<4,...> (3x3 stride 2 as a 2x2 convolution of the space-to-depth input, split halves: 16 of which 9 tap blocks are non-zero)', 3.0 * 16.0 / 9.0, F16_MFMA_PEAK_TFLOPS, ('split_conv_kernel<4, 2, 2, true', 'split_conv_kernel<4, 1, 2, true')),
         'gemm1x1': ('igemm_kernel<1,1,...> (1x1 conv / Linear, fp32 MFMA)', 1.0, FP32_MFMA_PEAK_TFLOPS, ('igemm_kernel<1, 1',)),
         'conv1x1_stream_f16x2': ('split_conv_kernel<1,...> (1x1 skip convolutions on images of more than 1024 pixels, split halves: read-once / write-once streaming)', 0.0, HBM_PEAK_GBS, ('split_conv_kernel<1',)),
-        'gemm1x1_f16x2': ('gemm_split_kernel (the LayerNorm-fed Linear layers of the Transformer on split halves: A and pre-split B fragments straight from L2, 3 f16 MFMAs per product)', 3.0, F16_MFMA_PEAK_TFLOPS, ('gemm_split_kernel',)),
+        'gemm1x1_f16x2': ('gemm_split_kernel (the parameter-bounded Linear layers of the Transformer on split halves: A and pre-split B fragments straight from L2, 3 f16 MFMAs per product)', 3.0, F16_MFMA_PEAK_TFLOPS, ('gemm_split_kernel',)),
     }
 
     def entry(kind):
@@ -301,9 +301,9 @@ def main():
             'metric': 'aligned 512x512 faces/sec (whole node) at w=0.5', 'value': round(faces_per_s, 2), 'unit': 'faces/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': {'fp32': 'f32', 'f16x2': 'f32 (tensors, accumulation; attention, AttnBlock 1x1, out-proj / MLP-down / feat_emb Linear layers and argmax on exact fp32 MFMA; 3x3 (stride 1, 2), image-sized 1x1 and the LayerNorm-fed Linear layers '
+            'dtype': {'fp32': 'f32', 'f16x2': 'f32 (tensors, accumulation; attention, AttnBlock 1x1, feat_emb and argmax on exact fp32 MFMA; 3x3 (stride 1, 2), image-sized 1x1 and the parameter-bounded Linear layers of the Transformer '
                                                   'products on split operands: fp32 = hi + lo IEEE halves, 3 f16 MFMAs per product)'}.get(
-                args.precision, f'{args.precision} operands / f32 accumulate (3x3 convs of generator + CFT); encoder and LayerNorm-fed Linear layers on split halves (hi + lo, fp32-grade); f32 (other Linear layers, AttnBlock 1x1)'),
+                args.precision, f'{args.precision} operands / f32 accumulate (3x3 convs of generator + CFT); encoder and the Transformer's parameter-bounded Linear layers on split halves (hi + lo, fp32-grade); f32 (feat_emb, AttnBlock 1x1)'),
             'data': 'synthetic',
             'config': {'workload': ({'fp32': 'BASELINE config 2 (IEEE fp32 arithmetic)',
                                      'f16x2': "BASELINE config 2 shapes and tensors; 3x3 products on split-half f16 operands (fp32-grade: meets the config's "

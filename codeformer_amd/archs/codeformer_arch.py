@@ -81,9 +81,13 @@ class TransformerSALayer(HipModule):
         code_ln = code if code_ln is None else code_ln
         c1 = ln_code(self, self.norm1, code_ln, pos)
         c2 = ln_code(self, self.norm2, code_ln)
+        # out-proj reads convex combinations of v = Wv LN1(x) + bv, MLP-down reads GELU(W1 LN2(x) + b1) with |GELU(h)| <= |h|: both inherit
+        # a bound from the norm's parameters and one weight matrix (bounded_code); `code` (gemm_precision='f16x2') overrides the check
+        c_o = code or bounded_code(self, 'o', code_ln, self.norm1, w[2 * E:], b[2 * E:])
+        c_d = code or bounded_code(self, 'd', code_ln, self.norm2, self.linear1.weight, self.linear1.bias)
         pw_qk = self._packed(('qk', c1), lambda: ops.pack_weight(w[:2 * E], b[:2 * E], bf16=c1), w, b)
         pw_v = self._packed(('v', c1), lambda: ops.pack_weight(w[2 * E:], b[2 * E:], bf16=c1), w, b)
-        pw_o = self._pw_conv(sa.out_proj, bf16=code)
+        pw_o = self._pw_conv(sa.out_proj, bf16=c_o)
         if pos is not None:
             t2, t2p = ops.layernorm(X, self.norm1.weight, self.norm1.bias, self.norm1.eps, pos=pos)
         else:
@@ -95,7 +99,7 @@ class TransformerSALayer(HipModule):
         X = ops.linear(a, pw_o, epilogue=EPI_RESIDUAL, res=X)
         t2 = ops.layernorm(X, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         h = ops.linear(t2, self._pw_conv('linear1', bf16=c2), epilogue=EPI_GELU)
-        return ops.linear(h, self._pw_conv('linear2', bf16=code), epilogue=EPI_RESIDUAL, res=X)
+        return ops.linear(h, self._pw_conv('linear2', bf16=c_d), epilogue=EPI_RESIDUAL, res=X)
 
     def forward(self, tgt, tgt_mask=None, tgt_key_padding_mask=None, query_pos=None):
         """tgt: (T=256, B, E) sequence-first like the reference."""
@@ -130,6 +134,24 @@ def ln_code(module, norm, code, pos=None):
                            lambda: float((norm.weight.detach().abs() * math.sqrt(norm.weight.numel() - 1) + norm.bias.detach().abs()).max())
                            + (0.0 if pos is None else float(pos.detach().abs().max())), *params)
     return ops.GSPLIT if bound < 32768.0 else 0
+
+
+def bounded_code(module, tag, code, norm, weight, bias):
+    """Operand code of a Linear layer whose input is bounded by max_n(|W| L + |b|)_n with L = |gamma| sqrt(C - 1) + |beta| the bound of
+    LayerNorm `norm`'s output and (W, b) the Linear layer in between (out-proj: the value projection -- attention outputs are convex
+    combinations of values; MLP-down: the MLP-up layer -- |GELU(h)| <= |h|): `code` while that stays inside the IEEE-half range of the
+    split-half token GEMM, else 0 (exact fp32).  One matrix-vector product per parameter version."""
+    if int(code) != ops.GSPLIT:
+        return int(code)
+
+    def bound():
+        L = norm.weight.detach().abs().float() * math.sqrt(norm.weight.numel() - 1) + norm.bias.detach().abs().float()
+        v = weight.detach().abs().float() @ L
+        if bias is not None:
+            v = v + bias.detach().abs().float()
+        return float(v.max())
+    params = (norm.weight, norm.bias, weight) + (() if bias is None else (bias,))
+    return ops.GSPLIT if module._packed(('lin_range', tag), bound, *params) < 32768.0 else 0
 
 
 class Fuse_sft_block(HipModule):
@@ -222,8 +244,10 @@ class CodeFormer(VQAutoEncoder):
         # Operand format of the Transformer's Linear layers (feat_emb, q|k / v / out projections, MLP, logits head): 'fp32' = exact fp32
         # MFMA GEMM; 'f16x2' = split-half operands (cf_gemm_split.hip) everywhere -- opt-in: the token GEMM has no range scale and the
         # inputs of out-proj / MLP-down / feat_emb are not bounded by anything the host can check; 'auto' (default) = split halves for the
-        # Linear layers that read a LayerNorm output (q|k, v, MLP-up, the logits head: 28 of 47 launches) when their bound
-        # |gamma| sqrt(C - 1) + |beta| (+ |pos|) stays inside the half range (ln_code) and `precision` is not 'fp32', exact fp32 elsewhere.
+        # Linear layers whose input the host can bound from parameters -- those behind a LayerNorm (q|k, v, MLP-up, the logits head:
+        # |gamma| sqrt(C - 1) + |beta| (+ |pos|), ln_code) and those one Linear layer further (out-proj, MLP-down: bounded_code), 46 of 47
+        # launches -- while the bound stays inside the half range and `precision` is not 'fp32'; exact fp32 elsewhere (feat_emb reads
+        # the un-normalised encoder feature).
         # Against fp64 the split-half GEMM is closer than the fp32-MFMA one (1.2e-6 vs 2.0e-6); logits / indices vs the reference unchanged.
         self.gemm_precision = os.environ.get('CODEFORMER_HIP_GEMM_PRECISION', 'auto')
         # Optional HIP-graph replay of the whole forward (one graph per input shape / w / flags): takes the ~250 host launches

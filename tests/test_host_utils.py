@@ -155,3 +155,19 @@ def test_stride2_space_to_depth_identity():
     assert zero_blocks == 7                                     # 16 tap x parity blocks, 9 taps
     got = F.conv2d(F.pad(X, (0, 1, 0, 1)), Wp, b)               # 2x2 taps at (i + ty, j + tx); beyond the last row / column: zero
     assert got.shape == ref.shape and float((got - ref).abs().max()) < 1e-12
+
+
+def test_linear_input_bounds_one_layer_behind_a_layernorm():
+    """bounded_code: out-proj / MLP-down take split-half operands while max_n(|W| L + |b|) stays inside the half range."""
+    import torch
+    from codeformer_amd import ops
+    from codeformer_amd.archs.codeformer_arch import TransformerSALayer, bounded_code
+    layer = TransformerSALayer(embed_dim=512, nhead=8, dim_mlp=1024)
+    w, b = layer.self_attn.in_proj_weight, layer.self_attn.in_proj_bias
+    assert bounded_code(layer, 'o', ops.GSPLIT, layer.norm1, w[1024:], b[1024:]) == ops.GSPLIT
+    assert bounded_code(layer, 'd', ops.GSPLIT, layer.norm2, layer.linear1.weight, layer.linear1.bias) == ops.GSPLIT
+    assert bounded_code(layer, 'd', 0, layer.norm2, layer.linear1.weight, layer.linear1.bias) == 0
+    with torch.no_grad():
+        layer.linear1.weight.mul_(500.0)                   # rows of ~1000 * 0.03 * 500 * sqrt(511): far outside
+    assert bounded_code(layer, 'd', ops.GSPLIT, layer.norm2, layer.linear1.weight, layer.linear1.bias) == 0
+    assert bounded_code(layer, 'o', ops.GSPLIT, layer.norm1, w[1024:], b[1024:]) == ops.GSPLIT

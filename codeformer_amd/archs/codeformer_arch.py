@@ -208,10 +208,12 @@ class CodeFormer(VQAutoEncoder):
                 for p in getattr(self, name).parameters():
                     p.requires_grad = False
 
-        # Operand format of the 3x3 stride-1 convolutions.  Tensors, accumulation, the Transformer and the code argmax are fp32 in every mode.
+        # Operand format of the convolutions (3x3 stride 1 / 2 / folded upsample and, for the split-half codes, the 1x1 skips on images).
+        # Tensors, accumulation, attention, statistics and the code argmax are fp32 in every mode; the Transformer's Linear layers: see
+        # gemm_precision.
         #   'f16x2' (default): fp32 operands split into hi + lo IEEE halves (22 significant bits), three f16 MFMAs per product, fp32
         #            accumulation, in the Winograd F(2x2,3x3) domain where the layer allows it (cf_wsplit.hip / cf_winograd.hip H2; folded
-        #            upsample convs: cf_split.hip), for generator, CFT and -- see encoder_precision -- the encoder.  Per layer at or below
+        #            upsample, stride-2 and image-sized 1x1 convs: cf_split.hip), for generator, CFT and -- see encoder_precision -- the encoder.  Per layer at or below
         #            the fp64-error of the exact kernels; whole network vs the reference on real crops: pixels 7.2e-5 (exact path
         #            7.1e-5; tolerance 1e-3), logits 6.7e-6 (exact: 7.6e-6; tolerance 1e-4), code indices identical.  1.5x the exact
         #            path's faces/s.

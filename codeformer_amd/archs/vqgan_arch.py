@@ -160,7 +160,8 @@ class ResBlock(HipModule):
             self.conv_out = nn.Conv2d(in_channels, oc, kernel_size=1, stride=1, padding=0)
 
     def forward_nhwc(self, x, x2=None, bf16=False):
-        """bf16=True: both 3x3 convs run on bf16 MFMA operands (fp32 accumulate / storage); the 1x1 skip stays fp32."""
+        """bf16: operand code of the two 3x3 convs (fp32 accumulate / storage); the 1x1 skip follows it only for split-half codes on images
+        (_skip_nhwc), otherwise it stays on the fp32 GEMM."""
         xs = (x,) if x2 is None else (x, x2)
         sc, sh = _gn_tables(self.norm1, *xs)
         hw = x.shape[1:3]

@@ -71,6 +71,27 @@ def test_argument_errors_are_reported_without_a_gpu(native):
     d.c0, d.acc_scale = 64, 0.0
     assert native.cf_conv2d(ctypes.byref(d), None) == -1 and 'acc_scale' in lib.last_error()
     assert native.cf_pack_conv_weight_f16x2(1, 64, 64, 0, 64, 64, 3.0, 1, None) == -1 and 'power of two' in lib.last_error()
+    # ABI v17: weight forms 2 (stride 2) / 3 (1x1 on images) and the descriptors they belong to
+    assert native.cf_pack_conv_weight_f16x2(1, 64, 64, 4, 64, 64, 2.0, 1, None) == -1 and 'form' in lib.last_error()
+    assert native.cf_pack_conv_weight_f16x2(1, 64, 20, 2, 64, 20, 2.0, 1, None) == -1 and 'padding' in lib.last_error()       # 4 * 20 % 32
+    assert native.cf_pack_conv_weight_f16x2(1, 64, 24, 2, 64, 24, 2.0, 1, None) == -1 and 'stride-2 form' in lib.last_error()  # cin % 16
+    assert native.cf_pack_conv_weight_f16x2(1, 64, 24, 2, 64, 32, 2.0, 1, None) == -1 and 'stride-2 form' in lib.last_error()  # padded cin
+    d = lib.ConvDesc(in0=1, weight=1, out=1, taps=9, stride=2, batch=1, hin=64, win=64, hout=32, wout=32, c0=64, cout=64,
+                     cout_pad=64, bf16_mfma=3, acc_scale=1.0, pad_lo=1)
+    assert native.cf_conv2d(ctypes.byref(d), None) == -1 and 'stride 2' in lib.last_error()         # symmetric padding: the fp32 kernel's
+    d.pad_lo, d.hin, d.hout = 0, 40, 20
+    assert native.cf_conv2d(ctypes.byref(d), None) == -1 and 'multiple of the 8x16 tile' in lib.last_error()
+    d = lib.ConvDesc(in0=1, weight=1, out=1, taps=1, stride=1, batch=1, hin=64, win=64, hout=64, wout=64, c0=48, cout=64,
+                     cout_pad=64, bf16_mfma=3, acc_scale=1.0)
+    assert native.cf_conv2d(ctypes.byref(d), None) == -1 and 'multiples of 32' in lib.last_error()  # 1x1 on an image: the convolution kernel's rules
+    d.c0, d.stats_out, d.stats_cpg = 64, 1, 2
+    assert native.cf_conv2d(ctypes.byref(d), None) == -1
+    # cf_act_scale_fused: statistics (one or two tensors) or a tensor, never both; cells and the table are required
+    assert native.cf_act_scale_fused(None, 0, None, 0, None, 0, 1, 4.0, 1, 1, None) == -1 and 'not both' in lib.last_error()
+    assert native.cf_act_scale_fused(1, 8, None, 0, 1, 1024, 1, 4.0, 1, 1, None) == -1 and 'not both' in lib.last_error()
+    assert native.cf_act_scale_fused(None, 0, 1, 8, 1, 1024, 1, 4.0, 1, 1, None) == -1
+    assert native.cf_act_scale_fused(None, 0, None, 0, 1, 1022, 1, 4.0, 1, 1, None) == -1 and 'multiple of 4' in lib.last_error()
+    assert native.cf_act_scale_fused(1, 8, None, 0, None, 0, 1, 4.0, None, 1, None) == -1
 
 
 def test_missing_library_is_a_loud_error(monkeypatch, tmp_path):

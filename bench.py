@@ -303,7 +303,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': {'fp32': 'f32', 'f16x2': 'f32 (tensors, accumulation; attention, AttnBlock 1x1, feat_emb and argmax on exact fp32 MFMA; 3x3 (stride 1, 2), image-sized 1x1 and the parameter-bounded Linear layers of the Transformer '
                                                   'products on split operands: fp32 = hi + lo IEEE halves, 3 f16 MFMAs per product)'}.get(
-                args.precision, f'{args.precision} operands / f32 accumulate (3x3 convs of generator + CFT); encoder and the Transformer's parameter-bounded Linear layers on split halves (hi + lo, fp32-grade); f32 (feat_emb, AttnBlock 1x1)'),
+                args.precision, f'{args.precision} operands / f32 accumulate (3x3 convs of generator + CFT); encoder and the parameter-bounded Linear layers of the Transformer on split halves (hi + lo, fp32-grade); f32 (feat_emb, AttnBlock 1x1)'),
             'data': 'synthetic',
             'config': {'workload': ({'fp32': 'BASELINE config 2 (IEEE fp32 arithmetic)',
                                      'f16x2': "BASELINE config 2 shapes and tensors; 3x3 products on split-half f16 operands (fp32-grade: meets the config's "

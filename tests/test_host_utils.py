@@ -171,3 +171,15 @@ def test_linear_input_bounds_one_layer_behind_a_layernorm():
         layer.linear1.weight.mul_(500.0)                   # rows of ~1000 * 0.03 * 500 * sqrt(511): far outside
     assert bounded_code(layer, 'd', ops.GSPLIT, layer.norm2, layer.linear1.weight, layer.linear1.bias) == 0
     assert bounded_code(layer, 'o', ops.GSPLIT, layer.norm1, w[1024:], b[1024:]) == ops.GSPLIT
+
+
+def test_entry_scripts_compile():
+    """bench.py / __graft_entry__.py / inference_codeformer.py and the tools are driver-facing scripts no CPU test imports: at least they
+    must compile (a quote inside an f-string once slipped through a GPU-less edit)."""
+    import glob
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [os.path.join(root, f) for f in ('bench.py', '__graft_entry__.py', 'inference_codeformer.py')] + sorted(glob.glob(os.path.join(root, 'tools', '*.py')))
+    assert len(files) > 10
+    for f in files:
+        compile(open(f).read(), f, 'exec')

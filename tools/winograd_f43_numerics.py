@@ -48,6 +48,29 @@ def winograd(x, w, BT, G, AT, m):
     return out
 
 
+def toom(points, m=4, r=3):
+    """Transforms of F(m, r) for the finite interpolation points `points` plus infinity (Toom-Cook).  AT and G follow from the points;
+    BT is solved from the bilinear identity AT [(G g) * (BT d)] = valid correlation of d with g (reproduces Lavin & Gray's matrices for
+    (0, 1, -1, 2, -2))."""
+    n = m + r - 1
+    p = np.array(points, np.float64)
+    AT, G = np.zeros((m, n)), np.zeros((n, r))
+    for j in range(n - 1):
+        AT[:, j] = p[j] ** np.arange(m)
+        G[j] = p[j] ** np.arange(r) / np.prod([p[j] - p[l] for l in range(n - 1) if l != j])
+    AT[m - 1, n - 1] = G[n - 1, r - 1] = 1.0
+    g0 = np.random.default_rng(1)
+    rows, rhs = [], []
+    for _ in range(80):
+        d, g = g0.standard_normal(n), g0.standard_normal(r)
+        for i in range(m):
+            rows.append(np.outer(AT[i] * (G @ g), d).ravel())
+            rhs.append(np.dot(d[i:i + r], g))
+    BT = np.linalg.lstsq(np.array(rows), np.array(rhs), rcond=None)[0].reshape(n, n)
+    BT[np.abs(BT) < 1e-12] = 0.0
+    return BT, G, AT
+
+
 x = rng.standard_normal((C, H, H))
 x = x / (1 + np.exp(-x))                                   # swish of N(0,1): what a GN-swish prologue hands the conv
 w = rng.standard_normal((C, C, 3, 3)) * np.sqrt(2.0 / (9 * C))
@@ -56,7 +79,10 @@ ref = np.zeros((C, H, H))
 for ky in range(3):
     for kx in range(3):
         ref += np.einsum('kc,chw->khw', w[:, :, ky, kx], xp[:, ky:ky + H, kx:kx + H])
-for name, (BT, G, AT, m) in (('F(2x2,3x3)', (BT2, G2, AT2, 2)), ('F(4x4,3x3)', (BT4, G4, AT4, 4))):
+cases = [('F(2x2,3x3)', (BT2, G2, AT2, 2)), ('F(4x4,3x3) points 0 +-1 +-2 inf (Lavin & Gray)', (BT4, G4, AT4, 4))]
+for pts in ((0, 1, -1, 0.5, -0.5), (0, 1, -1, 0.5, -2), (0, 1, -1, 2, -0.5), (0, 0.5, -0.5, 2, -2), (0, 1, -1, 1.5, -1.5)):
+    cases.append((f'F(4x4,3x3) points {pts} inf', toom(pts) + (4,)))
+for name, (BT, G, AT, m) in cases:
     y = winograd(xp, w, BT, G, AT, m)
     e = np.abs(y - ref)
     print(f'{name}: max err {e.max():.2e}  mean err {e.mean():.2e}  (output max {np.abs(ref).max():.2f}, C = {C}, {H}x{H})')

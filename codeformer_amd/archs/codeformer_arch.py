@@ -227,6 +227,10 @@ class CodeFormer(VQAutoEncoder):
         # stride-1 convolutions with Winograd F(2x2,3x3) -- the same function in fp32 with 2.25x fewer multiplies (cf_winograd.hip).
         # Set False (or CODEFORMER_HIP_WINOGRAD=0) for the direct evaluation everywhere.
         self.winograd = os.environ.get('CODEFORMER_HIP_WINOGRAD', '1') != '0'
+        # precision 'f16x2' only: generator / CFT layers the F(4x4,3x3) kernel covers (ops.f43_ok; which shapes: CODEFORMER_HIP_F43) run
+        # there -- 2.25 instead of 4 transform-domain products per output.  Its error against fp64 is ~5x that of F(2x2,3x3): far inside
+        # the pixel tolerance, never used in the encoder.  False / CODEFORMER_HIP_F43=0: F(2x2,3x3) everywhere.
+        self.winograd_f43 = ops.F43_LAYERS != '0'
         # Also evaluate the ENCODER's 3x3 stride-1 convolutions with Winograd, in every precision mode (the encoder is always
         # fp32, so logits / indices stay bitwise identical across 'fp32' / 'bf16' / 'fp16').  Measured against the reference:
         # logits 4.3e-6 (direct kernel 5.5e-6), lq_feat 1.0e-5 (1.4e-5), indices exact on every seeded face incl. one whose
@@ -328,6 +332,8 @@ class CodeFormer(VQAutoEncoder):
             bf16 = ops.WINOGRAD
         if bf16 == ops.SPLIT and not self.winograd:
             bf16 = ops.SPLIT_DIRECT
+        if bf16 == ops.SPLIT and self.winograd_f43:
+            bf16 = ops.SPLIT_F43   # generator + CFT only (this code never reaches the encoder, which decides the indices)
         gen_taps = None
         if w > 0:
             def fuse(t):
@@ -372,7 +378,7 @@ class CodeFormer(VQAutoEncoder):
     def _forward_graphed(self, x, w, code_only, adain):
         """Capture-once / replay-many execution of _forward_hip on the current stream.  Outputs are copies, so callers may
         keep them across calls.  A graph is re-captured when any packed weight was rebuilt since its capture."""
-        key = (tuple(x.shape), float(w), bool(code_only), bool(adain), self.precision, self.encoder_precision, self.gemm_precision, bool(self.winograd), bool(self.winograd_encoder), str(x.device))
+        key = (tuple(x.shape), float(w), bool(code_only), bool(adain), self.precision, self.encoder_precision, self.gemm_precision, bool(self.winograd), bool(self.winograd_encoder), bool(self.winograd_f43), str(x.device))
         ent = self._graphs.get(key)
         if ent is None or ent['epoch'] != PACK_EPOCH[0]:
             static_x = x.float().contiguous().clone()

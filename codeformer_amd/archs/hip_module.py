@@ -36,7 +36,7 @@ class HipModule(nn.Module):
         shapes they do not cover fall back as ops.conv_code says."""
         conv = getattr(self, name) if isinstance(name, str) else name
         code = 2 if f16 else int(bf16)
-        if code in (ops.WINOGRAD, ops.SPLIT, ops.SPLIT_DIRECT) or (code in (1, 2) and hw is not None and not up2x):
+        if code in (ops.WINOGRAD,) + ops.SPLIT_CODES or (code in (1, 2) and hw is not None and not up2x):
             cout, cin = conv.weight.shape[:2]
             if hw is None or tuple(conv.weight.shape[2:]) != (3, 3):
                 code = 0

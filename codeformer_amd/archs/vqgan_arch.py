@@ -112,7 +112,7 @@ class Downsample(HipModule):
         # split-half operands: the stride-2 form of cf_split.hip (a 2x2 convolution of the space-to-depth view of x); the input is the
         # un-normalised residual stream, so it carries a range scale.  The single-operand modes keep the exact kernel (as Upsample does).
         cin, cout = self.conv.in_channels, self.conv.out_channels
-        if int(bf16) in (2, ops.SPLIT, ops.SPLIT_DIRECT) and ops.split_s2_ok(cin, cout, x.shape[1], x.shape[2]):
+        if int(bf16) in (2,) + ops.SPLIT_CODES and ops.split_s2_ok(cin, cout, x.shape[1], x.shape[2]):
             pw = self._packed(('conv', 's2'), lambda: ops.pack_weight(self.conv.weight, self.conv.bias, bf16=ops.SPLIT, stride2=True),
                               self.conv.weight, self.conv.bias)
             return ops.conv2d(x, pw, stride=2, emit_stats=True, act=ops.act_scale(x))
@@ -182,7 +182,7 @@ class ResBlock(HipModule):
         through the split-half convolution kernel (these layers are HBM-bound; the fp32 MFMA GEMM holds them at 2-4 TB/s); the input
         is the un-normalised block input, so it carries a range scale -- one table for both halves of a concatenated input."""
         c_split = None if x2 is None else x.shape[3]
-        if int(code) in (2, ops.SPLIT, ops.SPLIT_DIRECT) and ops.RANGE_SCALE and \
+        if int(code) in (2,) + ops.SPLIT_CODES and ops.RANGE_SCALE and \
                 ops.split_1x1_ok(self.in_channels, self.out_channels, x.shape[1], x.shape[2], c_split):
             pw = self._packed(('conv_out', 'f16x2'), lambda: ops.pack_weight(self.conv_out.weight, self.conv_out.bias, bf16=ops.SPLIT),
                               self.conv_out.weight, self.conv_out.bias)

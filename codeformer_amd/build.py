@@ -12,7 +12,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, 'csrc')
 ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, 'libcodeformer_hip.so')
-SOURCES = ['cf_igemm.hip', 'cf_winograd.hip', 'cf_split.hip', 'cf_wsplit.hip', 'cf_gemm_split.hip', 'cf_norm.hip', 'cf_attention.hip', 'cf_misc.hip', 'cf_paste.hip']
+SOURCES = ['cf_igemm.hip', 'cf_winograd.hip', 'cf_split.hip', 'cf_wsplit.hip', 'cf_wf43.hip', 'cf_gemm_split.hip', 'cf_norm.hip', 'cf_attention.hip', 'cf_misc.hip', 'cf_paste.hip']
 
 
 def _hipcc():

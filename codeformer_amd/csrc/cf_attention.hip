@@ -368,34 +368,13 @@ extern "C" int cf_attention(const float* q, int ldq, const float* k, int ldk, co
              "cf_attention: bad dims");
   const dim3 grid(NKEY / BQ, heads, batch), block(256);
   if (head_dim == 64) {
-    static unsigned long long attr6_devs = 0;  // bit d: LDS attribute set on device d
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev >= 64 || !((attr6_devs >> dev) & 1ull)) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)A6_LDS_BYTES);
-      if (e != hipSuccess) {
-        cf_set_error("cf_attention: hipFuncSetAttribute(%zu B LDS): %s", A6_LDS_BYTES, hipGetErrorString(e));
-        return CF_ERR_LAUNCH;
-      }
-      if (dev < 64) attr6_devs |= 1ull << dev;  // benign race: the attribute call is idempotent
-    }
+    CF_LDS_ATTR(attn64_kernel, A6_LDS_BYTES);  // (cf_device_init sets the dynamic-LDS attribute on each device)
     if (CF_ATTN64_GENERIC)
       hipLaunchKernelGGL(attn_kernel<64>, grid, block, 0, (hipStream_t)stream, q, ldq, k, ldk, v, ldv, out, ldo, scale);
     else
       hipLaunchKernelGGL(attn64_kernel, grid, block, A6_LDS_BYTES, (hipStream_t)stream, q, ldq, k, ldk, v, ldv, out, ldo, scale);
   } else if (head_dim == 512) {
-    static unsigned long long attr_devs = 0;  // bit d: LDS attribute set on device d
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev >= 64 || !((attr_devs >> dev) & 1ull)) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn512_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)A5_LDS_BYTES);
-      if (e != hipSuccess) {
-        cf_set_error("cf_attention: hipFuncSetAttribute(%zu B LDS): %s", A5_LDS_BYTES, hipGetErrorString(e));
-        return CF_ERR_LAUNCH;
-      }
-      if (dev < 64) attr_devs |= 1ull << dev;  // benign race: the attribute call is idempotent
-    }
+    CF_LDS_ATTR(attn512_kernel, A5_LDS_BYTES);
     hipLaunchKernelGGL(attn512_kernel, dim3(NKEY / BQ, heads * 2, batch), dim3(A5_THREADS), A5_LDS_BYTES, (hipStream_t)stream, q, ldq,
                        k, ldk, v, ldv, out, ldo, scale);
   } else {

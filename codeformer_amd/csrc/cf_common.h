@@ -29,6 +29,17 @@ void cf_set_error(const char* fmt, ...);
     }                                                                           \
   } while (0)
 
+// Kernels that launch with more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize, a PER-DEVICE property of the
+// function.  The library keeps no mutable state: every such kernel enters a table while the shared object's static initialisers run
+// (cf_lds_attr<kernel, bytes>::reg below, named by its launch site; the table is constant afterwards) and cf_device_init() -- called once
+// per device by the host, codeformer_amd/lib.py -- sets the attribute of every entry on the current device.
+int cf_register_kernel_lds(const void* kernel, int lds_bytes);  // cf_misc.hip
+template <auto Kernel, int LdsBytes>
+struct cf_lds_attr {
+  static inline const int reg = cf_register_kernel_lds(reinterpret_cast<const void*>(Kernel), LdsBytes);
+};
+#define CF_LDS_ATTR(kernel, bytes) ((void)cf_lds_attr<kernel, (int)(bytes)>::reg)
+
 // K-slab geometry shared by every MFMA kernel: a slab is 16 k-values wide; LDS rows are padded to
 // 20 floats (80 B) so that 16 consecutive rows hit 16 distinct 16-byte bank slots under ds_read_b128.
 constexpr int CF_BK = 16;

@@ -1137,20 +1137,9 @@ int launch(const ConvArgsExt& a, hipStream_t stream, int* parts_query) {
     return CF_OK;
   }
   k.ntn = a.cout_pad / C::BN;
-  auto kern = igemm_kernel<TAPS, STRIDE, WM, WN, MI, NI, IN_NCHW, BF16, EXT, F16>;
+  constexpr auto kern = igemm_kernel<TAPS, STRIDE, WM, WN, MI, NI, IN_NCHW, BF16, EXT, F16>;
   constexpr size_t lds = C::LDS_FLOATS * sizeof(float);
-  static unsigned long long attr_devs = 0;  // bit d: attribute set on device d (it is a per-device property of the function)
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev >= 64 || !((attr_devs >> dev) & 1ull)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-      cf_set_error("cf_conv2d: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
-      return CF_ERR_LAUNCH;
-    }
-    if (dev < 64) attr_devs |= 1ull << dev;  // benign race: the attribute call is idempotent
-  }
+  CF_LDS_ATTR(kern, lds);  // (cf_device_init sets the dynamic-LDS attribute on each device)
   hipLaunchKernelGGL(kern, dim3(mtiles * k.ntn), dim3(256), lds, stream, k);
   CF_CHECK_LAUNCH("cf_conv2d");
   return CF_OK;
@@ -1178,19 +1167,9 @@ int launch_sk(const ConvArgsExt& a, float* ws, unsigned* counters, int nsplit, h
   k.ws = ws;
   k.counters = counters;
   k.nsplit = nsplit;
-  auto kern = igemm_kernel<1, 1, WM, WN, MI, NI, false, false, false, false, true>;
+  constexpr auto kern = igemm_kernel<1, 1, WM, WN, MI, NI, false, false, false, false, true>;
   constexpr size_t lds = C::LDS_FLOATS * sizeof(float);
-  static unsigned long long attr_devs = 0;
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev >= 64 || !((attr_devs >> dev) & 1ull)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-      cf_set_error("cf_conv2d: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
-      return CF_ERR_LAUNCH;
-    }
-    if (dev < 64) attr_devs |= 1ull << dev;
-  }
+  CF_LDS_ATTR(kern, lds);
   hipLaunchKernelGGL(kern, dim3(mtiles * k.ntn * nsplit), dim3(256), lds, stream, k);
   CF_CHECK_LAUNCH("cf_conv2d(split-K)");
   return CF_OK;
@@ -1323,6 +1302,7 @@ extern "C" int cf_pack_conv_weight(const float* w, int cout, int cin, int taps, 
 }
 
 int cf_winograd_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query);  // cf_winograd.hip
+int cf_wf43_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query);      // cf_wf43.hip
 int cf_gemm_split_launch(const cf_conv_desc* d, hipStream_t stream);                     // cf_gemm_split.hip
 int cf_gemm_split_geometry(const cf_conv_desc* d, int* tiles, long* bytes_per_part);
 int cf_split_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query);     // cf_split.hip
@@ -1416,6 +1396,8 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
     if ((long)d->hout * d->wout > CF_TOKEN_IMAGE_MAX) return cf_split_launch(d, stream, pq);
     return cf_gemm_split_launch(d, stream);
   }
+  if (d->winograd == 2) return cf_wf43_launch(d, stream, pq);  // F(4x4,3x3), split-half operands (cf_wf43.hip)
+  CF_REQUIRE(d->winograd == 0 || d->winograd == 1, "cf_conv2d: winograd must be 0, 1 (F(2x2,3x3)) or 2 (F(4x4,3x3)), got %d", d->winograd);
   if (d->winograd) return cf_winograd_launch(d, stream, pq);  // fp32 or split-half operands
   if (d->bf16_mfma == CF_OPERAND_F16X2) return cf_split_launch(d, stream, pq);
 

@@ -711,19 +711,9 @@ template <int TAPS, int NI, bool S2 = false>
 int split_launch(SplitArgs& k, int batch, hipStream_t stream) {
   using C = SplitCfg<TAPS, NI, SP_WM>;
   k.ntn = k.cout_pad / C::BN;
-  auto kern = split_conv_kernel<TAPS, NI, SP_WM, S2>;
+  constexpr auto kern = split_conv_kernel<TAPS, NI, SP_WM, S2>;
   constexpr size_t lds = C::LDS_FLOATS * sizeof(float);
-  static unsigned long long attr_devs = 0;  // bit d: the LDS attribute has been set on device d (it is a per-device property)
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev >= 64 || !((attr_devs >> dev) & 1ull)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-      cf_set_error("cf_conv2d(f16x2): hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
-      return CF_ERR_LAUNCH;
-    }
-    if (dev < 64) attr_devs |= 1ull << dev;  // benign race: the attribute call is idempotent
-  }
+  CF_LDS_ATTR(kern, lds);  // (cf_device_init sets the dynamic-LDS attribute on each device)
   hipLaunchKernelGGL(kern, dim3(k.tiles_per_img * batch * k.ntn), dim3(C::NT), lds, stream, k);
   CF_CHECK_LAUNCH("cf_conv2d(f16x2)");
   return CF_OK;

@@ -722,20 +722,11 @@ int cf_winograd_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_que
                "cf_conv2d(winograd): split_k %d needs cin %% 128 == 0 and split_k dividing cin/128 = %d", d->split_k, V);
     CF_REQUIRE(d->split_k == 1 || (d->workspace && d->counters), "cf_conv2d(winograd): split_k > 1 needs workspace and counters");
   }
-  const void* const kerns[4] = {reinterpret_cast<const void*>(winograd_kernel<false, false>), reinterpret_cast<const void*>(winograd_kernel<true, false>),
-                                reinterpret_cast<const void*>(winograd_kernel<false, true>), reinterpret_cast<const void*>(winograd_kernel<true, true>)};
-  const int ki = (h2 ? 2 : 0) + (sk ? 1 : 0);
-  static unsigned long long attr_devs[4] = {0, 0, 0, 0};  // bit d: attribute set on device d (a per-device property), per instantiation
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev >= 64 || !((attr_devs[ki] >> dev) & 1ull)) {
-    hipError_t e = hipFuncSetAttribute(kerns[ki], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-      cf_set_error("cf_conv2d: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
-      return CF_ERR_LAUNCH;
-    }
-    if (dev < 64) attr_devs[ki] |= 1ull << dev;  // benign race: the attribute call is idempotent
-  }
+  // (cf_device_init sets the dynamic-LDS attribute of these four on each device)
+  CF_LDS_ATTR((winograd_kernel<false, false>), (WG_PATCH_FLOATS + WG_V_FLOATS) * sizeof(float));
+  CF_LDS_ATTR((winograd_kernel<false, true>), (WG_PATCH_FLOATS + WG_V_FLOATS) * sizeof(float));
+  CF_LDS_ATTR((winograd_kernel<true, false>), (WG_PATCH_FLOATS + WG_V_FLOATS + WG_NI * 4 * 256 * 4) * sizeof(float));
+  CF_LDS_ATTR((winograd_kernel<true, true>), (WG_PATCH_FLOATS + WG_V_FLOATS + WG_NI * 4 * 256 * 4) * sizeof(float));
   const int tiles = a.tiles_per_img * d->batch * a.ntn;
   if (sk) {
     WinoArgsSK k;

@@ -513,25 +513,19 @@ int cf_wsplit_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query
     return CF_OK;
   }
   constexpr size_t lds = WS_LDS_FLOATS * sizeof(float);
-  static unsigned long long attr_devs = 0;  // bit d: the LDS attribute has been set on device d (a per-device property)
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev >= 64 || !((attr_devs >> dev) & 1ull)) {
-    hipError_t e = hipSuccess;
-    const void* const kerns[12] = {
-        reinterpret_cast<const void*>(wsplit_kernel<CF_PRO_NONE>), reinterpret_cast<const void*>(wsplit_kernel<CF_PRO_AFFINE>),
-        reinterpret_cast<const void*>(wsplit_kernel<CF_PRO_AFFINE_SWISH>), reinterpret_cast<const void*>(wsplit_kernel<CF_PRO_LEAKY>),
-        reinterpret_cast<const void*>(wsplit_kernel<CF_PRO_NONE, CF_OPERAND_F16>), reinterpret_cast<const void*>(wsplit_kernel<CF_PRO_AFFINE, CF_OPERAND_F16>),
-        reinterpret_cast<const void*>(wsplit_kernel<CF_PRO_AFFINE_SWISH, CF_OPERAND_F16>), reinterpret_cast<const void*>(wsplit_kernel<CF_PRO_LEAKY, CF_OPERAND_F16>),
-        reinterpret_cast<const void*>(wsplit_kernel<CF_PRO_NONE, CF_OPERAND_BF16>), reinterpret_cast<const void*>(wsplit_kernel<CF_PRO_AFFINE, CF_OPERAND_BF16>),
-        reinterpret_cast<const void*>(wsplit_kernel<CF_PRO_AFFINE_SWISH, CF_OPERAND_BF16>), reinterpret_cast<const void*>(wsplit_kernel<CF_PRO_LEAKY, CF_OPERAND_BF16>)};
-    for (int i = 0; i < 12 && e == hipSuccess; ++i) e = hipFuncSetAttribute(kerns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-      cf_set_error("cf_conv2d(winograd f16x2): hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
-      return CF_ERR_LAUNCH;
-    }
-    if (dev < 64) attr_devs |= 1ull << dev;  // benign race: the attribute call is idempotent
-  }
+  // (cf_device_init sets the dynamic-LDS attribute of the twelve instantiations on each device)
+  CF_LDS_ATTR((wsplit_kernel<CF_PRO_NONE>), lds);
+  CF_LDS_ATTR((wsplit_kernel<CF_PRO_AFFINE>), lds);
+  CF_LDS_ATTR((wsplit_kernel<CF_PRO_AFFINE_SWISH>), lds);
+  CF_LDS_ATTR((wsplit_kernel<CF_PRO_LEAKY>), lds);
+  CF_LDS_ATTR((wsplit_kernel<CF_PRO_NONE, CF_OPERAND_F16>), lds);
+  CF_LDS_ATTR((wsplit_kernel<CF_PRO_AFFINE, CF_OPERAND_F16>), lds);
+  CF_LDS_ATTR((wsplit_kernel<CF_PRO_AFFINE_SWISH, CF_OPERAND_F16>), lds);
+  CF_LDS_ATTR((wsplit_kernel<CF_PRO_LEAKY, CF_OPERAND_F16>), lds);
+  CF_LDS_ATTR((wsplit_kernel<CF_PRO_NONE, CF_OPERAND_BF16>), lds);
+  CF_LDS_ATTR((wsplit_kernel<CF_PRO_AFFINE, CF_OPERAND_BF16>), lds);
+  CF_LDS_ATTR((wsplit_kernel<CF_PRO_AFFINE_SWISH, CF_OPERAND_BF16>), lds);
+  CF_LDS_ATTR((wsplit_kernel<CF_PRO_LEAKY, CF_OPERAND_BF16>), lds);
   const dim3 grid(a.tiles_per_img * d->batch * a.ntn), block(WS_THREADS);
   auto launch_op = [&](auto op) {
     constexpr int OP = decltype(op)::value;

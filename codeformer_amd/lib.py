@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('CF_LIB_PATH') or os.path.join(_PKG, 'libcodeformer_hi
 
 c_float_p = ctypes.c_void_p  # device pointers are passed as integers
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 PRO_NONE, PRO_AFFINE, PRO_AFFINE_SWISH, PRO_LEAKY = 0, 1, 2, 3
 EPI_NONE, EPI_RESIDUAL, EPI_SFT, EPI_GELU, EPI_LEAKY, EPI_AXPY, EPI_AXPY2 = 0, 1, 2, 3, 4, 5, 6
 PAD_ZERO, PAD_REFLECT, PAD_EDGE = 0, 1, 2
@@ -52,6 +52,7 @@ SIGNATURES = {
     'cf_last_error': (ctypes.c_char_p, []),
     'cf_build_id': (ctypes.c_char_p, []),
     'cf_device_cu_count': (_I, []),
+    'cf_device_init': (_I, []),
     'cf_conv2d': (_I, [ctypes.POINTER(ConvDesc), _P]),
     'cf_conv2d_stats_parts': (_I, [ctypes.POINTER(ConvDesc)]),
     'cf_conv2d_workspace_bytes': (_L, [ctypes.POINTER(ConvDesc)]),
@@ -64,6 +65,7 @@ SIGNATURES = {
     'cf_pack_conv_weight_winograd': (_I, [_P, _I, _I, _I, _I, _P, _P]),
     'cf_pack_conv_weight_winograd_f16x2': (_I, [_P, _I, _I, _I, _I, _F, _P, _P]),
     'cf_pack_conv_weight_winograd_bf16': (_I, [_P, _I, _I, _I, _I, _F, _P, _P]),
+    'cf_pack_conv_weight_winograd43_f16x2': (_I, [_P, _I, _I, _I, _I, _F, _P, _P]),
     'cf_pack_linear_weight_f16x2': (_I, [_P, _I, _I, _F, _P, _P]),
     'cf_pack_conv_weight_up2x_bf16': (_I, [_P, _I, _I, _I, _I, _P, _P]),
     'cf_pack_conv_weight_up2x_f16': (_I, [_P, _I, _I, _I, _I, _P, _P]),
@@ -102,6 +104,8 @@ SIGNATURES = {
 }
 
 _lib = None
+_cuda = None      # torch.cuda.is_available(), asked once
+_devices = set()   # devices cf_device_init() has run on (the library itself keeps no such state)
 
 
 class NativeLibraryError(RuntimeError):
@@ -109,10 +113,22 @@ class NativeLibraryError(RuntimeError):
 
 
 def load():
-    """Load the shared object (once).  Raises NativeLibraryError if it is absent -- never falls back."""
+    """The shared object (loaded once), with cf_device_init() done on the current CUDA (ROCm) device.  Raises NativeLibraryError if
+    the file is absent -- never falls back."""
+    global _cuda
+    lib = _lib if _lib is not None else _open()
+    if _cuda is None:
+        _cuda = torch.cuda.is_available()
+    if _cuda:
+        dev = torch.cuda.current_device()
+        if dev not in _devices:   # per-device kernel attributes (dynamic LDS above 64 KB), once per device and process
+            check(lib.cf_device_init(), 'cf_device_init')
+            _devices.add(dev)
+    return lib
+
+
+def _open():
     global _lib
-    if _lib is not None:
-        return _lib
     if not os.path.exists(LIB_PATH):
         raise NativeLibraryError(
             f'{LIB_PATH} not found: build it with `python -m codeformer_amd.build` (hipcc --offload-arch=gfx950). '
@@ -136,7 +152,8 @@ def is_available():
 
 
 def last_error():
-    return load().cf_last_error().decode('utf-8', 'replace')
+    lib = _lib if _lib is not None else _open()   # (not load(): a failing cf_device_init reports through here)
+    return lib.cf_last_error().decode('utf-8', 'replace')
 
 
 def check(status, what):

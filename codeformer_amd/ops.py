@@ -67,7 +67,10 @@ WSPLIT = 6     # ... Winograd F(2x2,3x3) with split-half operands in the 16 tran
 GSPLIT = 7     # ... a Linear / 1x1 weight for the split-half token GEMM (cf_gemm_split.hip)
 WF16 = 8       # ... Winograd F(2x2,3x3) with SINGLE IEEE-half operands (eight-wave kernel of cf_wsplit.hip; precision 'fp16')
 WBF16 = 9      # ... the same with single bf16 operands (precision 'bf16')
-OPERAND_F16X2 = 3   # enum cf_operand value behind SPLIT / WSPLIT / GSPLIT
+SPLIT_F43 = 10  # ... REQUEST: SPLIT, with Winograd F(4x4,3x3) where its kernel applies (generator / CFT layers only: ~5x the error of F(2,3))
+WF43 = 11      # ... Winograd F(4x4,3x3) with split-half operands (cf_wf43.hip; cf_conv_desc.winograd = 2)
+OPERAND_F16X2 = 3   # enum cf_operand value behind SPLIT / WSPLIT / GSPLIT / WF43
+SPLIT_CODES = (SPLIT, SPLIT_DIRECT, SPLIT_F43)   # requested codes that put un-normalised inputs / stride-2 / 1x1 layers on the split-half kernels
 # SPLIT layers that the Winograd kernel covers take its split-half form (4/9 of the MFMA work); CODEFORMER_HIP_SPLIT_WINOGRAD=0
 # keeps them on the direct split-half kernel.
 SPLIT_WINOGRAD = os.environ.get('CODEFORMER_HIP_SPLIT_WINOGRAD', '1') != '0'
@@ -95,6 +98,18 @@ def winograd_ok(cin, cout, hout, wout):
     return cin % 16 == 0 and cout % 64 == 0 and hout % 8 == 0 and wout % 16 == 0
 
 
+# Which layers a SPLIT_F43 request puts on the F(4x4,3x3) kernel: 'c64' (default) = layers with 64 output channels (one 64-channel
+# workgroup covers the layer: the 512x512 ResBlocks of the generator), 'all' = every shape it covers, '0' = none (A/B).
+F43_LAYERS = os.environ.get('CODEFORMER_HIP_F43', 'c64')
+
+
+def f43_ok(cin, cout, hout, wout):
+    """Shapes the F(4x4,3x3) kernel covers (3x3 stride-1 dense NHWC): whole 16x32 output patches, 64-wide channel tiles."""
+    if F43_LAYERS == '0' or (F43_LAYERS == 'c64' and cout != 64):
+        return False
+    return cin % 16 == 0 and cin <= 512 and cout % 64 == 0 and hout % 16 == 0 and wout % 32 == 0
+
+
 # Smallest per-image input of the DIRECT split-half kernel and of the eight-wave Winograd kernel.  The 16x16 latents are below it: with
 # SPLIT they run the four-wave Winograd kernel on split halves with split-K (conv_code -> WSPLIT: measured on the reference's crops
 # before it became the default, profiles/r02_encoder_split_check.txt), with SPLIT_DIRECT they stay on the exact fp32 kernel.
@@ -112,11 +127,19 @@ def wsingle_ok(cin, cout, h, w):
 WINOGRAD_16BIT = os.environ.get('CODEFORMER_HIP_WINOGRAD_16BIT', '1') != '0'
 
 
+def c_split_ok(c_split, slab):
+    return c_split is None or c_split % slab == 0
+
+
 def conv_code(code, cin, cout, h, w, up2x=False, c_split=None, plain=True):
     """Operand code a 3x3 stride-1 convolution really runs with, given the requested one and its shape ((h, w) = INPUT size).
     SPLIT falls back to WINOGRAD and WINOGRAD to the direct fp32 kernel where their kernels do not apply; the decision depends
     on the per-image shape only (never on the batch), so results stay batch-invariant."""
     code = int(code)
+    if code == SPLIT_F43:
+        if plain and not up2x and c_split_ok(c_split, 16) and f43_ok(cin, cout, h, w):
+            return WF43
+        code = SPLIT
     if code in (SPLIT, SPLIT_DIRECT):
         if code == SPLIT and SPLIT_WINOGRAD and plain and not up2x and winograd_ok(cin, cout, h, w):
             return WSPLIT
@@ -215,7 +238,7 @@ def gn_range_ok(gmax, bmax, n):
 def exact_code(code):
     """Operand code of the exact-fp32 evaluation that replaces a 16-bit-operand code (range fallback); bf16 has fp32's exponent."""
     code = int(code)
-    return {SPLIT: WINOGRAD, SPLIT_DIRECT: 0, 2: WINOGRAD}.get(code, code)
+    return {SPLIT: WINOGRAD, SPLIT_F43: WINOGRAD, SPLIT_DIRECT: 0, 2: WINOGRAD}.get(code, code)
 
 
 def pack_weight(weight, bias=None, bf16=False, up2x=False, f16=False, stride2=False):
@@ -246,6 +269,18 @@ def pack_weight(weight, bias=None, bf16=False, up2x=False, f16=False, stride2=Fa
         L.check(lib.cf_pack_linear_weight_f16x2(L.ptr(w2.contiguous()), cout, cin, scale, L.ptr(packed, dtype=None), L.stream_ptr()),
                 'cf_pack_linear_weight_f16x2')
         return PackedWeight(packed, b, cout, cin, 1, cout, cin, bf16=OPERAND_F16X2, scale=scale)
+    if code == WF43:
+        if up2x or w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or cin % 16 or cout % 64:
+            raise ValueError('winograd F(4,3) f16x2 packing needs a 3x3 weight with cin % 16 == 0 and cout % 64 == 0 (no up2x)')
+        # max |G' g G'^T| for the power-of-two scale; G' = D^-1 G of the points (0, +-1/2, +-2, inf), the matrix cf_wf43.hip documents
+        Gm = torch.tensor([[4.0, 0.0, 0.0], [-32 / 15, -16 / 15, -8 / 15], [-32 / 15, 16 / 15, -8 / 15], [1 / 15, 2 / 15, 4 / 15],
+                           [1 / 15, -2 / 15, 4 / 15], [0.0, 0.0, 4.0]], dtype=torch.float64, device=w.device)
+        umax = float(torch.einsum('xa,kcab,yb->kcxy', Gm, w.double(), Gm).abs().max())
+        scale = 1.0 if umax == 0.0 or not math.isfinite(umax) else 2.0 ** (14 - math.frexp(umax)[1] + 1)
+        packed = torch.empty(36 * cin * cout, dtype=torch.float32, device=w.device)
+        L.check(lib.cf_pack_conv_weight_winograd43_f16x2(L.ptr(w), cout, cin, cout, cin, scale, L.ptr(packed, dtype=None), L.stream_ptr()),
+                'cf_pack_conv_weight_winograd43_f16x2')
+        return PackedWeight(packed, b, cout, cin, 9, cout, cin, bf16=OPERAND_F16X2, wino=2, scale=scale)
     if code in (WSPLIT, WF16, WBF16):
         if up2x or w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or cin % 16 or cout % 64:
             raise ValueError('winograd f16x2 packing needs a 3x3 weight with cin % 16 == 0 and cout % 64 == 0 (no up2x)')
@@ -344,6 +379,8 @@ def splitk_for(pw, ho, wo, cin, batch=1):
     """Split count for a 1x1 / Linear or a Winograd 3x3 on `batch` images of ho x wo pixels; 0: the layer is not a split-K layer."""
     if SPLITK_MAX <= 0 or (pw.bf16 and not pw.wino and pw.taps != 1) or ho * wo > 1024 or cin % 128:
         return 0
+    if pw.wino == 2:
+        return 0   # (F(4x4,3x3) has no split-K form)
     if pw.wino:
         if ho % 8 or wo % 16 or ho * wo > 256:   # the 16x16 latents only: from 32x32 up a batch fills the CUs without splitting
             return 0
@@ -485,7 +522,9 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
         kind += ('', '_bf16', '_f16', '_f16x2')[int(pw.bf16)]
     if pw.conv1:
         kind = 'conv1x1_stream_f16x2'   # 1x1 on images through the split-half convolution kernel (HBM-bound), not the token GEMM
-    if pw.wino and pw.bf16 and pw.cout % 128 == 0 and Ho * Wo >= 1024 and not split_k:
+    if pw.wino == 2:
+        kind = 'conv3x3_wino43_f16x2'   # F(4x4,3x3) on split halves (cf_wf43.hip)
+    elif pw.wino and pw.bf16 and pw.cout % 128 == 0 and Ho * Wo >= 1024 and not split_k:
         kind += '_8w'      # the eight-wave 128-channel kernel (cf_wsplit.hip; the rule of cf_wsplit_covers)
     PROFILE.append((kind, flops, nbytes, e0, e1, (B, H, W, cin, pw.cout)))
     return out

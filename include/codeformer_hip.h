@@ -12,7 +12,10 @@
  *   - every pointer is a DEVICE pointer owned by the caller (torch.empty allocations);
  *   - every function only ENQUEUES work on `stream` (a hipStream_t passed as void*);
  *     nothing synchronises, nothing allocates, there is no global mutable state
- *     besides the thread-local last-error string;
+ *     besides the thread-local last-error string (the table cf_device_init() walks is
+ *     filled while the library loads and constant afterwards);
+ *   - cf_device_init() is called once per device (with that device current) before the
+ *     first launch there: kernels with more than 64 KB of dynamic LDS fail to launch without it;
  *   - return 0 on success, <0 on error (cf_last_error() describes it);
  *   - activations are fp32, channels-last ("NHWC": [batch][h][w][c]) unless a flag
  *     says NCHW; token matrices are row-major [rows][cols] (the same memory).
@@ -26,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 17
+#define CF_ABI_VERSION 18
 
 typedef void* cf_stream_t; /* hipStream_t */
 
@@ -43,6 +46,11 @@ const char* cf_build_id(void);
 const char* cf_last_error(void);
 /* number of compute units of the current device (for host-side grid heuristics) */
 int cf_device_cu_count(void);
+/* Per-device setup (ABI v18): sets hipFuncAttributeMaxDynamicSharedMemorySize -- a per-device property of a function -- for every
+ * kernel of the library that launches with more than 64 KB of dynamic LDS, on the CURRENT device.  Idempotent; call it once per
+ * device before the first launch there (codeformer_amd/lib.py does, keyed by torch.cuda.current_device()).  Until v17 every launch
+ * site kept a function-static bitmap of initialised devices instead -- mutable state this header promises not to have. */
+int cf_device_init(void);
 
 /* ---- convolution / linear as implicit GEMM on fp32 MFMA ------------------------------------
  * Replaces: F.conv2d 3x3 s1 p1 (vqgan_arch.py:132,147,149,243,266,292,314; codeformer_arch.py:142-149),
@@ -148,7 +156,15 @@ typedef struct cf_conv_desc {
                              the 16 Winograd-domain GEMMs run on split operands: U and V as hi + lo IEEE halves, three f16
                              MFMAs per product, fp32 accumulation -- 4/9 of the split-half MFMA work of the direct form.
                              With CF_OPERAND_F16 / CF_OPERAND_BF16 (cout % 128 == 0, >= 32x32 pixels): single rounded operands,
-                             one MFMA per product (weight: see cf_pack_conv_weight_winograd_bf16) */
+                             one MFMA per product (weight: see cf_pack_conv_weight_winograd_bf16).
+                             2 (ABI v18): Winograd F(4x4,3x3) with CF_OPERAND_F16X2 operands only (`weight` from
+                             cf_pack_conv_weight_winograd43_f16x2, acc_scale set): 36 transform-domain GEMMs per 4x4 outputs = 2.25
+                             products per output and input channel instead of 4, interpolation points (0, +-1/2, +-2, inf).  Dense
+                             NHWC, zero padding, hout % 16 == 0, wout % 32 == 0, cout == cout_pad, cout % 64 == 0, cin % 16 == 0,
+                             cin <= 512; prologues / epilogues / statistics / act_scale as winograd 1, no split_k.  Its error
+                             against fp64 is ~5x that of F(2x2,3x3) (the conditioning of the larger transform), far inside the
+                             1e-3 pixel gate but too close for layers that decide code indices: the host uses it for generator /
+                             CFT convolutions only (vqgan_arch.py:296-323, codeformer_arch.py:136-157), never in the encoder */
   float acc_scale;        /* CF_OPERAND_F16X2 only (direct or winograd): the accumulator is multiplied by this before the bias is added -- the exact
                              inverse of the power-of-two scale given to cf_pack_conv_weight_f16x2 (> 0) */
   /* Deterministic split-K for layers with few output tiles (one face: 16x16 .. 64x64 pixels), where latency is the serial K loop of
@@ -189,6 +205,12 @@ int cf_pack_conv_weight_winograd(const float* w, int cout, int cin, int cout_pad
  * words); `scale` is a power of two that puts max|scale * U| into [2^14, 2^15) (cf_conv_desc.acc_scale = 1 / scale) */
 int cf_pack_conv_weight_winograd_f16x2(const float* w, int cout, int cin, int cout_pad, int cin_pad, float scale, void* packed,
                                        cf_stream_t stream);
+/* winograd == 2 (F(4x4,3x3)) + CF_OPERAND_F16X2: scale * U', U' = G' g G'^T with the rows of G scaled by (4, 4, 4, 2, 2, 4) (the input
+ * transform carries the inverse powers of two), as hi + lo IEEE halves in MFMA-operand order [36 positions][cin_pad/16][cout_pad/32]
+ * [hi, lo][64 lanes][4 words] = 36*cin_pad*cout_pad 32-bit words; cout_pad % 64 == 0; `scale` a power of two that puts
+ * max|scale * U'| into [2^14, 2^15) (cf_conv_desc.acc_scale = 1 / scale) */
+int cf_pack_conv_weight_winograd43_f16x2(const float* w, int cout, int cin, int cout_pad, int cin_pad, float scale, void* packed,
+                                         cf_stream_t stream);
 /* winograd + SINGLE 16-bit operands (cout % 128 == 0, at least 32x32 pixels per image: the eight-wave kernel of cf_wsplit.hip; the
  * network's 'fp16' / 'bf16' modes, BASELINE configs 3 and 5): one MFMA per transform-domain product.  CF_OPERAND_F16 reads the hi slot of
  * the split packing above as it is; CF_OPERAND_BF16 takes this buffer: bf16(scale * U) in the hi slot of the same layout, zeros in the

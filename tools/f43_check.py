@@ -87,7 +87,7 @@ def case(B, H, W, cin, cout, timing=False, check=True, **kwargs):
         if kw['emit_stats']:
             e4 = stats_err(y4, B, H, W)
             msg += f' stats {e4:.1e}'
-            ok = ok and e4 < 1e-9
+            ok = ok and e4 < 2e-6   # (fp32 over four values, then fp64: the shipped kernels' scheme)
         y4b = ops.conv2d(x1, pw4, x2=x2, **kw)
         if not torch.equal(y4, y4b):
             msg += ' NOT REPRODUCIBLE'

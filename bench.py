@@ -8,19 +8,25 @@ followed, for N>1, by the single gather of the restored faces to rank 0 (left in
 gathers are joined inside the timed region).  Inputs are resident in HBM before the timed region; host PNG decode/encode is
 outside the path and outside the timed region.  Weak scaling: 16 faces per GPU.
 
-Precision (--precision, default f16x2): every tensor is fp32; accumulation, the Transformer, the 1x1 / stride-2 convolutions and the
-code argmax are exact fp32 in every mode.  'f16x2' evaluates the 3x3 stride-1 convolutions of encoder, generator and fusion blocks
-with split operands -- each fp32 operand as hi + lo IEEE halves (22 significant bits), three f16 MFMAs per product, fp32
-accumulation (cf_split.hip): against the reference its pixels and logits are as close as the exact-fp32 path's (pixels 5.7e-5 vs
-5.6e-5, logits 8.0e-6 vs 7.8e-6 on real crops; tolerances 1e-3 / 1e-4; indices identical).  'fp32' is the exact path (Winograd
-F(2x2,3x3) on fp32 MFMA); at N=1 the default run times it too and reports it under `exact_fp32`, together with the largest pixel
-and logit differences between the two modes on the bench batch and whether the code indices agree.
+Precision (--precision, default f16x2): every tensor is fp32 and every accumulation is fp32.  What stays on exact fp32 MFMA in EVERY
+mode: attention (QK^T, PV), the AttnBlock 1x1 convolutions, feat_emb (un-normalised input), the 16x16 token 1x1s, the statistics and
+the code argmax.  'f16x2' evaluates on SPLIT operands -- each fp32 operand as hi + lo IEEE halves (22 significant bits, 5-bit
+exponent behind a per-image power-of-two range scale), three f16 MFMAs per product -- every 3x3 convolution (stride 1 of encoder,
+generator and fusion blocks as Winograd F(2x2,3x3) / F(4x4,3x3), stride 2 as a 2x2 convolution of the space-to-depth view, the folded
+upsample convolutions), the image-sized 1x1 skip convolutions and 46 of the 47 Linear launches of the Transformer (those whose input
+is bounded by a LayerNorm one Linear layer back).  That is NARROWER than IEEE fp32: the headline of this mode is not "fp32"; it
+meets the config's gates (pixels 1e-3, logits 1e-4, code indices exact; `parity`).  'fp32' is the IEEE-fp32 evaluation (Winograd
+F(2x2,3x3) on fp32 MFMA: the same function, a different summation order than ATen's); at N=1 the default run times it too and reports
+it under `exact_fp32` WITH ITS OWN roofline object -- that leg is BASELINE config 2 to the letter.  `config3_rank` is one rank's share of
+BASELINE config 3 (batch 16 per GPU, w = 0.7, precision 'bf16': single bf16 operands in generator + fusion blocks), timed after its
+own gate (indices exact, logits 1e-4, pixels within the stated bf16 gate of the reference golden at w = 0.7).
 
 Rank 0 prints ONE JSON line with the contract fields plus
   roofline:     the kernel with the largest summed duration of a step, timed live per launch with events on the launch stream:
-                achieved = MFMA FLOPs it EXECUTES / duration, against the dense peak of the MFMA type it issues (f16: 2500
-                TFLOP/s, fp32: 157.3, MI355X_MICROARCH.md); effective_tflops = the convolution's algorithmic FLOPs
-                (2*taps*Cin*Cout per output pixel) / duration; `other_kernels` holds the same record for every other kernel class;
+                achieved = the convolution's ALGORITHMIC FLOPs (2*taps*Cin*Cout per output pixel) / duration, against
+                the dense peak of the MFMA type it issues (f16: 2500 TFLOP/s, fp32: 157.3, MI355X_MICROARCH.md): frac =
+                frac_algorithmic; executed_tflops / frac_executed count the MFMA FLOPs the kernel really issues (Winograd fewer,
+                split operands three times as many); `other_kernels` holds the same record for every other kernel class;
                 `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_bench.json), quoted only when
                 that file's build id equals the loaded library's (null otherwise: the kernels changed since the counters were taken).
   cpu_baseline: the CPU oracle (oracle/codeformer_oracle.py -- kind "port": the restatement pinned to the reference's outputs, not the
@@ -135,6 +141,8 @@ def roofline_leg(net, x, w):
         'conv3x3_wino_bf16_8w': ('wsplit_kernel<., BF16> (Winograd F(2x2,3x3), single bf16 operands, one MFMA per product)', 4.0 / 9.0, F16_MFMA_PEAK_TFLOPS, ('wsplit_kernel',)),
         'conv3x3_wino_f16x2': ('winograd_kernel<.,true> (the same on the four-wave 64-channel kernel: 64-channel layers and the 16x16 latents)',
                                3.0 * 4.0 / 9.0, F16_MFMA_PEAK_TFLOPS, ('winograd_kernel<false, true', 'winograd_kernel<true, true')),
+        'conv3x3_wino43_f16x2': ('wf43_kernel (3x3 s1 as Winograd F(4x4,3x3), 64 output channels per 8-wave workgroup, generator / fusion layers only; U and V as hi+lo '
+                                 'halves: 36 transform-domain products per 16 outputs x 3 f16 MFMAs)', 3.0 * 2.25 / 9.0, F16_MFMA_PEAK_TFLOPS, ('wf43_kernel',)),
         'conv3x3': ('igemm_kernel<9,1,...> (direct 3x3 s1 implicit GEMM, fp32 MFMA)', 1.0, FP32_MFMA_PEAK_TFLOPS, ('igemm_kernel<9, 1',)),
         'conv3x3_io': ('conv3x3_few_cin / conv3x3_few_cout (3->64 and 64->3 at 512x512 on the vector ALU: write- / read-bound)', 0.0, HBM_PEAK_GBS, ('conv3x3_few_c',)),
         'conv_up2x': ('igemm_kernel<4,1,...> (folded nearest-x2 + 3x3, fp32 MFMA)', 1.0, FP32_MFMA_PEAK_TFLOPS, ('igemm_kernel<4, 1',)),
@@ -146,29 +154,30 @@ def roofline_leg(net, x, w):
     }
 
     def entry(kind):
-        """`achieved` / `frac` = the FLOPs the MFMA pipe really EXECUTES for these launches over their summed durations, against
-        the dense peak of the MFMA type used; the convolution's algorithmic rate (2*taps*Cin*Cout per output pixel)
-        is reported separately as `effective_tflops` (it exceeds `achieved` for Winograd, which executes 4/9 of those
-        multiplies, and is a third of it for the split-half kernel, which issues 3 MFMAs per product)."""
-        name, ratio, peak, pmc = KINDS.get(kind, (kind, 1.0, F16_MFMA_PEAK_TFLOPS if kind.endswith(('_f16', '_bf16')) else FP32_MFMA_PEAK_TFLOPS, ('igemm_kernel<9, 1',)))
+        """`achieved` / `frac` (= `frac_algorithmic`): the convolution's ALGORITHMIC FLOPs (2*taps*Cin*Cout per output pixel, SURVEY
+        8(d)) of these launches over their summed durations, against the dense peak of the MFMA type the kernel issues.
+        `executed_tflops` / `frac_executed`: the FLOPs the MFMA pipe really executes for them (Winograd F(2,3) 4/9 and F(4,3) 1/4 of the
+        multiplies, times 3 for split operands) -- what the matrix pipe is busy with, not what the layer needed."""
+        name, ratio, peak, pmc = KINDS.get(kind, (kind, 1.0, F16_MFMA_PEAK_TFLOPS if kind.endswith(('_f16', '_bf16', '_f16x2')) else FP32_MFMA_PEAK_TFLOPS, ('igemm_kernel<9, 1',)))
         c = agg[kind]
+        tr = recorded_traffic(pmc)
         common = {'avg_launch_ms': round(c[2] / c[3] * 1e3, 4), 'launches_per_step': c[3] // reps,
                   'algorithmic_gflop_per_step': round(c[0] / reps / 1e9, 1), 'ms_per_step': round(c[2] / reps * 1e3, 2),
                   'alg_bytes_per_launch': round(c[1] / c[3]), 'frac_hbm_peak_alg_bytes': round(c[1] / c[2] / 1e9 / HBM_PEAK_GBS, 4),
-                  'traffic': recorded_traffic(pmc)}
+                  'traffic': tr, 'traffic_per_alg_bytes': round(tr['bytes_per_launch'] / (c[1] / c[3]), 3) if tr else None}
         if ratio == 0.0:   # no MFMA: algorithmic bytes / duration against the HBM peak
             gbs = c[1] / c[2] / 1e9
             return {'bound': 'hbm', 'kernel': name, 'achieved': round(gbs, 1), 'peak': peak, 'unit': 'GB/s', 'frac': round(gbs / peak, 4), **common}
         alg = c[0] / c[2] / 1e12
-        ach = alg * ratio
-        return {'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                'frac': round(ach / peak, 4), 'effective_tflops': round(alg, 2), 'executed_per_algorithmic_flop': round(ratio, 4), **common}
+        return {'bound': 'mfma', 'kernel': name, 'achieved': round(alg, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(alg / peak, 4),
+                'frac_algorithmic': round(alg / peak, 4), 'executed_tflops': round(alg * ratio, 2), 'frac_executed': round(alg * ratio / peak, 4),
+                'executed_per_algorithmic_flop': round(ratio, 4), **common}
 
     order = sorted(agg, key=lambda k: -agg[k][2])
     roof = entry(order[0])                                   # the dominant kernel = the kind with the largest summed duration
     roof['other_kernels'] = {k: entry(k) for k in order[1:]}
     # executed fp32-MFMA-equivalent work of one step (Winograd at its 4/9; a split-half product counted once) + attention (2.01 GF / face)
-    exec_flops = sum(v[0] * (4.0 / 9.0 if k.startswith('conv3x3_wino') else 1.0) for k, v in agg.items()) / reps + 2.01e9 * x.shape[0]
+    exec_flops = sum(v[0] * (0.25 if k.startswith('conv3x3_wino43') else 4.0 / 9.0 if k.startswith('conv3x3_wino') else 1.0) for k, v in agg.items()) / reps + 2.01e9 * x.shape[0]
     roof['executed_gflop_per_face_whole_path'] = round(exec_flops / x.shape[0] / 1e9, 2)
     return roof, table
 
@@ -195,6 +204,30 @@ def parity_gate(net, sd_cpu, weights, w):
            'code_indices_equal': bool(torch.equal(idx, ref_idx)), 'tolerances': 'pixels 1e-3, logits 1e-4, code indices exact'}
     if not (res['max_abs_pixel_diff'] <= 1e-3 and res['max_abs_logit_diff'] <= 1e-4 and res['code_indices_equal']):
         raise SystemExit(f'bench.py: parity gate FAILED, nothing timed: {json.dumps(res)}')
+    return res
+
+
+def config3_gate(net, weights):
+    """Gate of the bf16 / w = 0.7 leg (tests/test_gpu_real_images.py:test_config3_fidelity_weight_through_the_network, tools/gpu_check.py:g_bf16):
+    the seeded face at w = 0.7 with net.precision = 'bf16' against the REFERENCE's committed outputs -- code indices exact, logits 1e-4
+    (encoder and Transformer do not run on bf16), pixels within the stated bf16 gate (max 0.18, mean 0.014 on outputs of std ~0.5)."""
+    import numpy as np
+    from oracle.synth import seeded_input
+    g7 = os.path.join(ROOT, 'tests', 'golden', 'restoration_seed0_face0_w0.7.npz')
+    g5 = os.path.join(ROOT, 'tests', 'golden', 'restoration_seed0_face0.npz')
+    if weights != 'seed-0 random-init' or not (os.path.exists(g7) and os.path.exists(g5)):
+        return {'against': None, 'note': 'no committed reference output for these weights at w=0.7: leg timed without a gate'}
+    g, g0 = np.load(g7), np.load(g5)
+    out, logits, _ = net(seeded_input(1).to(next(net.parameters()).device), w=0.7, adain=True)
+    torch.cuda.synchronize()
+    d = (out.cpu()[:, :, ::4, ::4] - torch.from_numpy(g['out_sub'])).abs()
+    res = {'against': 'reference golden (tests/golden/restoration_seed0_face0_w0.7.npz, every 4th pixel; logits / indices of restoration_seed0_face0.npz)',
+           'max_abs_pixel_diff': float(d.max()), 'mean_abs_pixel_diff': float(d.mean()),
+           'max_abs_logit_diff': float((logits.cpu() - torch.from_numpy(g0['logits'])).abs().max()),
+           'code_indices_equal': bool(np.array_equal(net.last_indices.cpu().numpy().reshape(-1), g0['idx'].reshape(-1))),
+           'tolerances': 'pixels max 0.18 / mean 0.014 (bf16 operands), logits 1e-4, code indices exact'}
+    if not (res['max_abs_pixel_diff'] <= 0.18 and res['mean_abs_pixel_diff'] <= 0.014 and res['max_abs_logit_diff'] <= 1e-4 and res['code_indices_equal']):
+        raise SystemExit(f'bench.py: config-3 (bf16, w=0.7) gate FAILED, leg not timed: {json.dumps(res)}')
     return res
 
 
@@ -238,6 +271,7 @@ def main():
                          "3/5), encoder on split halves")
     ap.add_argument('--no-parity-gate', action='store_true', help='skip the golden-face check that precedes the timed region')
     ap.add_argument('--no-exact-leg', action='store_true', help='skip the extra exact-fp32 timing of the default run')
+    ap.add_argument('--no-config3-leg', action='store_true', help='skip the bf16 / w=0.7 timing (one rank of BASELINE config 3) of the default run')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--details', action='store_true', help='print the per-kernel-class table to stderr')
@@ -327,25 +361,48 @@ def main():
                 line['whole_path']['frac_fp32_mfma_peak'] = round(faces_per_s * ex / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world), 4)
             if args.details:
                 print(json.dumps(table, indent=1), file=sys.stderr)
+        def timed(w):
+            for _ in range(args.warmup):
+                net(x, w=w, adain=True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                net(x, w=w, adain=True)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t1
+
+        def leg_roofline(w):
+            """The dominant kernel's record of a secondary leg (its `other_kernels` reduced to name -> ms_per_step, frac)."""
+            r, _ = roofline_leg(net, x, w)
+            r.pop('executed_gflop_per_face_whole_path')
+            r['other_kernels'] = {k: {'ms_per_step': v['ms_per_step'], 'frac': v['frac'], 'bound': v['bound']} for k, v in r['other_kernels'].items()}
+            return r
+
         if world == 1 and args.precision == 'f16x2' and not args.no_exact_leg:
             y_split = net(x, w=args.w, adain=True)
             net.precision = 'fp32'
             y_exact = net(x, w=args.w, adain=True)
-            for _ in range(args.warmup):
-                net(x, w=args.w, adain=True)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                net(x, w=args.w, adain=True)
-            torch.cuda.synchronize()
-            dt1 = time.perf_counter() - t1
-            net.precision = args.precision
+            dt1 = timed(args.w)
             line['exact_fp32'] = {'value': round(args.steps * total / dt1, 2), 'unit': 'faces/s', 'ms_per_step': round(dt1 / args.steps * 1e3, 3),
-                                  'what': 'the same step with precision=fp32: every convolution on exact fp32 MFMA (Winograd F(2x2,3x3) '
-                                          'where eligible)',
+                                  'what': 'the same step with precision=fp32 -- BASELINE config 2 to the letter: every convolution on exact fp32 MFMA '
+                                          '(Winograd F(2x2,3x3) where eligible: the same function, another summation order than ATen)',
                                   'max_abs_pixel_diff_vs_default': float((y_split[0] - y_exact[0]).abs().max()),
                                   'max_abs_logit_diff_vs_default': float((y_split[1] - y_exact[1]).abs().max()),
                                   'code_indices_equal': bool(torch.equal(y_split[1].argmax(-1), y_exact[1].argmax(-1)))}
+            if not args.no_roofline:
+                line['exact_fp32']['roofline'] = leg_roofline(args.w)
+            net.precision = args.precision
+        if world == 1 and args.precision == 'f16x2' and not args.no_config3_leg and B == 16:
+            net.precision = 'bf16'
+            gate = config3_gate(net, weights)      # raises before anything is timed
+            dt3 = timed(0.7)
+            line['config3_rank'] = {'value': round(args.steps * total / dt3, 2), 'unit': 'faces/s', 'ms_per_step': round(dt3 / args.steps * 1e3, 3),
+                                    'what': "one rank's share of BASELINE config 3 (batch 16 per GPU, w=0.7, precision=bf16: single bf16 operands / f32 "
+                                            'accumulate in the 3x3 convolutions of generator + fusion blocks; encoder and Transformer as in the default mode)',
+                                    'gate': gate}
+            if not args.no_roofline:
+                line['config3_rank']['roofline'] = leg_roofline(0.7)
+            net.precision = args.precision
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline_leg(sd_cpu, args.w)
         print(json.dumps(line), flush=True)

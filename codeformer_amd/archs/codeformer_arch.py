@@ -252,8 +252,9 @@ class CodeFormer(VQAutoEncoder):
         # inputs of out-proj / MLP-down / feat_emb are not bounded by anything the host can check; 'auto' (default) = split halves for the
         # Linear layers whose input the host can bound from parameters -- those behind a LayerNorm (q|k, v, MLP-up, the logits head:
         # |gamma| sqrt(C - 1) + |beta| (+ |pos|), ln_code) and those one Linear layer further (out-proj, MLP-down: bounded_code), 46 of 47
-        # launches -- while the bound stays inside the half range and `precision` is not 'fp32'; exact fp32 elsewhere (feat_emb reads
-        # the un-normalised encoder feature).
+        # launches -- while the bound stays inside the half range and neither `precision` nor `encoder_precision` is 'fp32' (so that
+        # encoder_precision = 'fp32' alone keeps the logits bitwise identical across modes); exact fp32 elsewhere (feat_emb reads the
+        # un-normalised encoder feature).
         # Against fp64 the split-half GEMM is closer than the fp32-MFMA one (1.2e-6 vs 2.0e-6); logits / indices vs the reference unchanged.
         self.gemm_precision = os.environ.get('CODEFORMER_HIP_GEMM_PRECISION', 'auto')
         # Optional HIP-graph replay of the whole forward (one graph per input shape / w / flags): takes the ~250 host launches
@@ -309,7 +310,8 @@ class CodeFormer(VQAutoEncoder):
         if self.gemm_precision not in ('auto', 'fp32', 'f16x2'):
             raise ValueError(f"gemm_precision must be 'auto', 'fp32' or 'f16x2', got {self.gemm_precision!r}")
         gcode = ops.GSPLIT if self.gemm_precision == 'f16x2' else 0
-        gcode_ln = ops.GSPLIT if (self.gemm_precision == 'f16x2' or (self.gemm_precision == 'auto' and self.precision != 'fp32')) else 0
+        # 'auto' follows the encoder: encoder_precision = 'fp32' alone keeps logits bitwise identical across the precision modes
+        gcode_ln = ops.GSPLIT if (self.gemm_precision == 'f16x2' or (self.gemm_precision == 'auto' and self.precision != 'fp32' and self.encoder_precision != 'fp32')) else 0
         X = ops.linear(tokens, self._pw_conv('feat_emb', bf16=gcode))
         for layer in self.ft_layers:
             X = layer.forward_tokens(X, self.position_emb, B, code=gcode, code_ln=gcode_ln)

@@ -110,12 +110,13 @@ class Downsample(HipModule):
 
     def forward_nhwc(self, x, bf16=False):
         # split-half operands: the stride-2 form of cf_split.hip (a 2x2 convolution of the space-to-depth view of x); the input is the
-        # un-normalised residual stream, so it carries a range scale.  The single-operand modes keep the exact kernel (as Upsample does).
+        # un-normalised residual stream, so it carries a range scale (computed only when the table is used: CODEFORMER_HIP_RANGE_SCALE=0
+        # drops it).  Mode 2 (single IEEE-half operands) takes the same split-half stride-2 form; bf16 (1) keeps the exact kernel.
         cin, cout = self.conv.in_channels, self.conv.out_channels
         if int(bf16) in (2,) + ops.SPLIT_CODES and ops.split_s2_ok(cin, cout, x.shape[1], x.shape[2]):
             pw = self._packed(('conv', 's2'), lambda: ops.pack_weight(self.conv.weight, self.conv.bias, bf16=ops.SPLIT, stride2=True),
                               self.conv.weight, self.conv.bias)
-            return ops.conv2d(x, pw, stride=2, emit_stats=True, act=ops.act_scale(x))
+            return ops.conv2d(x, pw, stride=2, emit_stats=True, act=ops.act_scale(x) if ops.needs_act_scale(pw) else None)
         return ops.conv2d(x, self._pw_conv('conv'), stride=2, emit_stats=True)
 
     def forward_host(self, x):

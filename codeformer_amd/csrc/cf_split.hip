@@ -8,9 +8,14 @@
 // i.e. THREE f16 MFMAs with fp32 accumulation per fp32 multiply-add: 3/16 of the fp32-MFMA issue time, on a pipe that
 // co-executes with the VALU.  Operands carry 22 instead of 24 significant bits; accumulation is fp32.  Measured against fp64
 // the error of a layer is 1-3x that of the exact-fp32 kernels (tests/test_gpu_split.py), against the reference the whole
-// network stays inside the 1e-3 pixel tolerance by more than an order of magnitude.  Used for the generator / fusion (CFT)
-// convolutions only (reference: vqgan_arch.py:132-164,276-323, codeformer_arch.py:136-157): encoder, Transformer and the code
-// argmax stay on exact fp32, so logits and code indices are bitwise those of the fp32 mode.
+// network stays inside the 1e-3 pixel tolerance by more than an order of magnitude.  What runs on this kernel in the default mode
+// (precision 'f16x2'): the folded upsample convolutions, the stride-2 Downsample convolutions and the image-sized 1x1 skip
+// convolutions of ENCODER, generator and fusion blocks (the 3x3 stride-1 layers take the Winograd forms of the same split scheme,
+// cf_wsplit.hip / cf_winograd.hip / cf_wf43.hip; reference: vqgan_arch.py:117-164,243-323, codeformer_arch.py:136-157).  The encoder
+// is therefore NOT on exact fp32 in that mode: logits and code indices are not bitwise those of precision 'fp32' -- they meet the
+// reference's goldens (logits 1e-4, indices exact; tests/test_gpu_parity.py, tests/test_gpu_range.py).  Exact fp32 in every mode:
+// attention, AttnBlock 1x1, feat_emb, statistics and the code argmax; encoder_precision = 'fp32' together with gemm_precision =
+// 'fp32' puts encoder and Transformer back on exact fp32 MFMA.
 //
 // Range: hi is an IEEE half, so conv INPUTS (post-activation values) must stay below 65504 in magnitude -- an overflow becomes
 // inf / NaN in the output, never a silently wrong finite value.  Weights are scaled at pack time by a power of two (exact) so

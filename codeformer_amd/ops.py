@@ -191,11 +191,12 @@ def act_scale(x, x2=None, growth=4.0):
     """(B, 2) float32 table (s_b, 1 / s_b): power-of-two scale that puts growth * max|x_b| into [2^13, 2^14) -- from the statistics
     partials the producing conv wrote (no pass over x; the bound is loose by a few bits, which is harmless) or, for tensors without
     them, from x itself; one launch (cf_act_scale_fused).  x2: the second half of a concatenated input -- the table then covers both.
-    Cached on the tensor (one table serves every conv that reads it; pairs are not cached)."""
+    Cached on the tensor under (growth, tensor version): one table serves every conv that reads the tensor, and an in-place write
+    (out= reuse, a user-held buffer) or another growth factor gets a fresh table; pairs are not cached."""
     if x2 is None:
-        act = getattr(x, '_cf_act', None)
-        if act is not None:
-            return act
+        cached = getattr(x, '_cf_act', None)
+        if cached is not None and cached[0] == (float(growth), x._version):
+            return cached[1]
     lib = L.load()
     B = x.shape[0]
     act = torch.empty(B, 2, dtype=torch.float32, device=x.device)
@@ -213,7 +214,7 @@ def act_scale(x, x2=None, growth=4.0):
             L.check(lib.cf_act_scale_from_stats(L.ptr(st.part, dtype=torch.float64), B, st.part.numel() // (2 * B), float(growth), L.ptr(scratch), L.ptr(act), L.stream_ptr()), 'cf_act_scale_from_stats')
         else:
             L.check(lib.cf_act_scale_from_tensor(L.ptr(_f32(x)), B, x.numel() // B, float(growth), L.ptr(scratch), L.ptr(act), L.stream_ptr()), 'cf_act_scale_from_tensor')
-        x._cf_act = act
+        x._cf_act = ((float(growth), x._version), act)
         return act
     if st is not None:
         nper = st.part.numel() // (2 * B)
@@ -226,7 +227,7 @@ def act_scale(x, x2=None, growth=4.0):
         L.check(lib.cf_act_scale_fused(None, 0, None, 0, L.ptr(_f32(x)), x.numel() // B, B, float(growth), cells, L.ptr(act), L.stream_ptr()),
                 'cf_act_scale_fused')
     if x2 is None:
-        x._cf_act = act
+        x._cf_act = ((float(growth), x._version), act)
     return act
 
 

@@ -166,7 +166,11 @@ def restore_whole_images(args, input_img_list, result_root, w):
         except Exception as error:   # the reference's per-image fallback (inference_codeformer.py:207-209): keep going, report at the end
             if args.strict:
                 raise
-            print(f'\tFailed inference for CodeFormer: {error}')
+            if len(names) > 1:       # a window failed: redo it image by image so that only the offending image is lost
+                for one in zip(frames, affs, names, grays):
+                    flush(*[[v] for v in one])
+                return
+            print(f'\tFailed inference for CodeFormer ({names[0]}): {error}')
             failed.extend(names)
             return
         for name, img, (crops, faces) in zip(names, outs, per_frame):

@@ -2,7 +2,7 @@
 # Kernel-trace summary of the batch-N call (default N=1): where a small-batch forward spends its time.
 n=${1:-1}; tag=${2:-b$n}
 mkdir -p gpurun_out; export TMPDIR=/tmp
-rm -rf /tmp/prof_b && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o b -- python bench.py --batch-per-gpu $n --steps 20 --warmup 3 --no-cpu-baseline --no-roofline --no-exact-leg > gpurun_out/rocprof_run_$tag.log 2>&1; echo "rc=$?"
+rm -rf /tmp/prof_b && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o b -- python bench.py --batch-per-gpu $n --steps 20 --warmup 3 --no-cpu-baseline --no-roofline --no-exact-leg --no-config3-leg > gpurun_out/rocprof_run_$tag.log 2>&1; echo "rc=$?"
 tail -1 gpurun_out/rocprof_run_$tag.log | cut -c1-200
 f=$(find /tmp/prof_b -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" gpurun_out/rocprof_kernel_stats_$tag.csv
 python - <<PY

@@ -11,6 +11,6 @@ for f in gpurun_ablate/lib_ab*.so; do
 done
 if [ "$2" != "nosuite" ]; then
 echo "== pytest -m gpu"; timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu_f43_$tag.log 2>&1; echo "rc=$?"; tail -5 gpurun_out/pytest_gpu_f43_$tag.log
-echo "== bench F43 default"; timeout 400 python bench.py --details --no-cpu-baseline --no-exact-leg > gpurun_out/bench_f43_$tag.json 2> gpurun_out/bench_details_f43_$tag.txt; echo "rc=$?"; cat gpurun_out/bench_f43_$tag.json
-echo "== bench F43=0"; CODEFORMER_HIP_F43=0 timeout 400 python bench.py --no-cpu-baseline --no-exact-leg --no-roofline > gpurun_out/bench_f43off_$tag.json 2>/dev/null; echo "rc=$?"; cat gpurun_out/bench_f43off_$tag.json
+echo "== bench F43 default"; timeout 400 python bench.py --details --no-cpu-baseline --no-exact-leg --no-config3-leg > gpurun_out/bench_f43_$tag.json 2> gpurun_out/bench_details_f43_$tag.txt; echo "rc=$?"; cat gpurun_out/bench_f43_$tag.json
+echo "== bench F43=0"; CODEFORMER_HIP_F43=0 timeout 400 python bench.py --no-cpu-baseline --no-exact-leg --no-config3-leg --no-roofline > gpurun_out/bench_f43off_$tag.json 2>/dev/null; echo "rc=$?"; cat gpurun_out/bench_f43off_$tag.json
 fi

@@ -5,7 +5,7 @@ mkdir -p gpurun_out; export TMPDIR=/tmp
 i=0
 for set in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1)); rm -rf /tmp/pb$i
-  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pb$i -o p -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-exact-leg --no-parity-gate > gpurun_out/pmcbench_${tag}_run$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pb$i -o p -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-exact-leg --no-config3-leg --no-parity-gate > gpurun_out/pmcbench_${tag}_run$i.log 2>&1
   echo "set $i rc=$?"
 done
 python - "$tag" <<'PY'
@@ -32,7 +32,7 @@ for k, d in agg.items():
 import ctypes, os
 lib = ctypes.CDLL(os.path.join('codeformer_amd', 'libcodeformer_hip.so'))
 lib.cf_build_id.restype = ctypes.c_char_p
-out['_meta'] = {'cf_build_id': lib.cf_build_id().decode(), 'command': 'bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-exact-leg --no-parity-gate'}
+out['_meta'] = {'cf_build_id': lib.cf_build_id().decode(), 'command': 'bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-exact-leg --no-config3-leg --no-parity-gate'}
 json.dump(out, open(f'gpurun_out/pmc_bench_{tag}.json', 'w'), indent=1, sort_keys=True)
 for k, d in out.items():
     if k == '_meta':

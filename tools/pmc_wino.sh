@@ -6,7 +6,7 @@ rocprofv3 --list-avail 2>/dev/null | grep -o "SQ_[A-Z_]*\(VALU\|LDS\|MFMA\)[A-Z_
 i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" "SQ_VALU_MFMA_COEXEC_CYCLES SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_TRANS_F32 SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"; do
   i=$((i+1)); rm -rf /tmp/pw$i
-  timeout 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pw$i -o p -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-exact-leg > gpurun_out/pmcwino_run$i.log 2>&1
+  timeout 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pw$i -o p -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-exact-leg --no-config3-leg > gpurun_out/pmcwino_run$i.log 2>&1
   echo "set $i rc=$?"
 done
 python - <<'PY'

@@ -1,7 +1,8 @@
-// Winograd F(4x4,3x3) convolution with split-half operands, 64 output channels per eight-wave workgroup (gfx950).
+// Winograd F(4x4,3x3) convolution with split-half operands: 16x16-pixel patches, 64 output channels per eight-wave workgroup, TWO
+// workgroups per CU (gfx950).
 //
-// Serves the 3x3 stride-1 convolutions of the GENERATOR whose output has 64 channels (vqgan_arch.py:300-316: the two ResBlocks at
-// 512x512) -- never the encoder, which decides the code indices and stays on F(2x2,3x3).
+// Serves 3x3 stride-1 convolutions of GENERATOR and fusion (CFT) blocks (vqgan_arch.py:141-164,296-323, codeformer_arch.py:136-157) --
+// never the encoder, which decides the code indices and stays on F(2x2,3x3).
 //
 //   Y = A^T [ (G g G^T) (.) (B^T d B) ] A      d: 6x6 input tile, g: 3x3 kernel, Y: 4x4 outputs
 // with the interpolation points (0, +-1/2, +-2, inf) -- the set with the smallest mean error among those tools/winograd_f43_numerics.py
@@ -13,40 +14,41 @@
 //            0 .25 0 -1.0625 0 .25 ]
 //   G'   = [ 4 0 0 ; -32/15 -16/15 -8/15 ; -32/15 16/15 -8/15 ; 1/15 2/15 4/15 ; 1/15 -2/15 4/15 ; 0 0 4 ]
 //   A^T  = [ 1 1 1 1 1 0 ; 0 .5 -.5 2 -2 0 ; 0 .25 .25 4 4 0 ; 0 .125 -.125 8 -8 1 ]
-// The 36 transform-domain GEMMs  M[xi,nu][tile][n] = sum_c V[xi,nu][tile][c] U[xi,nu][c][n]  run on v_mfma_f32_32x32x16_f16 with U and V
-// as hi + lo IEEE halves (hi*hi + lo*hi + hi*lo, fp32 accumulation), as in cf_wsplit.hip: 36 positions per 16 outputs = 2.25 products per
-// output pixel and input channel instead of 4 -- and with them 0.56 of the MFMAs, of the weight-fragment bytes through the
-// vector-memory path, of the V bytes through LDS and of the operand splits per output; the halo factor drops from 1.41 to 1.20.
+// The 36 transform-domain GEMMs  M[xi,nu][tile][n] = sum_c V[xi,nu][tile][c] U[xi,nu][c][n]  run on v_mfma_f32_16x16x16_f16 with U and V
+// as hi + lo IEEE halves (hi*hi + lo*hi + hi*lo, fp32 accumulation): 36 positions per 16 outputs = 2.25 products per output pixel and
+// input channel instead of the 4 of F(2,3).
 //
-// Why 64 output channels and not 128: one MFMA row tile is 32 Winograd tiles = a 16x32-pixel patch, and the accumulators of 36
-// positions x 32 tiles x 128 channels (590 KB) exceed the CU's 512 KB register file; x 64 channels they are 295 KB = 144 registers
-// per lane of eight waves.  A 64-channel workgroup on a 128-channel layer repeats gather + prologue + transform per channel half,
-// which costs about what the matrix side saves -- so the kernel is used where one workgroup covers the layer.
+// Why this shape.  The first two forms of this kernel (one eight-wave workgroup per CU owning a 16x32 patch on 32-row MFMAs, 256
+// registers per lane; stage-synchronous, then two wave groups half a slab apart: profiles/r04_f43_sync_ablation.txt) measured 1.16 ms
+// on 64 -> 64 @ 512x512 x 16, no better than F(2,3), with the stages adding up -- and the largest of them was the EPILOGUE (0.43 ms):
+// a CU moves about 11 bytes per clock to and from HBM whatever the other CUs do, so the 262 KB a patch reads (residual) and writes
+// take 24k cycles during which a single resident workgroup computes nothing, and its 43k cycles of compute leave the memory path idle.
+// Only a second resident workgroup overlaps the two.  Hence 16 tiles per patch (the 16-row MFMA; its accumulators are 72 registers per
+// lane at 64 channels), 128 registers per lane, under 80 KB of LDS: two workgroups per CU, four waves per SIMD, each workgroup's
+// memory phases under the other's compute.  The price: the legacy 16x16x16 MFMA issues at half the rate of 32x32x16 (these layers
+// keep the matrix pipe under a quarter busy), and a weight fragment now serves 16 instead of 32 tiles (twice the fragment bytes out
+// of L2 per output).
 //
-// Work decomposition (512 threads = 8 waves, one workgroup per CU, 157 KB LDS):
-//   * a workgroup owns a 16x32 output patch of ONE image (4x8 tiles of 4x4 outputs) x 64 channels; K loop over 16-channel slabs;
-//   * two wave groups, A = waves 0..3 and B = waves 4..7, each own ONE xi half of the transform domain (18 positions): a group
-//     transforms its half of V and runs the MFMAs on it, so a V half never crosses groups -- and the groups run half a slab out of
-//     phase:       phase 1:  A: transform(s)                     | B: MMA(s - 1), prologue + store(s + 1)
-//                  phase 2:  A: MMA(s), prologue + store(s + 1)  | B: transform(s)            (one barrier after each phase)
-//     so on every SIMD (it hosts one wave of each group) the LDS-bound transform of one wave runs beside the MFMA / weight-fragment /
-//     swish work of the other.  The stage-synchronous first version of this kernel (all waves: transform | MMA, store) measured
-//     1.17 ms on 64 -> 64 @ 512x512 x 16 with the stages adding up: loads + epilogue alone 0.51 ms (6.3 TB/s), MFMAs 0.12, transform
-//     0.19, prologue + store 0.25, weight fetch 0.15 (profiles/r04_f43_sync_ablation.txt);
-//   * gather: the 18x34 halo patch of a slab (612 pixels x 4 channel quads, five float4 items per thread) is requested a whole slab
-//     ahead (registers), passes the GroupNorm-apply / swish or LeakyReLU prologue, zero padding and concat as in the other kernels, and
-//     is written to one of TWO patch buffers (slab parity): [18 rows x 36 pixel slots][16 floats], unpadded; the 64-byte pixel slot p
-//     lives at p ^ ((p >> 2) & 3) (low two bits), which spreads the four tile columns a half-wave reads over the four 64-byte windows
-//     of the 256-byte bank row;
-//   * input transform: item = (tile, channel pair) of the group's xi half: column pass for three rows of B'^T d (five of the six tile
-//     rows are read), row pass for their six nu, split into hi + lo and written to V[36][32 tiles][16 hi halves | 16 lo halves]
-//     (64-byte rows, 16-byte chunk c of tile t at c ^ ((t >> 2) & 3): conflict-free for the lane groups of ds_read_b128);
-//   * MFMA stage: wave = (xi half = group, nu half, channel half): nine positions x 32 channels = 144 accumulator registers; A
-//     fragments from V, B fragments global/L2 -> registers through a four-position ring, MFMAs of two positions interleaved;
-//   * epilogue: the accumulators go through LDS in two passes (16 tiles each, [36][16 tiles][64 ch], over patch buffers + V); item =
-//     (tile, channel pair) reads its 36 transform-domain values ONCE, contracts xi and nu, applies acc_scale / bias / residual / SFT,
-//     stores the 4x4 pixels as 8-byte pairs (a half-wave writes 256 contiguous bytes per pixel) and accumulates the GroupNorm
-//     statistics of what it wrote (fp32 over four values, then fp64; fixed shuffle order: eight partials per patch and group).
+// Work decomposition (512 threads = 8 waves, 80,896 bytes of LDS):
+//   * a workgroup owns a 16x16 output patch of ONE image (4x4 tiles of 4x4 outputs) x 64 channels; K loop over 16-channel slabs, two
+//     barrier intervals per slab:     T: waves 4..7: prologue + store of patch(s + 1), request of patch(s + 2);
+//                                        waves 0..3: input transform of slab s (patch(s) -> V)
+//                                     M: every wave: its MFMAs of slab s (V x weight fragments straight from L2)
+//   * gather: the 18x18 halo patch of a slab (324 pixels x 4 channel quads, six float4 items per thread of waves 4..7) is requested
+//     one interval pair ahead (registers), passes the GroupNorm-apply / swish or LeakyReLU prologue, zero padding and concat as in the other
+//     kernels, and is written to one of TWO patch buffers (slab parity): [324 pixel slots][16 floats]; the 64-byte slot p lives at
+//     p ^ ((p >> 2) & 3) (low two bits), which spreads the four tiles a half-wave reads over the four 64-byte windows of a bank row;
+//   * input transform (waves 0..3): item = (xi half, tile, channel pair): column pass for three rows of B'^T d (five of the six tile
+//     rows are read), row pass for their six nu, split into hi + lo, written to V[36][16 tiles][4 quads: 4 hi halves | 4 lo halves]
+//     (64-byte rows; quad q of tile t at q ^ s(t >> 2), s = 0, 2, 3, 1: conflict-free for the lane groups of ds_read_b128);
+//   * MFMA interval: wave = (xi half g = wave >> 2, 16-channel block nb = wave & 3): positions 18 g .. 18 g + 17 = 72 accumulator
+//     registers; one ds_read_b128 per position is the A fragment (hi | lo), one global_load_dwordx4 the B fragment (hi | lo), ring of four;
+//   * epilogue: two passes (tile columns 0, 1 / 2, 3) through LDS: M[36][8 tiles][64 ch] over patch buffers + V; item = (tile, channel
+//     pair, output-row half): reads 30 of the tile's 36 transform-domain values, contracts xi for its two output rows and nu for the
+//     four columns, applies acc_scale / bias / residual / SFT, stores 8-byte pairs (a half-wave writes 256 contiguous bytes per pixel) and
+//     accumulates the GroupNorm statistics of what it wrote (fp32 over four values, then fp64; fixed shuffle order: sixteen partials
+//     per patch and group).
+#include <cstdlib>
 #include <type_traits>
 
 #include "cf_common.h"
@@ -55,29 +57,64 @@
 #define F4_ABLATE 0
 #endif
 
+#ifndef F4_TIMING   // experiment builds only (tools/f43_timing.py): s_memtime stamps of one workgroup in the middle of the grid
+#define F4_TIMING 0
+#endif
+#if F4_TIMING
+__device__ unsigned long long f4_timing_buf[8 * 16];
+extern "C" int cf_debug_f4_timing(unsigned long long* host16x8) {
+  return hipMemcpyFromSymbol(host16x8, HIP_SYMBOL(f4_timing_buf), sizeof(f4_timing_buf)) == hipSuccess ? 0 : -1;
+}
+#define F4_T(slot)                                                   \
+  do {                                                               \
+    const unsigned long long t__ = __builtin_amdgcn_s_memtime();     \
+    tacc[slot] += t__ - tlast;                                       \
+    tlast = t__;                                                     \
+  } while (0)
+#else
+#define F4_T(slot) ((void)0)
+#endif
+
 namespace {
 
-constexpr int F4_TH = 16, F4_TW = 32;            // output patch of a workgroup
-constexpr int F4_PW = F4_TW + 2;                 // halo patch 18 x 34
-constexpr int F4_NPIX = (F4_TH + 2) * F4_PW;     // 612
-constexpr int F4_PWL = 36;                       // pixel slots per patch row in LDS (a multiple of 4: the swizzle stays inside a row)
-constexpr int F4_SLOTS = (F4_TH + 2) * F4_PWL;   // 648
-constexpr int F4_DUMMY = 646;                    // an unused slot (row 17 holds pixels in slots 612..645): target of the padding items
-constexpr int F4_NT = 32;                        // tiles per patch (4 rows x 8 columns) = one MFMA row tile
+constexpr int F4_TH = 16, F4_TW = 16;            // output patch of a workgroup
+constexpr int F4_PW = F4_TW + 2;                 // halo patch 18 x 18
+constexpr int F4_NPIX = (F4_TH + 2) * F4_PW;     // 324 pixels = 324 slots (rows are not padded: the swizzle works on the linear slot index)
+constexpr int F4_SLOTS = F4_NPIX + 4;            // + one aligned group of four: the target of the padding items
+constexpr int F4_DUMMY = F4_NPIX;
+constexpr int F4_NT = 16;                        // tiles per patch (4 x 4) = one MFMA row tile
 constexpr int F4_THREADS = 512;
 constexpr int F4_BN = 64;                        // output channels per workgroup
-constexpr int F4_APT = 5;                        // float4 gather items per thread: 640 items x 4 quads / 512 threads
-constexpr int F4_PATCH_FLOATS = F4_SLOTS * CF_BK;   // 10368 floats = 41472 bytes per buffer
-constexpr int F4_PS = F4_NT * CF_BK;             // 512 floats between positions of V
-constexpr int F4_V_FLOATS = 36 * F4_PS;          // 18432
-constexpr int F4_M_FLOATS = 36 * 16 * F4_BN;     // 36864: one pass of the epilogue (36 positions x 16 tiles x 64 channels)
-constexpr int F4_TAB = 512;                      // GroupNorm scale / shift rows of the image (cin <= 512)
-constexpr int F4_LDS_FLOATS = 2 * F4_PATCH_FLOATS + F4_V_FLOATS + 2 * F4_TAB;   // 160,768 bytes
+constexpr int F4_APT = 6;                        // float4 gather items per thread of waves 4..7: 384 pixel slots x 4 quads / 256 threads
+constexpr int F4_PATCH_FLOATS = F4_SLOTS * CF_BK;   // 5248 floats = 20992 bytes per buffer
+constexpr int F4_PS = F4_NT * CF_BK;             // 256 floats between positions of V
+constexpr int F4_V_FLOATS = 36 * F4_PS;          // 9216
+constexpr int F4_M_FLOATS = 36 * 8 * F4_BN;      // 18432: one pass of the epilogue (36 positions x 8 tiles x 64 channels)
+constexpr int F4_TAB = 256;                      // GroupNorm scale / shift rows of the image (cin <= 256)
+constexpr int F4_LDS_FLOATS = 2 * F4_PATCH_FLOATS + F4_V_FLOATS + 2 * F4_TAB;   // 80,896 bytes: two workgroups per CU
 static_assert(F4_M_FLOATS <= 2 * F4_PATCH_FLOATS + F4_V_FLOATS, "epilogue staging must fit the patch buffers + V");
-static_assert(F4_LDS_FLOATS * 4 <= 163840, "LDS budget");
+static_assert(F4_LDS_FLOATS * 4 <= 81920, "LDS budget of two workgroups per CU");
 
-typedef _Float16 f4_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f4_f16x4 __attribute__((ext_vector_type(4)));
 typedef float f4_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned f4_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned f4_u32x2 __attribute__((ext_vector_type(2)));
+
+// Buffer addressing (scalar descriptor + 32-bit lane offset + scalar offset) for every global access of the kernel: with plain
+// pointers hipcc keeps one 64-bit lane address per unrolled access alive across the slab loop (18 weight-fragment pointers, 6 gather
+// pointers, 24 epilogue pointers) -- at 128 registers per lane that is what spilled.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t f4_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 f4_ld128(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ f4_f32x2 f4_ld64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f4_f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void f4_st64(f4_f32x2 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(f4_u32x2, v), r, (int)voff, (int)soff, 0);
+}
 
 struct F4Args {
   const float* in0;
@@ -88,7 +125,7 @@ struct F4Args {
   int prologue, epilogue;
   const float* pro_scale;
   const float* pro_shift;
-  const float* weight;  // [36 pos][nchunks][cout/32][hi, lo][64 lanes][4 words]  (cf_pack_conv_weight_winograd43_f16x2)
+  const float* weight;  // [36 pos][nchunks][cout/16][64 lanes][hi 2 words | lo 2 words]  (cf_pack_conv_weight_winograd43_f16x2)
   const float* bias;
   const float* res;
   const float* sft_scale;
@@ -101,8 +138,11 @@ struct F4Args {
   int tiles_x, tiles_per_img, ntn;
 };
 
-template <int PRO>
-__global__ __launch_bounds__(F4_THREADS, 1) void wf43_kernel(const F4Args a) {
+// quad swizzle of V: tile row ty -> 0, 2, 3, 1
+__device__ __forceinline__ int f4_vs(int ty) { return (0x78 >> (2 * ty)) & 3; }
+
+template <int PRO, int EPI>
+__global__ __launch_bounds__(F4_THREADS, 4) void wf43_kernel(const F4Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const V = smem + 2 * F4_PATCH_FLOATS;
   float* const tab = V + F4_V_FLOATS;  // [scale: F4_TAB][shift: F4_TAB]
@@ -110,9 +150,6 @@ __global__ __launch_bounds__(F4_THREADS, 1) void wf43_kernel(const F4Args a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave-uniform by construction: keeps what depends on it in SGPRs)
-  const int grp = wave >> 2;                                   // wave group = xi half
-  const int half = lane >> 5;
-  const int l31 = lane & 31;
 
   int bid = blockIdx.x;
   {  // XCD-contiguous tile order (see cf_igemm.hip)
@@ -128,6 +165,12 @@ __global__ __launch_bounds__(F4_THREADS, 1) void wf43_kernel(const F4Args a) {
   const int y0 = tyw * F4_TH;
   const int x0 = (rt - tyw * a.tiles_x) * F4_TW;
   const int n = a.nchunks;
+#if F4_TIMING
+  // slots: 0 fill, 1 T work, 2 T barrier, 3 M work, 4 M barrier, 5 epilogue load + stage, 6 epilogue barriers, 7 epilogue compute + store
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_amdgcn_s_memtime();
+  const unsigned long long tstart = tlast;
+#endif
 
   constexpr bool affine = PRO == CF_PRO_AFFINE || PRO == CF_PRO_AFFINE_SWISH;
   if (affine) {  // this image's GroupNorm rows -> LDS, read per slab by the patch store (first use is behind the first barrier)
@@ -143,39 +186,52 @@ __global__ __launch_bounds__(F4_THREADS, 1) void wf43_kernel(const F4Args a) {
   }
   const float act_s02 = 0.2f * act_s;  // LeakyReLU slope folded with the scale: fl(y * (0.2 s)) == fl(0.2 y) * s
 
-  // ---- gather: item j of this thread is float4 #k4 of halo pixel p = (tid >> 2) + 128 j ----
-  // One word per item: bits 0..9 the (swizzled) LDS pixel slot, bits 10..30 the pixel's index inside the image, bit 31 = outside the
-  // image or a padding item (p >= 612): loaded from pixel 0, stored as zeros (padding items: into an unused slot).
-  const int k4 = tid & 3;
-  unsigned pcode[F4_APT];
-#pragma unroll
-  for (int j = 0; j < F4_APT; ++j) {
-    const int p = (tid >> 2) + 128 * j;
-    unsigned code = 0x80000000u;
-    int slot = F4_DUMMY;
-    if (p < F4_NPIX) {
-      const int hy = p / F4_PW;
-      const int hx = p - hy * F4_PW;
-      const int iy = y0 - 1 + hy;
-      const int ix = x0 - 1 + hx;
-      slot = hy * F4_PWL + hx;
-      if (iy >= 0 && iy < a.h && ix >= 0 && ix < a.w) code = (unsigned)(iy * a.w + ix) << 10;
-    }
-    pcode[j] = code | (unsigned)((slot & ~3) | ((slot ^ (slot >> 2)) & 3));
-  }
+  // ---- gather (waves 4..7; waves 0..3 spend the same interval on the input transform): item j of a thread is float4 #k4 of halo pixel
+  //      p = u + 64 j, u = (tid - 256) >> 2.  Everything per item -- the pixel's offset from the patch origin, whether it lies inside the
+  //      image, its LDS slot -- is REBUILT per slab from the thread id (about ten integer instructions per item: these waves wait for
+  //      the transform of waves 0..3 anyway) instead of being carried through the slab loop in registers. ----
+  // p < 324: pixel (hy, hx) = (p / 18, p % 18); padding items (p >= 324, item 5 of most threads) and pixels outside the image are loaded
+  // from the patch's centre pixel and stored as zeros (padding items: not stored).  The LDS slot of item j is that of item 0 plus 64 j
+  // (the swizzle repeats every 16 slots): one address + immediates.
+  const int pix_origin = (y0 - 1) * a.w + (x0 - 1);  // (wave-uniform; negative on the top / left border: only invalid items would use it there)
+  auto item = [&](unsigned u, int j, unsigned& rel, bool& valid) __attribute__((always_inline)) {
+    const unsigned p = u + 64u * (unsigned)j;
+    const unsigned hy = (p * 3641u) >> 16;  // p / 18 for p < 1024
+    const unsigned hx = p - 18u * hy;
+    const int iy = y0 - 1 + (int)hy, ix = x0 - 1 + (int)hx;
+    valid = (int)(p < (unsigned)F4_NPIX) & (int)((unsigned)iy < (unsigned)a.h) & (int)((unsigned)ix < (unsigned)a.w);  // (no short circuit: no branches)
+    rel = valid ? hy * (unsigned)a.w + hx : (unsigned)(9 * a.w + 9);
+  };
   const size_t img0 = (size_t)b * a.h * a.w;
+  const unsigned img_px = (unsigned)(a.h * a.w);
+  // one descriptor per concatenated input, based at this image (the launch checks that an image stays below 2^31 bytes)
+  const __amdgpu_buffer_rsrc_t rs_in0 = f4_rsrc(a.in0 + img0 * a.c0, img_px * (unsigned)a.c0 * 4u);
+  const __amdgpu_buffer_rsrc_t rs_in1 = f4_rsrc(a.c1 ? a.in1 + img0 * a.c1 : a.in0, img_px * (unsigned)a.c1 * 4u);
   f32x4 ra[F4_APT];
   // unconditional loads from clamped addresses; out-of-image items are zeroed at the store (see cf_winograd.hip)
   auto load_A = [&](int chunk) __attribute__((always_inline)) {
-    const int c = chunk * CF_BK + k4 * 4;
+    // a slab lies in ONE of the concatenated inputs (c0 % 16 == 0): descriptor, channel stride and channel offset are wave-uniform
+    const int c = chunk * CF_BK;
     const bool first = c < a.c0;
-    const int cs = first ? a.c0 : a.c1;
-    const float* src = (first ? a.in0 : a.in1) + img0 * cs + (first ? c : c - a.c0);
+    const unsigned cs = (unsigned)(first ? a.c0 : a.c1);
+    const unsigned soff = (unsigned)(first ? c : c - a.c0) * 4u;
+    unsigned tl = (unsigned)tid & 255u;
+    asm volatile("" : "+v"(tl));  // opaque per slab (see above)
+    const unsigned k4x = (tl & 3u) * 4u;
 #pragma unroll
-    for (int j = 0; j < F4_APT; ++j) ra[j] = *reinterpret_cast<const f32x4*>(src + (size_t)((pcode[j] & 0x7fffffffu) >> 10) * cs);
+    for (int j = 0; j < F4_APT; ++j) {
+      unsigned rel;
+      bool valid;
+      item(tl >> 2, j, rel, valid);
+      const unsigned voff = (__umul24((unsigned)(pix_origin + (int)rel), cs) + k4x) * 4u;
+      ra[j] = first ? f4_ld128(rs_in0, voff, soff) : f4_ld128(rs_in1, voff, soff);
+    }
   };
   auto store_patch = [&](int chunk) __attribute__((always_inline)) {
-    float* const pb = smem + (chunk & 1) * F4_PATCH_FLOATS + k4 * 4;
+    unsigned tl = (unsigned)tid & 255u;
+    asm volatile("" : "+v"(tl));
+    const unsigned k4 = tl & 3u, slot = tl >> 2;
+    char* const pb = reinterpret_cast<char*>(smem + (chunk & 1) * F4_PATCH_FLOATS) + (((slot & ~3u) | ((slot ^ (slot >> 2)) & 3u)) * 64u + k4 * 16u);
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (affine) {
       sc = *reinterpret_cast<const f32x4*>(tab + chunk * CF_BK + k4 * 4);
@@ -183,7 +239,9 @@ __global__ __launch_bounds__(F4_THREADS, 1) void wf43_kernel(const F4Args a) {
     }
 #pragma unroll
     for (int j = 0; j < F4_APT; ++j) {
-      const bool valid = (int)pcode[j] >= 0;
+      unsigned rel;
+      bool valid;
+      item(slot, j, rel, valid);
       f32x4 v = ra[j];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -197,24 +255,20 @@ __global__ __launch_bounds__(F4_THREADS, 1) void wf43_kernel(const F4Args a) {
         if (PRO == CF_PRO_NONE) y = y * act_s;
         v[e] = valid ? y : 0.f;
       }
-      *reinterpret_cast<f32x4*>(pb + (pcode[j] & 1023u) * CF_BK) = v;
+      // item 5 covers pixels 320..383 of which 320..323 exist (lanes 0..15 of wave 4); the others would land past the buffer: skipped
+      if (j < 5 || tl < 16u) *reinterpret_cast<f32x4*>(pb + j * 4096) = v;
     }
   };
 
-  // ---- input transform of this group's xi half: item = (tile (ty, tx), channel pair cp): V[(3 grp + aa) * 6 + nu], aa = 0..2, nu = 0..5 ----
-  const int t_tx = lane >> 3, t_cp = lane & 7, t_ty = wave & 3;
-  // pixel (tile row r, tile column j) sits in slot (4 ty + r) * 36 + 4 tx + j, stored at its low two bits ^ ((slot >> 2) & 3) =
-  // ^ ((r + tx) & 3) for j < 4 and ^ ((r + tx + 1) & 3) for j = 4, 5 (36 ty * 9 and 9 r reduce to r mod 4): byte offset of column j
-  // inside the row = (j << 6) ^ sw[r & 3], resp. 256 + (((j - 4) << 6) ^ sw[(r + 1) & 3]).
-  const unsigned t_base = (unsigned)(((4 * t_ty) * F4_PWL + 4 * t_tx) * 64 + t_cp * 8);  // bytes from the patch buffer: tile row 0, column 0
-  unsigned sw[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) sw[k] = (unsigned)((t_tx + k) & 3) << 6;
-  const int t_tile = t_ty * 8 + t_tx;
-  const int t_st = (t_tile >> 2) & 3;
-  // hi word of channel pair cp: chunk cp >> 2 (0, 1), lo word: chunk 2 + (cp >> 2); chunks swizzled by the tile
-  float* const t_hi = V + (grp * 18) * F4_PS + t_tile * CF_BK + (((t_cp >> 2) ^ t_st) << 2) + (t_cp & 3);
-  float* const t_lo = V + (grp * 18) * F4_PS + t_tile * CF_BK + (((2 + (t_cp >> 2)) ^ t_st) << 2) + (t_cp & 3);
+  // ---- input transform (waves 0..3): item = (xi half tg, tile (ty, tx), channel pair cp): V[18 tg + aa * 6 + nu], aa = 0..2, nu = 0..5 ----
+  // Thread constants of the transform are REBUILT per slab from the lane id (a handful of integer instructions) instead of living
+  // in registers across the slab loop: at 128 registers hipcc spills such values and every reload is a wait on vmcnt(0).
+  const int tg = (wave >> 1) & 1;
+  // pixel (tile row r, tile column j) is slot 18 (4 ty + r) + 4 tx + j = 4 G + (q & 3) with q = 2 r + j and G = 18 ty + tx + 4 r + (q >> 2);
+  // it is stored at low bits (q & 3) ^ (G & 3), G & 3 = (2 ty + tx + (q >> 2)) & 3: byte offset from the buffer =
+  //   256 (18 ty + tx) + cp * 8  [t_base]  +  256 (4 r + (q >> 2))  [immediate]  +  (((q & 3) << 6) ^ sw[q >> 2]),  sw[k] = ((2 ty + tx + k) & 3) << 6
+  // (t_base has bits 6, 7 clear, so the swizzle of window k folds into it: tk[k] = t_base | sw[k], and a read costs one xor with 64 (q & 3))
+  float* t_hi;  // hi word of channel pair cp: quad cp >> 1 (swizzled by the tile row), word cp & 1; lo word two words further
   auto row_pass = [&](const f4_f32x2 (&zz)[6], int pos) __attribute__((always_inline)) {
     f4_f32x2 v[6];
     v[0] = (zz[0] + zz[4]) * 0.25f - zz[2] * 1.0625f;
@@ -228,23 +282,33 @@ __global__ __launch_bounds__(F4_THREADS, 1) void wf43_kernel(const F4Args a) {
     v[4] = e2 - o2;
     v[5] = (zz[1] + zz[5]) * 0.25f - zz[3] * 1.0625f;
 #pragma unroll
-    for (int nu = 0; nu < 6; ++nu) {  // operand split, store: [hi: 16 halves | lo: 16 halves] per (position, tile)
+    for (int nu = 0; nu < 6; ++nu) {  // operand split, store: per (position, tile) four quads of [4 hi halves | 4 lo halves]
       float hi, lo;
       cf_split_pair(v[nu][0], v[nu][1], hi, lo);
       t_hi[(pos + nu) * F4_PS] = hi;
-      t_lo[(pos + nu) * F4_PS] = lo;
+      t_hi[(pos + nu) * F4_PS + 2] = lo;
     }
   };
-  // Two parts keep the live set small (the accumulators hold 144 of the 256 registers): first the single row of the half (xi 0 from
-  // tile rows 0, 2, 4 / xi 5 from rows 1, 3, 5), then the even / odd pair (xi 1, 2 or 3, 4: tile rows 1..4).  `mid` runs between the
-  // column and the row pass of the second part (the slab's first weight fragments are requested there: fewest live registers).
+  // Two parts keep the live set small: first the single row of the half (xi 0 from tile rows 0, 2, 4 / xi 5 from rows 1, 3, 5), then
+  // the even / odd pair (xi 1, 2 or 3, 4: tile rows 1..4).  `mid` runs between the two row passes of the second part (the slab's first
+  // weight fragments are requested there: the first pass's column sums are dead, the live set is at its smallest).
   auto transform = [&](int chunk, auto mid) __attribute__((always_inline)) {
-    const char* const pb = reinterpret_cast<const char*>(smem + (chunk & 1) * F4_PATCH_FLOATS) + t_base;
+    const char* const pb = reinterpret_cast<const char*>(smem + (chunk & 1) * F4_PATCH_FLOATS);
+    unsigned ln = (unsigned)lane;
+    asm volatile("" : "+v"(ln));  // opaque per slab (see above)
+    const unsigned t_tile = 8u * (unsigned)(wave & 1) + (ln >> 3), t_cp = ln & 7u;
+    const unsigned t_ty = t_tile >> 2, t_tx = t_tile & 3u;
+    const unsigned t_base = 256u * (18u * t_ty + t_tx) + t_cp * 8u;
+    const unsigned tb0 = 2u * t_ty + t_tx;
+    unsigned tk[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tk[k] = t_base | (((tb0 + k) & 3u) << 6);
+    t_hi = V + (tg * 18) * F4_PS + t_tile * CF_BK + (((t_cp >> 1) ^ (unsigned)f4_vs((int)t_ty)) << 2) + (t_cp & 1u);
     auto px = [&](int r, int j) __attribute__((always_inline)) {  // (r, j compile-time after unrolling)
-      const unsigned off = j < 4 ? (((unsigned)j << 6) ^ sw[r & 3]) : (256u + (((unsigned)(j - 4) << 6) ^ sw[(r + 1) & 3]));
-      return *reinterpret_cast<const f4_f32x2*>(pb + r * (F4_PWL * 64) + off);
+      const int q = 2 * r + j;
+      return *reinterpret_cast<const f4_f32x2*>(pb + 256 * (4 * r + (q >> 2)) + (tk[q >> 2] ^ (((unsigned)q & 3u) << 6)));
     };
-    if (grp == 0) {
+    if (tg == 0) {
       {  // xi = 0: .25 (d0 + d4) - 1.0625 d2
         f4_f32x2 z[6];
 #pragma unroll
@@ -264,9 +328,9 @@ __global__ __launch_bounds__(F4_THREADS, 1) void wf43_kernel(const F4Args a) {
           if (j == 2) __builtin_amdgcn_sched_barrier(0);  // (keeps the reads of the later columns from being hoisted)
         }
         __builtin_amdgcn_sched_barrier(0);
-        mid();
-        __builtin_amdgcn_sched_barrier(0);
         row_pass(zp, 6);
+        __builtin_amdgcn_sched_barrier(0);
+        mid();
         __builtin_amdgcn_sched_barrier(0);
         row_pass(zm, 12);
       }
@@ -290,184 +354,256 @@ __global__ __launch_bounds__(F4_THREADS, 1) void wf43_kernel(const F4Args a) {
           if (j == 2) __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        mid();
-        __builtin_amdgcn_sched_barrier(0);
         row_pass(zp, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mid();
         __builtin_amdgcn_sched_barrier(0);
         row_pass(zm, 6);
       }
     }
   };
 
-  // ---- MFMA stage: wave = (xi half = grp, nu half, channel half) owns positions (3 grp + i / 3, 3 nuh + i % 3), i = 0..8, x 32 channels ----
-  const int m_nh = wave & 1, m_g = wave >> 1;
-  const int m_pos0 = (3 * (m_g >> 1)) * 6 + 3 * (m_g & 1);
-  f32x16 acc[9];
+  // ---- MFMA interval: wave = (xi half m_g, 16-channel block m_nb) owns positions 18 m_g + i, i = 0..17 ----
+  const int m_g = wave >> 2, m_nb = wave & 3;
+  f32x4 acc[18];
 #pragma unroll
-  for (int i = 0; i < 9; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  const size_t pos_stride = (size_t)a.nchunks * a.cout * CF_BK;
-  const float* const wbase = a.weight + (size_t)m_pos0 * pos_stride + (size_t)(n0 / 32 + m_nh) * 512;  // (wave-uniform)
-  f32x4 bq[4][2];  // ring of four positions: [slot][hi, lo]
-  auto load_B = [&](int chunk, int i) __attribute__((always_inline)) {
+  for (int i = 0; i < 18; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // weight fragments: descriptor over the packed tensor, lane offset 16 lane bytes, everything else in the scalar offset
+  const __amdgpu_buffer_rsrc_t rs_w = f4_rsrc(a.weight, 36u * (unsigned)a.cin * (unsigned)a.cout * 4u);
+  const unsigned w_pos = (unsigned)(a.nchunks * a.cout * CF_BK) * 4u;                                 // bytes between positions
+  const unsigned w_s0 = (unsigned)(18 * m_g) * w_pos + (unsigned)(n0 / 16 + m_nb) * 1024u;          // (wave-uniform)
+  constexpr std::integral_constant<int, 4> nb4{};
+  unsigned lane16;   // (rebuilt per slab, as a_base: see the transform)
+  f32x4 bq[4];  // ring of weight fragments: hi | lo
+  auto load_B = [&](int chunk, int i, auto nb) __attribute__((always_inline)) {
 #if !(F4_ABLATE & 16)
-    const float* wc = wbase + (size_t)((i / 3) * 6 + i % 3) * pos_stride + (size_t)chunk * a.cout * CF_BK + lane * 4;
-    bq[i & 3][0] = *reinterpret_cast<const f32x4*>(wc);
-    bq[i & 3][1] = *reinterpret_cast<const f32x4*>(wc + 256);
+    bq[i % decltype(nb)::value] = f4_ld128(rs_w, lane16, w_s0 + (unsigned)i * w_pos + (unsigned)chunk * (unsigned)(a.cout * CF_BK * 4));
 #endif
   };
-  const int m_st = (l31 >> 2) & 3;
-  const float* const a_hi = V + m_pos0 * F4_PS + l31 * CF_BK + ((half ^ m_st) << 2);        // row = tile l31, channels half*8 .. +7
-  const float* const a_lo = V + m_pos0 * F4_PS + l31 * CF_BK + (((2 + half) ^ m_st) << 2);
-  f32x4 va[2][2];  // A fragments of two positions: [slot][hi, lo]
-  auto read_A = [&](int i) __attribute__((always_inline)) {
-    va[i & 1][0] = *reinterpret_cast<const f32x4*>(a_hi + ((i / 3) * 6 + i % 3) * F4_PS);
-    va[i & 1][1] = *reinterpret_cast<const f32x4*>(a_lo + ((i / 3) * 6 + i % 3) * F4_PS);
+  auto set_lane16 = [&]() __attribute__((always_inline)) {
+    unsigned ln = (unsigned)lane;
+    asm volatile("" : "+v"(ln));
+    lane16 = ln * 16u;
   };
-  auto mfma = [&](f32x4 av, f32x4 bv, f32x16& c) __attribute__((always_inline)) {
+  const float* a_base;  // row = tile l15, channels 4 lq .. + 3
+  f32x4 va[4];  // A fragments: hi | lo
+  auto mfma = [&](float a0, float a1, float b0, float b1, f32x4& c) __attribute__((always_inline)) {
 #if F4_ABLATE & 1
-    c[0] += av[0] + bv[1];
+    c[0] += a0 + b1;
 #else
-    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f4_f16x8, av), __builtin_bit_cast(f4_f16x8, bv), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f4_f16x4, f4_f32x2{a0, a1}), __builtin_bit_cast(f4_f16x4, f4_f32x2{b0, b1}), c, 0, 0, 0);
 #endif
   };
-  // Position by position: lo*hi + hi*lo + hi*hi (the order of the F(2,3) kernels) into one accumulator -- back-to-back MFMAs with the
-  // same destination forward their result; only one wave per SIMD is in this stage at a time, the other one fills the issue slots
-  // with its transform.  A fragments one position ahead (two slots), B fragments four ahead (ring of four).
-  auto mma_stage = [&](int chunk) __attribute__((always_inline)) {  // B(0), B(1) of this slab were requested inside the transform
-    load_B(chunk, 2);
-    load_B(chunk, 3);
+  // Two positions at a time: lo*hi + hi*lo + hi*hi (the order of the F(2,3) kernels) into each position's accumulator, the two chains
+  // interleaved (an MFMA never waits for its predecessor's result).  B fragments: ring of four, positions 0..3 requested in the T
+  // interval.  A fragments: NA = 4 reads the next pair while this one multiplies (waves 0..3); NA = 2 reads it afterwards (waves
+  // 4..7, which carry the 24 gather registers through the end of this interval).
+  auto mma_stage = [&](int chunk, auto na, auto after_last_B) __attribute__((always_inline)) {
+    constexpr int NA = decltype(na)::value;
+    {
+      unsigned ln = (unsigned)lane;
+      asm volatile("" : "+v"(ln));
+      const unsigned t15 = ln & 15u;
+      a_base = V + (18 * m_g) * F4_PS + t15 * CF_BK + (((ln >> 4) ^ (unsigned)f4_vs((int)(t15 >> 2))) << 2);
+      lane16 = ln * 16u;
+    }
+    auto read_A = [&](int i) __attribute__((always_inline)) { va[i % NA] = *reinterpret_cast<const f32x4*>(a_base + i * F4_PS); };
     read_A(0);
+    read_A(1);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      if (i + 1 < 9) read_A(i + 1);
+    for (int i = 0; i < 18; i += 2) {
+      if (NA == 4 && i + 2 < 18) {
+        read_A(i + 2);
+        read_A(i + 3);
+      }
       __builtin_amdgcn_sched_barrier(0);
-      mfma(va[i & 1][1], bq[i & 3][0], acc[i]);
-      mfma(va[i & 1][0], bq[i & 3][1], acc[i]);
-      mfma(va[i & 1][0], bq[i & 3][0], acc[i]);
-      if (i + 4 < 9) load_B(chunk, i + 4);  // refill of the slot just consumed
+      const f32x4 a0 = va[i % NA], a1 = va[(i + 1) % NA], b0 = bq[i % 4], b1 = bq[(i + 1) % 4];
+      mfma(a0[2], a0[3], b0[0], b0[1], acc[i]);
+      mfma(a1[2], a1[3], b1[0], b1[1], acc[i + 1]);
+      mfma(a0[0], a0[1], b0[2], b0[3], acc[i]);
+      mfma(a1[0], a1[1], b1[2], b1[3], acc[i + 1]);
+      mfma(a0[0], a0[1], b0[0], b0[1], acc[i]);
+      mfma(a1[0], a1[1], b1[0], b1[1], acc[i + 1]);
+      if (NA == 2 && i + 2 < 18) {
+        read_A(i + 2);
+        read_A(i + 3);
+      }
+      if (i + 4 < 18) {  // refill of the two slots just consumed
+        load_B(chunk, i + 4, nb4);
+        load_B(chunk, i + 5, nb4);
+      }
+      // the gather request of waves 4..7 goes BEHIND the slab's last weight-fragment request: loads return in order, so a request
+      // placed earlier would have to land before the next fragment can be waited for
+      if (i + 4 == 16) after_last_B();
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  auto do_transform = [&](int s) __attribute__((always_inline)) {
-#if !(F4_ABLATE & 2)
-    transform(s, [&]() __attribute__((always_inline)) {
-      load_B(s, 0);
-      load_B(s, 1);
-    });
-#else
-    load_B(s, 0);
-    load_B(s, 1);
-#endif
-  };
-  auto feed = [&](int s) __attribute__((always_inline)) {  // prologue + store of slab s (if any), then the request for slab s + 1
+  constexpr std::integral_constant<int, 4> na4{};
+  constexpr std::integral_constant<int, 2> na2{};
+  auto feed = [&](int s) __attribute__((always_inline)) {  // waves 4..7: prologue + store of slab s (if any); its successor is requested inside the M interval
     if (s < n) {
 #if !(F4_ABLATE & 4)
       store_patch(s);
 #endif
-      if (s + 1 < n) load_A(s + 1);
     }
   };
 
-  // ---- slab loop: the two groups half a slab apart; every wave passes 2 n + 2 barriers ----
-  load_A(0);
-  __syncthreads();  // (the GroupNorm rows are in LDS)
-  feed(0);
-  __syncthreads();  // patch(0) visible
-  if (grp == 0) {
+  // ---- slab loop: two barrier intervals per slab; one loop per wave role (a common loop would keep the gather registers of waves 4..7
+  //      alive through the transform of waves 0..3: the allocator is per kernel, not per wave) ----
+  if (wave < 4) {
+    __syncthreads();
+    __syncthreads();  // patch(0) visible
+    F4_T(0);
     for (int s = 0; s < n; ++s) {
-      do_transform(s);
+#if !(F4_ABLATE & 2)
+      transform(s, [&]() __attribute__((always_inline)) {
+        set_lane16();
+        load_B(s, 0, nb4);
+        load_B(s, 1, nb4);
+      });
       __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();  // this group's V(s) visible; B is done with patch(s - 1)
-      mma_stage(s);
+      load_B(s, 2, nb4);
+      load_B(s, 3, nb4);
+#else
+      set_lane16();
+      for (int i = 0; i < 4; ++i) load_B(s, i, nb4);
+#endif
       __builtin_amdgcn_sched_barrier(0);
-      feed(s + 1);
+      F4_T(1);
+      __syncthreads();  // V(s) and patch(s + 1) visible
+      F4_T(2);
+      mma_stage(s, na4, []() __attribute__((always_inline)) {});
       __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();  // patch(s + 1) complete (B stored its items a phase earlier)
+      F4_T(3);
+      __syncthreads();  // V and patch(s) are free
+      F4_T(4);
     }
   } else {
-    for (int s = 0; s < n; ++s) {
-      if (s > 0) mma_stage(s - 1);
-      __builtin_amdgcn_sched_barrier(0);
+    load_A(0);
+    __syncthreads();  // (the GroupNorm rows are in LDS)
+    feed(0);
+    if (n > 1) load_A(1);
+    __syncthreads();
+    F4_T(0);
+    // (two loops: with the gather request under a condition inside one loop, hipcc's wait for the weight fragments requested before
+    //  it must also be right for the path without the request -- and then waits for the gather as well)
+    int s = 0;
+    for (; s + 2 < n; ++s) {
       feed(s + 1);
       __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();  // A is done with patch(s - 1) ... and this group's items of patch(s + 1) are written
-      do_transform(s);
+      set_lane16();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) load_B(s, i, nb4);
       __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();  // this group's V(s) visible
+      F4_T(1);
+      __syncthreads();
+      F4_T(2);
+      mma_stage(s, na2, [&]() __attribute__((always_inline)) { load_A(s + 2); });
+      __builtin_amdgcn_sched_barrier(0);
+      F4_T(3);
+      __syncthreads();
+      F4_T(4);
     }
-    mma_stage(n - 1);
+    for (; s < n; ++s) {  // the last two slabs: nothing left to request
+      feed(s + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      set_lane16();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) load_B(s, i, nb4);
+      __builtin_amdgcn_sched_barrier(0);
+      F4_T(1);
+      __syncthreads();
+      F4_T(2);
+      mma_stage(s, na2, []() __attribute__((always_inline)) {});
+      __builtin_amdgcn_sched_barrier(0);
+      F4_T(3);
+      __syncthreads();
+      F4_T(4);
+    }
   }
 
 #if F4_ABLATE & 8
   if (a.sft_w != 12345.f) return;
 #endif
-  // ---- epilogue: two passes (tile half th) through LDS: M[36 positions][16 tiles][64 channels] over the patch buffers + V ----
+  // ---- epilogue: two passes (tile columns 2 th, 2 th + 1) through LDS: M[36 positions][8 tiles][64 channels] over the patch buffers + V ----
+  // staging: accumulator register r of position i is tile 4 lq + r (tile row lq = lane >> 4, tile column r), channel 16 m_nb + (lane & 15); pass th takes
+  // r = 2 th, 2 th + 1 as staging tile tp = 2 lq + (r & 1).  item = (tp = wave, channel pair e_cp, output-row half e_rh).
   float* const Mst = smem;
-  const int e_t16 = wave * 2 + half;                       // tile within the pass's 16
-  const int e_cp = l31;                                    // channel pair within the 64 channels
+  const int e_cp = lane & 31, e_rh = lane >> 5;
   const float acc_s = a.acc_scale * act_is;                // (a product of powers of two: exact)
   const int nn = n0 + 2 * e_cp;
   f4_f32x2 bias2 = {0.f, 0.f};
   if (a.bias) bias2 = *reinterpret_cast<const f4_f32x2*>(a.bias + nn);
-  const unsigned e_rowc = (unsigned)a.w * (unsigned)a.cout;
-  double dsum = 0.0, dsq = 0.0, dsum1 = 0.0, dsq1 = 0.0;  // (channel 0 / 1 of the pair; joined below unless the group is one channel wide)
+  const unsigned e_rowc = (unsigned)a.w * (unsigned)a.cout * 4u;   // bytes between image rows
+  const unsigned e_px = (unsigned)a.cout * 4u;                       // ... between pixels
+  const unsigned e_img = img_px * (unsigned)a.cout * 4u;
+  const __amdgpu_buffer_rsrc_t rs_out = f4_rsrc(a.out + img0 * a.cout, e_img);
+  const __amdgpu_buffer_rsrc_t rs_res = f4_rsrc(EPI == CF_EPI_NONE ? a.out : a.res + img0 * a.cout, e_img);
+  const __amdgpu_buffer_rsrc_t rs_sft = f4_rsrc(EPI == CF_EPI_SFT ? a.sft_scale + img0 * a.cout : a.out, e_img);
+  const bool rh1 = e_rh != 0;
+  // xi contraction of this lane's two output rows: rows 0, 1 (e_rh = 0): tA = (s1 + s2) + m0, tB = .5 d1 + 2 d2;
+  //                                                 rows 2, 3 (e_rh = 1): tA = .25 s1 + 4 s2,  tB = (.125 d1 + 8 d2) + m5
+  const float ca1 = rh1 ? 0.25f : 1.f, ca2 = rh1 ? 4.f : 1.f, cb1 = rh1 ? 0.125f : 0.5f, cb2 = rh1 ? 8.f : 2.f;
 #pragma unroll
   for (int th = 0; th < 2; ++th) {  // (unrolled: `th` selects accumulator registers)
-    const int tile = th * 16 + e_t16;
-    const unsigned off0 = (((unsigned)b * a.h + (y0 + 4 * (tile >> 3))) * a.w + (x0 + 4 * (tile & 7))) * (unsigned)a.cout + nn;
+    unsigned e_zero = 0;
+    asm volatile("" : "+v"(e_zero));  // opaque 0 placed here: keeps hipcc from hoisting this pass's residual / SFT loads above the slab loop / the previous pass
+    // lane part: the output-row half and the channel pair; scalar part: the tile of this wave and pass
+    const unsigned voff0 = (unsigned)(2 * e_rh) * e_rowc + (unsigned)(2 * e_cp) * 4u + e_zero;
+    const unsigned soff0 = (unsigned)(y0 + 4 * (wave >> 1)) * e_rowc + (unsigned)(x0 + 4 * (2 * th + (wave & 1))) * e_px + (unsigned)n0 * 4u;
     // residual / SFT operands of this pass first: their latency overlaps the staging
-    f4_f32x2 r0[4][4], r1[4][4];
+    f4_f32x2 r0[2][4], r1[2][4];
 #pragma unroll
-    for (int aa = 0; aa < 4; ++aa)
+    for (int aa = 0; aa < 2; ++aa)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         r0[aa][c] = r1[aa][c] = f4_f32x2{0.f, 0.f};
-        if (a.epilogue == CF_EPI_RESIDUAL || a.epilogue == CF_EPI_SFT)
-          r0[aa][c] = *reinterpret_cast<const f4_f32x2*>(a.res + off0 + aa * e_rowc + c * a.cout);
-        if (a.epilogue == CF_EPI_SFT) r1[aa][c] = *reinterpret_cast<const f4_f32x2*>(a.sft_scale + off0 + aa * e_rowc + c * a.cout);
+        if (EPI == CF_EPI_RESIDUAL || EPI == CF_EPI_SFT) r0[aa][c] = f4_ld64(rs_res, voff0, soff0 + aa * e_rowc + c * e_px);
+        if (EPI == CF_EPI_SFT) r1[aa][c] = f4_ld64(rs_sft, voff0, soff0 + aa * e_rowc + c * e_px);
       }
     __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();  // the previous pass's reads (first pass: the last MMA stage's reads of V) are complete
+    F4_T(5);
+    if (th > 0) __syncthreads();  // the previous pass's reads are complete (first pass: the slab loop ended with a barrier)
+    F4_T(6);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      float* mp = Mst + ((m_pos0 + (i / 3) * 6 + i % 3) * 16 + 4 * half) * F4_BN + m_nh * 32 + l31;
-#pragma unroll
-      for (int r8 = 0; r8 < 8; ++r8) mp[((r8 & 3) + 8 * (r8 >> 2)) * F4_BN] = acc[i][th * 8 + r8];
+    for (int i = 0; i < 18; ++i) {
+      float* mp = Mst + ((18 * m_g + i) * 8 + 2 * (lane >> 4)) * F4_BN + m_nb * 16 + (lane & 15);
+      mp[0] = acc[i][2 * th];
+      mp[F4_BN] = acc[i][2 * th + 1];
     }
+    F4_T(5);
     __syncthreads();
-    // item (tile, channel pair): the xi axis per nu column (t[aa] = sum_xi A^T[aa][xi] M[xi][nu]), columns folded into the 4x4 outputs
-    const float* mq = Mst + e_t16 * F4_BN + 2 * e_cp;
-    f4_f32x2 o[4][4];
-    auto col = [&](int nu, f4_f32x2 (&t)[4]) __attribute__((always_inline)) {
-      f4_f32x2 m[6];
-#pragma unroll
-      for (int xi = 0; xi < 6; ++xi) m[xi] = *reinterpret_cast<const f4_f32x2*>(mq + ((xi * 6 + nu) * 16) * F4_BN);
-      const f4_f32x2 s1 = m[1] + m[2], d1 = m[1] - m[2], s2 = m[3] + m[4], d2 = m[3] - m[4];
-      t[0] = (m[0] + s1) + s2;
-      t[1] = d1 * 0.5f + d2 * 2.f;
-      t[2] = s1 * 0.25f + s2 * 4.f;
-      t[3] = (d1 * 0.125f + d2 * 8.f) + m[5];
+    F4_T(6);
+    const float* mq = Mst + wave * F4_BN + 2 * e_cp;
+    auto col = [&](int nu, f4_f32x2& tA, f4_f32x2& tB) __attribute__((always_inline)) {
+      auto m = [&](int xi) __attribute__((always_inline)) { return *reinterpret_cast<const f4_f32x2*>(mq + ((xi * 6 + nu) * 8) * F4_BN); };
+      const f4_f32x2 m1 = m(1), m2 = m(2), m3 = m(3), m4 = m(4);
+      const f4_f32x2 me = *reinterpret_cast<const f4_f32x2*>(mq + (((rh1 ? 5 : 0) * 6 + nu) * 8) * F4_BN);
+      const f4_f32x2 s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+      const f4_f32x2 x = s1 * ca1 + s2 * ca2, y = d1 * cb1 + d2 * cb2;
+      const f4_f32x2 xm = x + me, ym = y + me;
+      tA = rh1 ? x : xm;
+      tB = rh1 ? ym : y;
     };
+    f4_f32x2 o[2][4];
     {
-      f4_f32x2 t0[4], ta[4], tb[4];
-      col(0, t0);
-      col(1, ta);
-      col(2, tb);
+      f4_f32x2 t0[2], ta[2], tb[2];
+      col(0, t0[0], t0[1]);
+      col(1, ta[0], ta[1]);
+      col(2, tb[0], tb[1]);
 #pragma unroll
-      for (int aa = 0; aa < 4; ++aa) {
+      for (int aa = 0; aa < 2; ++aa) {
         const f4_f32x2 s = ta[aa] + tb[aa], d = ta[aa] - tb[aa];
         o[aa][0] = t0[aa] + s;
         o[aa][1] = d * 0.5f;
         o[aa][2] = s * 0.25f;
         o[aa][3] = d * 0.125f;
       }
-      col(3, ta);
-      col(4, tb);
-      col(5, t0);
+      col(3, ta[0], ta[1]);
+      col(4, tb[0], tb[1]);
+      col(5, t0[0], t0[1]);
 #pragma unroll
-      for (int aa = 0; aa < 4; ++aa) {
+      for (int aa = 0; aa < 2; ++aa) {
         const f4_f32x2 s = ta[aa] + tb[aa], d = ta[aa] - tb[aa];
         o[aa][0] += s;
         o[aa][1] += d * 2.f;
@@ -475,15 +611,16 @@ __global__ __launch_bounds__(F4_THREADS, 1) void wf43_kernel(const F4Args a) {
         o[aa][3] += d * 8.f + t0[aa];
       }
     }
+    double dsum = 0.0, dsq = 0.0, dsum1 = 0.0, dsq1 = 0.0;  // (channel 0 / 1 of the pair; joined below: the pair lies in one group)
 #pragma unroll
-    for (int aa = 0; aa < 4; ++aa) {
+    for (int aa = 0; aa < 2; ++aa) {
       f4_f32x2 rs = {0.f, 0.f}, rq = {0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         f4_f32x2 v = o[aa][c] * acc_s + bias2;
-        if (a.epilogue == CF_EPI_RESIDUAL) v += r0[aa][c];
-        else if (a.epilogue == CF_EPI_SFT) v = r0[aa][c] + a.sft_w * (r0[aa][c] * r1[aa][c] + v);
-        *reinterpret_cast<f4_f32x2*>(a.out + off0 + aa * e_rowc + c * a.cout) = v;
+        if (EPI == CF_EPI_RESIDUAL) v += r0[aa][c];
+        else if (EPI == CF_EPI_SFT) v = r0[aa][c] + a.sft_w * (r0[aa][c] * r1[aa][c] + v);
+        f4_st64(v, rs_out, voff0, soff0 + aa * e_rowc + c * e_px);
         rs += v;
         rq += v * v;
       }
@@ -492,40 +629,49 @@ __global__ __launch_bounds__(F4_THREADS, 1) void wf43_kernel(const F4Args a) {
       dsum1 += (double)rs[1];
       dsq1 += (double)rq[1];
     }
-  }
-  if (a.stats_out) {
-    // GroupNorm statistics of the values this wave wrote (2 tiles x 2 passes x 64 channels): fp64 partials, fixed shuffle order; one
-    // partial per (image, group, patch, wave): nparts = tiles_per_img * 8
-    const int cpg = a.stats_cpg;
-    dsum += dsum1;  // (the pair belongs to one group: cpg is even)
-    dsq += dsq1;
-    dsum += __shfl_xor(dsum, 32, 64);  // the wave's two tiles
-    dsq += __shfl_xor(dsq, 32, 64);
-    for (int o2 = 1; o2 * 2 < cpg; o2 <<= 1) {  // adjacent channel pairs of one group (cpg >= 4)
-      dsum += __shfl_xor(dsum, o2, 64);
-      dsq += __shfl_xor(dsq, o2, 64);
+    if (a.stats_out) {
+      // GroupNorm statistics of the values this wave wrote in this pass (one tile x 64 channels): fp64 partials, fixed shuffle order;
+      // one partial per (image, group, patch, pass, wave): nparts = tiles_per_img * 16
+      const int cpg = a.stats_cpg;
+      dsum += dsum1;  // (the pair belongs to one group: cpg is even)
+      dsq += dsq1;
+      dsum += __shfl_xor(dsum, 32, 64);  // the two output-row halves
+      dsq += __shfl_xor(dsq, 32, 64);
+      for (int o2 = 1; o2 * 2 < cpg; o2 <<= 1) {  // adjacent channel pairs of one group
+        dsum += __shfl_xor(dsum, o2, 64);
+        dsq += __shfl_xor(dsq, o2, 64);
+      }
+      if (e_rh == 0 && (nn % cpg) == 0) {
+        const size_t pidx = ((size_t)rt * 2 + th) * 8 + wave;
+        const int ng = a.cout / cpg;
+        double* op = a.stats_out + (((size_t)b * ng + nn / cpg) * a.nparts + pidx) * 2;
+        op[0] = dsum;
+        op[1] = dsq;
+      }
     }
-    if (half == 0 && (nn % cpg) == 0) {
-      const size_t pidx = (size_t)rt * 8 + wave;
-      const int ng = a.cout / cpg;
-      double* op = a.stats_out + (((size_t)b * ng + nn / cpg) * a.nparts + pidx) * 2;
-      op[0] = dsum;
-      op[1] = dsq;
-    }
+    F4_T(7);
   }
+#if F4_TIMING
+  if (blockIdx.x == gridDim.x / 2 + 8 && lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f4_timing_buf[wave * 16 + k] = tacc[k];
+    f4_timing_buf[wave * 16 + 8] = tlast - tstart;
+    f4_timing_buf[wave * 16 + 9] = (unsigned long long)n;
+  }
+#endif
 }
 
 // U' = scale * G' g G'^T (fp64, rounded once to fp32) as hi = f16(U'), lo = f16(U' - hi), in MFMA-operand order
-// [pos = xi*6 + nu][cin_pad/16][cout_pad/32][part: hi, lo][lane 64][4 words]; a lane's 16 bytes are the 8 halves of
-// U'[n = tile*32 + (lane&31)][c = chunk*16 + (lane>>5)*8 + 0..7]  (v_mfma_f32_32x32x16_f16 B operand).
+// [pos = xi*6 + nu][cin_pad/16][cout_pad/16][lane 64][4 words: hi, hi, lo, lo]; a lane's 16 bytes are the hi and the lo halves of
+// U'[n = block*16 + (lane&15)][c = chunk*16 + (lane>>4)*4 + 0..3]  (v_mfma_f32_16x16x16_f16 B operand, hi | lo in one dwordx4).
 __global__ void pack_weight_wf43_kernel(const float* __restrict__ w, int cout, int cin, int cout_pad, int nchunks, float scale,
                                         unsigned* __restrict__ packed, long total) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one 32-bit word = two halves
   if (i >= total) return;
-  const int e = (int)(i & 3), ln = (int)((i >> 2) & 63), part = (int)((i >> 8) & 1);
-  long r = i >> 9;
-  const int ntiles = cout_pad / 32;
-  const int nn = (int)(r % ntiles) * 32 + (ln & 31);
+  const int e = (int)(i & 1), part = (int)((i >> 1) & 1), ln = (int)((i >> 2) & 63);
+  long r = i >> 8;
+  const int ntiles = cout_pad / 16;
+  const int nn = (int)(r % ntiles) * 16 + (ln & 15);
   r /= ntiles;
   const int chunk = (int)(r % nchunks);
   const int pos = (int)(r / nchunks);
@@ -536,7 +682,7 @@ __global__ void pack_weight_wf43_kernel(const float* __restrict__ w, int cout, i
   unsigned out = 0;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    const int c = chunk * CF_BK + (ln >> 5) * 8 + e * 2 + h;
+    const int c = chunk * CF_BK + (ln >> 4) * 4 + e * 2 + h;
     float val = 0.f;
     if (nn < cout && c < cin) {
       const float* g = w + ((long)nn * cin + c) * 9;
@@ -583,13 +729,16 @@ int cf_wf43_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query) 
   CF_REQUIRE(d->cout % F4_BN == 0 && d->cout_pad == d->cout, "cf_conv2d(winograd 2): needs cout == cout_pad, a multiple of 64 (got %d / %d)",
              d->cout, d->cout_pad);
   CF_REQUIRE((long)d->hout * d->wout <= (1L << 21), "cf_conv2d(winograd 2): at most 2^21 pixels per image (got %dx%d)", d->hout, d->wout);
+  CF_REQUIRE((long)d->hout * d->wout * (d->c0 > d->cout ? d->c0 : d->cout) * 4 < (1L << 31) && (long)d->hout * d->wout * d->c1 * 4 < (1L << 31),
+             "cf_conv2d(winograd 2): an image of a tensor must stay below 2^31 bytes (%dx%d, %d / %d / %d channels)", d->hout, d->wout, d->c0, d->c1, d->cout);
   CF_REQUIRE(d->c0 + d->c1 <= F4_TAB, "cf_conv2d(winograd 2): at most %d input channels (got %d)", F4_TAB, d->c0 + d->c1);
   CF_REQUIRE(d->epilogue == CF_EPI_NONE || d->epilogue == CF_EPI_RESIDUAL || d->epilogue == CF_EPI_SFT,
              "cf_conv2d(winograd 2): epilogues are none / residual / SFT");
   CF_REQUIRE(d->pad_mode == CF_PAD_ZERO && (d->ld_in0 == 0 || d->ld_in0 == d->c0) && (d->ld_in1 == 0 || d->ld_in1 == d->c1) &&
                  (d->ld_out == 0 || d->ld_out == d->cout) && d->split_k < 1,
              "cf_conv2d(winograd 2): reads / writes dense tensors with zero padding, no split_k");
-  CF_REQUIRE(d->stats_cpg == 0 || (d->stats_cpg <= 64 && d->stats_cpg % 2 == 0), "cf_conv2d(winograd 2): stats_cpg %d (even, at most 64)", d->stats_cpg);
+  CF_REQUIRE(d->stats_cpg == 0 || (d->stats_cpg <= 64 && (d->stats_cpg & (d->stats_cpg - 1)) == 0 && d->stats_cpg >= 2),
+             "cf_conv2d(winograd 2): stats_cpg %d (a power of two, 2..64)", d->stats_cpg);
   F4Args a;
   a.in0 = d->in0;
   a.in1 = d->in1;
@@ -617,24 +766,38 @@ int cf_wf43_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query) 
   a.stats_cpg = d->stats_cpg > 0 ? d->stats_cpg : 2;
   a.tiles_x = d->wout / F4_TW;
   a.tiles_per_img = a.tiles_x * (d->hout / F4_TH);
-  a.nparts = a.tiles_per_img * 8;
+  a.nparts = a.tiles_per_img * 16;
   a.ntn = d->cout / F4_BN;
   if (parts_query) {
     *parts_query = a.nparts;
     return CF_OK;
   }
+#if F4_TIMING
+  const size_t lds = F4_LDS_FLOATS * sizeof(float) + (getenv("CF_F43_ONE_WG") ? 32768 : 0);   // experiment: one workgroup per CU
+#else
   constexpr size_t lds = F4_LDS_FLOATS * sizeof(float);
-  CF_LDS_ATTR((wf43_kernel<CF_PRO_NONE>), lds);  // (cf_device_init sets the dynamic-LDS attribute on each device)
-  CF_LDS_ATTR((wf43_kernel<CF_PRO_AFFINE>), lds);
-  CF_LDS_ATTR((wf43_kernel<CF_PRO_AFFINE_SWISH>), lds);
-  CF_LDS_ATTR((wf43_kernel<CF_PRO_LEAKY>), lds);
+#endif
   const dim3 grid(a.tiles_per_img * d->batch * a.ntn), block(F4_THREADS);
+  // (cf_device_init sets the dynamic-LDS attribute of every instantiation on each device)
+#define F4_LAUNCH(P, E)                                                            \
+  do {                                                                             \
+    CF_LDS_ATTR((wf43_kernel<P, E>), F4_LDS_FLOATS * sizeof(float) + (F4_TIMING ? 32768 : 0));   \
+    hipLaunchKernelGGL((wf43_kernel<P, E>), grid, block, lds, stream, a);          \
+  } while (0)
+#define F4_LAUNCH_EPI(P)                                                           \
+  do {                                                                             \
+    if (d->epilogue == CF_EPI_RESIDUAL) F4_LAUNCH(P, CF_EPI_RESIDUAL);             \
+    else if (d->epilogue == CF_EPI_SFT) F4_LAUNCH(P, CF_EPI_SFT);                  \
+    else F4_LAUNCH(P, CF_EPI_NONE);                                                \
+  } while (0)
   switch (d->prologue) {
-    case CF_PRO_AFFINE: hipLaunchKernelGGL((wf43_kernel<CF_PRO_AFFINE>), grid, block, lds, stream, a); break;
-    case CF_PRO_AFFINE_SWISH: hipLaunchKernelGGL((wf43_kernel<CF_PRO_AFFINE_SWISH>), grid, block, lds, stream, a); break;
-    case CF_PRO_LEAKY: hipLaunchKernelGGL((wf43_kernel<CF_PRO_LEAKY>), grid, block, lds, stream, a); break;
-    default: hipLaunchKernelGGL((wf43_kernel<CF_PRO_NONE>), grid, block, lds, stream, a); break;
+    case CF_PRO_AFFINE: F4_LAUNCH_EPI(CF_PRO_AFFINE); break;
+    case CF_PRO_AFFINE_SWISH: F4_LAUNCH_EPI(CF_PRO_AFFINE_SWISH); break;
+    case CF_PRO_LEAKY: F4_LAUNCH_EPI(CF_PRO_LEAKY); break;
+    default: F4_LAUNCH_EPI(CF_PRO_NONE); break;
   }
+#undef F4_LAUNCH_EPI
+#undef F4_LAUNCH
   CF_CHECK_LAUNCH("cf_conv2d(winograd F(4,3) f16x2)");
   return CF_OK;
 }

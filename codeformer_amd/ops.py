@@ -104,10 +104,11 @@ F43_LAYERS = os.environ.get('CODEFORMER_HIP_F43', 'c64')
 
 
 def f43_ok(cin, cout, hout, wout):
-    """Shapes the F(4x4,3x3) kernel covers (3x3 stride-1 dense NHWC): whole 16x32 output patches, 64-wide channel tiles."""
+    """Shapes the F(4x4,3x3) kernel covers (3x3 stride-1 dense NHWC): whole 16x16 output patches, 64-wide channel tiles, at most 256
+    input channels (the GroupNorm rows of an image sit in LDS)."""
     if F43_LAYERS == '0' or (F43_LAYERS == 'c64' and cout != 64):
         return False
-    return cin % 16 == 0 and cin <= 512 and cout % 64 == 0 and hout % 16 == 0 and wout % 32 == 0
+    return cin % 16 == 0 and cin <= 256 and cout % 64 == 0 and hout % 16 == 0 and wout % 16 == 0
 
 
 # Smallest per-image input of the DIRECT split-half kernel and of the eight-wave Winograd kernel.  The 16x16 latents are below it: with

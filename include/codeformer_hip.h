@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 18
+#define CF_ABI_VERSION 19
 
 typedef void* cf_stream_t; /* hipStream_t */
 
@@ -157,11 +157,11 @@ typedef struct cf_conv_desc {
                              MFMAs per product, fp32 accumulation -- 4/9 of the split-half MFMA work of the direct form.
                              With CF_OPERAND_F16 / CF_OPERAND_BF16 (cout % 128 == 0, >= 32x32 pixels): single rounded operands,
                              one MFMA per product (weight: see cf_pack_conv_weight_winograd_bf16).
-                             2 (ABI v18): Winograd F(4x4,3x3) with CF_OPERAND_F16X2 operands only (`weight` from
+                             2 (ABI v18; v19: 16x16 patches and the weight layout below): Winograd F(4x4,3x3) with CF_OPERAND_F16X2 operands only (`weight` from
                              cf_pack_conv_weight_winograd43_f16x2, acc_scale set): 36 transform-domain GEMMs per 4x4 outputs = 2.25
                              products per output and input channel instead of 4, interpolation points (0, +-1/2, +-2, inf).  Dense
-                             NHWC, zero padding, hout % 16 == 0, wout % 32 == 0, cout == cout_pad, cout % 64 == 0, cin % 16 == 0,
-                             cin <= 512; prologues / epilogues / statistics / act_scale as winograd 1, no split_k.  Its error
+                             NHWC, zero padding, hout % 16 == 0, wout % 16 == 0, cout == cout_pad, cout % 64 == 0, cin % 16 == 0,
+                             cin <= 256, an image of any of its tensors below 2^31 bytes; prologues / epilogues / statistics / act_scale as winograd 1, no split_k.  Its error
                              against fp64 is ~5x that of F(2x2,3x3) (the conditioning of the larger transform), far inside the
                              1e-3 pixel gate but too close for layers that decide code indices: the host uses it for generator /
                              CFT convolutions only (vqgan_arch.py:296-323, codeformer_arch.py:136-157), never in the encoder */
@@ -206,8 +206,8 @@ int cf_pack_conv_weight_winograd(const float* w, int cout, int cin, int cout_pad
 int cf_pack_conv_weight_winograd_f16x2(const float* w, int cout, int cin, int cout_pad, int cin_pad, float scale, void* packed,
                                        cf_stream_t stream);
 /* winograd == 2 (F(4x4,3x3)) + CF_OPERAND_F16X2: scale * U', U' = G' g G'^T with the rows of G scaled by (4, 4, 4, 2, 2, 4) (the input
- * transform carries the inverse powers of two), as hi + lo IEEE halves in MFMA-operand order [36 positions][cin_pad/16][cout_pad/32]
- * [hi, lo][64 lanes][4 words] = 36*cin_pad*cout_pad 32-bit words; cout_pad % 64 == 0; `scale` a power of two that puts
+ * transform carries the inverse powers of two), as hi + lo IEEE halves in MFMA-operand order [36 positions][cin_pad/16][cout_pad/16]
+ * [64 lanes][hi 2 words | lo 2 words] (ABI v19: the 16x16x16 MFMA's B operand) = 36*cin_pad*cout_pad 32-bit words; cout_pad % 64 == 0; `scale` a power of two that puts
  * max|scale * U'| into [2^14, 2^15) (cf_conv_desc.acc_scale = 1 / scale) */
 int cf_pack_conv_weight_winograd43_f16x2(const float* w, int cout, int cin, int cout_pad, int cin_pad, float scale, void* packed,
                                          cf_stream_t stream);

@@ -33,7 +33,7 @@ def test_header_symbols_are_exported(native):
 
 
 def test_version_and_error_string(native):
-    assert native.cf_version() == lib.ABI_VERSION == 18
+    assert native.cf_version() == lib.ABI_VERSION == 19
     assert isinstance(lib.last_error(), str)
 
 
@@ -92,20 +92,20 @@ def test_argument_errors_are_reported_without_a_gpu(native):
     assert native.cf_act_scale_fused(None, 0, 1, 8, 1, 1024, 1, 4.0, 1, 1, None) == -1
     assert native.cf_act_scale_fused(None, 0, None, 0, 1, 1022, 1, 4.0, 1, 1, None) == -1 and 'multiple of 4' in lib.last_error()
     assert native.cf_act_scale_fused(1, 8, None, 0, None, 0, 1, 4.0, None, 1, None) == -1
-    # ABI v18: winograd == 2 (F(4x4,3x3), split-half operands only, 16x32 output patches, 64-wide channel tiles) and its weight form
+    # ABI v19: winograd == 2 (F(4x4,3x3), split-half operands only, 16x16 output patches, 64-wide channel tiles, cin <= 256) and its weight form
     d = lib.ConvDesc(in0=1, weight=1, out=1, taps=9, stride=1, batch=1, hin=32, win=32, hout=32, wout=32, c0=64, cout=64,
                      cout_pad=64, bf16_mfma=0, acc_scale=1.0, winograd=2)
     assert native.cf_conv2d(ctypes.byref(d), None) == -1 and 'split-half' in lib.last_error()
     d.bf16_mfma, d.acc_scale = 3, 0.0
     assert native.cf_conv2d(ctypes.byref(d), None) == -1 and 'acc_scale' in lib.last_error()
     d.acc_scale, d.hout, d.hin = 1.0, 24, 24
-    assert native.cf_conv2d(ctypes.byref(d), None) == -1 and '16x32' in lib.last_error()
+    assert native.cf_conv2d(ctypes.byref(d), None) == -1 and '16x16' in lib.last_error()
     d.hout, d.hin, d.split_k = 32, 32, 1
     assert native.cf_conv2d(ctypes.byref(d), None) == -1 and 'split_k' in lib.last_error()
     d.split_k, d.winograd = 0, 3
     assert native.cf_conv2d(ctypes.byref(d), None) == -1 and 'winograd must be' in lib.last_error()
     d.winograd, d.stats_cpg = 2, 2
-    assert native.cf_conv2d_stats_parts(ctypes.byref(d)) == 16       # eight partials per 16x32 patch, two patches per 32x32 image
+    assert native.cf_conv2d_stats_parts(ctypes.byref(d)) == 64       # sixteen partials per 16x16 patch, four patches per 32x32 image
     assert native.cf_pack_conv_weight_winograd43_f16x2(1, 64, 64, 64, 64, 3.0, 1, None) == -1 and 'power of two' in lib.last_error()
     assert native.cf_pack_conv_weight_winograd43_f16x2(1, 64, 64, 96, 64, 2.0, 1, None) == -1 and 'padding' in lib.last_error()
 

@@ -108,7 +108,7 @@ SMALL = [dict(B=1, H=16, W=32, cin=16, cout=64),
          dict(B=1, H=48, W=32, cin=32, cout=128, prologue=ops.PRO_AFFINE, stats=True, seed=4),
          dict(B=1, H=32, W=32, cin=256, cout=256, prologue=ops.PRO_AFFINE_SWISH, stats=True, seed=5),
          dict(B=3, H=16, W=64, cin=64, cout=64, c_split=48, seed=6),
-         dict(B=1, H=32, W=32, cin=512, cout=64, prologue=ops.PRO_AFFINE_SWISH, seed=7),
+         dict(B=1, H=32, W=32, cin=256, cout=64, prologue=ops.PRO_AFFINE_SWISH, seed=7),
          # magnitudes: the pack-time weight scale and the per-image activation scale must absorb them
          dict(B=1, H=16, W=32, cin=64, cout=64, wscale=300.0, seed=9),
          dict(B=2, H=16, W=32, cin=64, cout=64, wscale=1e-4, xscale=1e9, seed=10),

@@ -7,7 +7,7 @@ i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" \
            "SQ_INST_CYCLES_VMEM SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE" \
-           "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+           "SQ_WAVES SQ_LEVEL_WAVES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1)); rm -rf /tmp/ps$i
   timeout 120 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/ps$i -o p -- python tools/split_one.py "$@" > gpurun_out/pmcsplit_${tag}_run$i.log 2>&1
   echo "set $i rc=$?"
@@ -21,7 +21,7 @@ for f in sorted(glob.glob('/tmp/ps*/**/*counter_collection.csv', recursive=True)
     seen = set()
     for r in csv.DictReader(open(f)):
         name = r['Kernel_Name']
-        if 'split_conv' in name or 'winograd' in name or 'igemm' in name or 'wsplit' in name:
+        if 'split_conv' in name or 'winograd' in name or 'igemm' in name or 'wsplit' in name or 'wf43_kernel' in name:
             key = name.replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0][:64]
             agg[key][r['Counter_Name']].append(float(r['Counter_Value']))
             if (f, r['Dispatch_Id']) not in seen:

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from codeformer_amd import ops
 cin, cout, H, swish, up = (int(v) for v in sys.argv[1:6])
 reps = int(sys.argv[6]) if len(sys.argv) > 6 else 5
-code = {'split': ops.SPLIT, 'wino': ops.WINOGRAD, 'wsplit': ops.WSPLIT, 'direct': 0}[os.environ.get('CONV_KIND', 'split')]
+code = {'split': ops.SPLIT, 'wino': ops.WINOGRAD, 'wsplit': ops.WSPLIT, 'wf43': ops.WF43, 'direct': 0}[os.environ.get('CONV_KIND', 'split')]
 B = 16
 x = torch.randn(B, H, H, cin, device='cuda')
 pw = ops.pack_weight(torch.randn(cout, cin, 3, 3, device='cuda') * 0.05, torch.randn(cout, device='cuda'), bf16=code, up2x=bool(up))

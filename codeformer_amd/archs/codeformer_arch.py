@@ -262,9 +262,13 @@ class CodeFormer(VQAutoEncoder):
         # bound even B=1), so it is off by default; useful when the host thread is busy (decode / encode of PNGs).
         # Round 3 re-measurement: with the faster kernels a one-face call is host-bound in places when run eagerly (the Transformer section:
         # 1.6 ms of host enqueue for 0.9 ms of GPU work), and replay takes the whole call from 6.76 to 6.55 ms on a box where the host is the
-        # slower side; it stays opt-in because a replayed graph cannot notice in-place parameter updates (only load_state_dict / .to() /
-        # invalidate_packed_weights() drop it) and pins the activations of every captured shape.
-        self.use_hip_graphs = os.environ.get('CODEFORMER_HIP_GRAPHS', '0') == '1'
+        # slower side.  Round 4: 'auto' (default) replays a graph for batches of at most `graph_max_batch` faces -- the reference's own call
+        # pattern is one face per call (inference_codeformer.py:197-206) -- behind a parameter signature (sum of the parameters' versions
+        # and storage addresses, ~70 us per call): a versioned in-place update, load_state_dict, .to() or invalidate_packed_weights() all
+        # re-capture; only an un-versioned `.data` edit needs the explicit invalidate_packed_weights() the packed-weight cache needs too.
+        # '1': every batch size; '0': never.  At most four captured graphs are kept (each pins the activations of its shape).
+        self.use_hip_graphs = {'0': False, '1': True}.get(os.environ.get('CODEFORMER_HIP_GRAPHS', 'auto'), 'auto')
+        self.graph_max_batch = 4
         self._graphs = {}
         self.connect_list = connect_list
         self.n_layers = n_layers
@@ -380,9 +384,10 @@ class CodeFormer(VQAutoEncoder):
     def _forward_graphed(self, x, w, code_only, adain):
         """Capture-once / replay-many execution of _forward_hip on the current stream.  Outputs are copies, so callers may
         keep them across calls.  A graph is re-captured when any packed weight was rebuilt since its capture."""
-        key = (tuple(x.shape), float(w), bool(code_only), bool(adain), self.precision, self.encoder_precision, self.gemm_precision, bool(self.winograd), bool(self.winograd_encoder), bool(self.winograd_f43), str(x.device))
+        key = (tuple(x.shape), float(w), bool(code_only), bool(adain), self.precision, self.encoder_precision, self.gemm_precision, bool(self.winograd), bool(self.winograd_encoder), bool(self.winograd_f43), str(x.device), ops.switches())
         ent = self._graphs.get(key)
-        if ent is None or ent['epoch'] != PACK_EPOCH[0]:
+        sig = self._param_signature()
+        if ent is None or ent['epoch'] != PACK_EPOCH[0] or ent['sig'] != sig:
             static_x = x.float().contiguous().clone()
             for _ in range(2):                      # warm-up: packs weights, sets kernel attributes, primes the allocator
                 self._forward_hip(static_x, w, code_only, adain)
@@ -390,7 +395,10 @@ class CodeFormer(VQAutoEncoder):
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 outs = self._forward_hip(static_x, w, code_only, adain)
-            ent = {'graph': graph, 'x': static_x, 'outs': outs, 'epoch': PACK_EPOCH[0], 'idx': getattr(self, 'last_indices', None)}
+            ent = {'graph': graph, 'x': static_x, 'outs': outs, 'epoch': PACK_EPOCH[0], 'sig': sig, 'idx': getattr(self, 'last_indices', None)}
+            self._graphs.pop(key, None)
+            while len(self._graphs) >= 4:           # oldest first: a graph pins the activations of its shape
+                self._graphs.pop(next(iter(self._graphs)))
             self._graphs[key] = ent
         ent['x'].copy_(x)
         ent['graph'].replay()
@@ -398,23 +406,35 @@ class CodeFormer(VQAutoEncoder):
             self.last_indices = ent['idx']
         return tuple(o.clone() for o in ent['outs'])
 
+    def _param_signature(self):
+        """(sum of versions, sum of storage addresses) over the parameters and buffers: changes with every versioned in-place update and
+        every re-allocation; the tensor list is cached (rebuilt by load_state_dict / _apply / invalidate_packed_weights)."""
+        ts = self.__dict__.get('_sig_tensors')
+        if ts is None:
+            ts = self.__dict__['_sig_tensors'] = list(self.parameters()) + list(self.buffers())
+        return (sum(t._version for t in ts), sum(t.data_ptr() for t in ts))
+
     def load_state_dict(self, *args, **kwargs):
         self._graphs.clear()                       # captured graphs point at the old packed weights
+        self.__dict__.pop('_sig_tensors', None)
         return super().load_state_dict(*args, **kwargs)
 
     def _apply(self, fn, *args, **kwargs):         # .to() / .cuda() / .float(): parameters move, graphs are stale
         if getattr(self, '_graphs', None):
             self._graphs.clear()
+        self.__dict__.pop('_sig_tensors', None)
         return super()._apply(fn, *args, **kwargs)
 
     def invalidate_packed_weights(self):
         self._graphs.clear()
+        self.__dict__.pop('_sig_tensors', None)
         super().invalidate_packed_weights()
 
     def forward(self, x, w=0, detach_16=True, code_only=False, adain=False):
         if x.is_cuda:
             with torch.no_grad():
-                if self.use_hip_graphs and ops.PROFILE is None:
+                graphed = self.use_hip_graphs is True or (self.use_hip_graphs == 'auto' and x.shape[0] <= self.graph_max_batch)
+                if graphed and ops.PROFILE is None and not torch.cuda.is_current_stream_capturing():
                     return self._forward_graphed(x, w, code_only, adain)
                 return self._forward_hip(x, w, code_only, adain)
         return self._forward_host(x, w, detach_16, code_only, adain)

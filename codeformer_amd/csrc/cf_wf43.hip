@@ -46,8 +46,8 @@
 //   * epilogue: two passes (tile columns 0, 1 / 2, 3) through LDS: M[36][8 tiles][64 ch] over patch buffers + V; item = (tile, channel
 //     pair, output-row half): reads 30 of the tile's 36 transform-domain values, contracts xi for its two output rows and nu for the
 //     four columns, applies acc_scale / bias / residual / SFT, stores 8-byte pairs (a half-wave writes 256 contiguous bytes per pixel) and
-//     accumulates the GroupNorm statistics of what it wrote (fp32 over four values, then fp64; fixed shuffle order: sixteen partials
-//     per patch and group).
+//     accumulates the GroupNorm statistics of what it wrote (fp32 over four values, then fp64; fixed shuffle order, the waves joined
+//     through LDS in wave order: one partial per patch and group).
 #include <cstdlib>
 #include <type_traits>
 
@@ -544,6 +544,7 @@ __global__ __launch_bounds__(F4_THREADS, 4) void wf43_kernel(const F4Args a) {
   // xi contraction of this lane's two output rows: rows 0, 1 (e_rh = 0): tA = (s1 + s2) + m0, tB = .5 d1 + 2 d2;
   //                                                 rows 2, 3 (e_rh = 1): tA = .25 s1 + 4 s2,  tB = (.125 d1 + 8 d2) + m5
   const float ca1 = rh1 ? 0.25f : 1.f, ca2 = rh1 ? 4.f : 1.f, cb1 = rh1 ? 0.125f : 0.5f, cb2 = rh1 ? 8.f : 2.f;
+  double psum = 0.0, psq = 0.0;  // this wave's GroupNorm partial over both passes
 #pragma unroll
   for (int th = 0; th < 2; ++th) {  // (unrolled: `th` selects accumulator registers)
     unsigned e_zero = 0;
@@ -559,7 +560,6 @@ __global__ __launch_bounds__(F4_THREADS, 4) void wf43_kernel(const F4Args a) {
       for (int c = 0; c < 4; ++c) {
         r0[aa][c] = r1[aa][c] = f4_f32x2{0.f, 0.f};
         if (EPI == CF_EPI_RESIDUAL || EPI == CF_EPI_SFT) r0[aa][c] = f4_ld64(rs_res, voff0, soff0 + aa * e_rowc + c * e_px);
-        if (EPI == CF_EPI_SFT) r1[aa][c] = f4_ld64(rs_sft, voff0, soff0 + aa * e_rowc + c * e_px);
       }
     __builtin_amdgcn_sched_barrier(0);
     F4_T(5);
@@ -570,6 +570,12 @@ __global__ __launch_bounds__(F4_THREADS, 4) void wf43_kernel(const F4Args a) {
       float* mp = Mst + ((18 * m_g + i) * 8 + 2 * (lane >> 4)) * F4_BN + m_nb * 16 + (lane & 15);
       mp[0] = acc[i][2 * th];
       mp[F4_BN] = acc[i][2 * th + 1];
+    }
+    if (EPI == CF_EPI_SFT) {  // (requested here, where the staged accumulator registers are free)
+#pragma unroll
+      for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) r1[aa][c] = f4_ld64(rs_sft, voff0, soff0 + aa * e_rowc + c * e_px);
     }
     F4_T(5);
     __syncthreads();
@@ -630,8 +636,8 @@ __global__ __launch_bounds__(F4_THREADS, 4) void wf43_kernel(const F4Args a) {
       dsq1 += (double)rq[1];
     }
     if (a.stats_out) {
-      // GroupNorm statistics of the values this wave wrote in this pass (one tile x 64 channels): fp64 partials, fixed shuffle order;
-      // one partial per (image, group, patch, pass, wave): nparts = tiles_per_img * 16
+      // GroupNorm statistics of the values this wave wrote in this pass (one tile x 64 channels): fp64, fixed shuffle order; the two
+      // passes of a wave are joined in registers (psum / psq), the eight waves through LDS below: ONE partial per (image, group, patch)
       const int cpg = a.stats_cpg;
       dsum += dsum1;  // (the pair belongs to one group: cpg is even)
       dsq += dsq1;
@@ -641,15 +647,35 @@ __global__ __launch_bounds__(F4_THREADS, 4) void wf43_kernel(const F4Args a) {
         dsum += __shfl_xor(dsum, o2, 64);
         dsq += __shfl_xor(dsq, o2, 64);
       }
-      if (e_rh == 0 && (nn % cpg) == 0) {
-        const size_t pidx = ((size_t)rt * 2 + th) * 8 + wave;
-        const int ng = a.cout / cpg;
-        double* op = a.stats_out + (((size_t)b * ng + nn / cpg) * a.nparts + pidx) * 2;
-        op[0] = dsum;
-        op[1] = dsq;
-      }
+      psum = th == 0 ? dsum : psum + dsum;
+      psq = th == 0 ? dsq : psq + dsq;
     }
     F4_T(7);
+  }
+  if (a.stats_out) {
+    // the waves' partials -> LDS (over the staging area: every wave is past its reads behind this barrier), summed in wave order by
+    // the lanes of wave 0 that own a group: a 512x512 image then carries 1024 partials per group instead of 16384 (134 MB less to
+    // write and to read back per 64-channel layer at sixteen faces)
+    const int cpg = a.stats_cpg;
+    double* const sred = reinterpret_cast<double*>(smem);  // [8 waves][32 channel pairs][2]
+    __syncthreads();
+    if (e_rh == 0) {
+      sred[(wave * 32 + e_cp) * 2] = psum;
+      sred[(wave * 32 + e_cp) * 2 + 1] = psq;
+    }
+    __syncthreads();
+    if (wave == 0 && e_rh == 0 && (nn % cpg) == 0) {
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int wv = 0; wv < 8; ++wv) {
+        s0 += sred[(wv * 32 + e_cp) * 2];
+        s1 += sred[(wv * 32 + e_cp) * 2 + 1];
+      }
+      const int ng = a.cout / cpg;
+      double* op = a.stats_out + (((size_t)b * ng + nn / cpg) * a.nparts + rt) * 2;
+      op[0] = s0;
+      op[1] = s1;
+    }
   }
 #if F4_TIMING
   if (blockIdx.x == gridDim.x / 2 + 8 && lane == 0) {
@@ -766,7 +792,7 @@ int cf_wf43_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query) 
   a.stats_cpg = d->stats_cpg > 0 ? d->stats_cpg : 2;
   a.tiles_x = d->wout / F4_TW;
   a.tiles_per_img = a.tiles_x * (d->hout / F4_TH);
-  a.nparts = a.tiles_per_img * 16;
+  a.nparts = a.tiles_per_img;
   a.ntn = d->cout / F4_BN;
   if (parts_query) {
     *parts_query = a.nparts;

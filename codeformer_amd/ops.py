@@ -167,6 +167,11 @@ RANGE_SCALE = os.environ.get('CODEFORMER_HIP_RANGE_SCALE', '1') != '0'
 HALF_LIMIT = 65504.0 / 4.0    # largest |activation| a Winograd-domain IEEE-half operand can carry
 
 
+def switches():
+    """The module-level A/B switches a captured forward depends on (part of the graph-replay key of the arch modules)."""
+    return (SPLIT_WINOGRAD, F43_LAYERS, WINOGRAD_16BIT, RANGE_SCALE, ACT_FUSED, SPLITK_MAX)
+
+
 def needs_act_scale(pw):
     """True when `pw` runs on a kernel with 16-bit MFMA operands that applies cf_conv_desc.act_scale."""
     if pw.conv1:

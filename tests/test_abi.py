@@ -105,7 +105,7 @@ def test_argument_errors_are_reported_without_a_gpu(native):
     d.split_k, d.winograd = 0, 3
     assert native.cf_conv2d(ctypes.byref(d), None) == -1 and 'winograd must be' in lib.last_error()
     d.winograd, d.stats_cpg = 2, 2
-    assert native.cf_conv2d_stats_parts(ctypes.byref(d)) == 64       # sixteen partials per 16x16 patch, four patches per 32x32 image
+    assert native.cf_conv2d_stats_parts(ctypes.byref(d)) == 4        # one partial per 16x16 patch, four patches per 32x32 image
     assert native.cf_pack_conv_weight_winograd43_f16x2(1, 64, 64, 64, 64, 3.0, 1, None) == -1 and 'power of two' in lib.last_error()
     assert native.cf_pack_conv_weight_winograd43_f16x2(1, 64, 64, 96, 64, 2.0, 1, None) == -1 and 'padding' in lib.last_error()
 

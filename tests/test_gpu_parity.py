@@ -233,7 +233,15 @@ def test_hip_graph_replay_is_bitwise_eager(chk):
     from oracle.synth import seeded_input
     net = chk.build_net().cuda()
     x = seeded_input(2).cuda()
+    assert net.use_hip_graphs == 'auto' and net.graph_max_batch == 4     # the default: replay for batches of at most four faces
+    net.use_hip_graphs = False
     eager = [t.clone() for t in net(x, w=0.5, adain=True)]
+    assert not net._graphs
+    net.use_hip_graphs = 'auto'
+    auto = net(x, w=0.5, adain=True)
+    assert len(net._graphs) == 1 and all(torch.equal(a, b) for a, b in zip(auto, eager))
+    net(seeded_input(8).cuda(), w=0.5, adain=True)
+    assert len(net._graphs) == 1                                         # eight faces: eager
     net.use_hip_graphs = True
     for _ in range(2):                                   # first call captures, second replays
         got = net(x, w=0.5, adain=True)

@@ -32,13 +32,13 @@ def bench(x, n):
 
 for mode in modes:
     net.precision = mode
-    for graphs in (False, True):
+    for graphs in (False, True, 'auto'):
         net.use_hip_graphs = graphs
         row = []
         for B in (1, 2, 4, 8, 16, 32):
             dt = bench(xs[:B].contiguous(), 10 if B <= 4 else 5)
             row.append(f'B={B}: {dt * 1e3:6.2f} ms {B / dt:6.1f}/s')
-        print(f'{mode:6s} {"graph" if graphs else "eager"} | ' + ' | '.join(row), flush=True)
+        print(f'{mode:6s} {"auto " if graphs == "auto" else "graph" if graphs else "eager"} | ' + ' | '.join(row), flush=True)
 net.use_hip_graphs = False
 if len(sys.argv) > 2:      # per-launch timing of one B=1 forward: where the time goes
     net.precision = modes[0]

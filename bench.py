@@ -141,8 +141,8 @@ def roofline_leg(net, x, w):
         'conv3x3_wino_bf16_8w': ('wsplit_kernel<., BF16> (Winograd F(2x2,3x3), single bf16 operands, one MFMA per product)', 4.0 / 9.0, F16_MFMA_PEAK_TFLOPS, ('wsplit_kernel',)),
         'conv3x3_wino_f16x2': ('winograd_kernel<.,true> (the same on the four-wave 64-channel kernel: 64-channel layers and the 16x16 latents)',
                                3.0 * 4.0 / 9.0, F16_MFMA_PEAK_TFLOPS, ('winograd_kernel<false, true', 'winograd_kernel<true, true')),
-        'conv3x3_wino43_f16x2': ('wf43_kernel (3x3 s1 as Winograd F(4x4,3x3), 64 output channels per 8-wave workgroup, generator / fusion layers only; U and V as hi+lo '
-                                 'halves: 36 transform-domain products per 16 outputs x 3 f16 MFMAs)', 3.0 * 2.25 / 9.0, F16_MFMA_PEAK_TFLOPS, ('wf43_kernel',)),
+        'conv3x3_wino43_f16x2': ('wf43_kernel (3x3 s1 as Winograd F(4x4,3x3) on 16x16 patches, generator / fusion layers only: 64 output channels per 8-wave workgroup (two per CU) '
+                                 'or 128 per 16-wave workgroup; U and V as hi+lo halves: 36 transform-domain products per 16 outputs x 3 f16 MFMAs)', 3.0 * 2.25 / 9.0, F16_MFMA_PEAK_TFLOPS, ('wf43_kernel',)),
         'conv3x3': ('igemm_kernel<9,1,...> (direct 3x3 s1 implicit GEMM, fp32 MFMA)', 1.0, FP32_MFMA_PEAK_TFLOPS, ('igemm_kernel<9, 1',)),
         'conv3x3_io': ('conv3x3_few_cin / conv3x3_few_cout (3->64 and 64->3 at 512x512 on the vector ALU: write- / read-bound)', 0.0, HBM_PEAK_GBS, ('conv3x3_few_c',)),
         'conv_up2x': ('igemm_kernel<4,1,...> (folded nearest-x2 + 3x3, fp32 MFMA)', 1.0, FP32_MFMA_PEAK_TFLOPS, ('igemm_kernel<4, 1',)),

@@ -61,7 +61,7 @@
 #define F4_TIMING 0
 #endif
 #if F4_TIMING
-__device__ unsigned long long f4_timing_buf[8 * 16];
+__device__ unsigned long long f4_timing_buf[16 * 16];
 extern "C" int cf_debug_f4_timing(unsigned long long* host16x8) {
   return hipMemcpyFromSymbol(host16x8, HIP_SYMBOL(f4_timing_buf), sizeof(f4_timing_buf)) == hipSuccess ? 0 : -1;
 }
@@ -83,17 +83,18 @@ constexpr int F4_NPIX = (F4_TH + 2) * F4_PW;     // 324 pixels = 324 slots (rows
 constexpr int F4_SLOTS = F4_NPIX + 4;            // + one aligned group of four: the target of the padding items
 constexpr int F4_DUMMY = F4_NPIX;
 constexpr int F4_NT = 16;                        // tiles per patch (4 x 4) = one MFMA row tile
-constexpr int F4_THREADS = 512;
-constexpr int F4_BN = 64;                        // output channels per workgroup
-constexpr int F4_APT = 6;                        // float4 gather items per thread of waves 4..7: 384 pixel slots x 4 quads / 256 threads
+// NW = waves per workgroup: 8 -> 64 output channels, two workgroups per CU; 16 -> 128 output channels, one workgroup per CU (the gather,
+// prologue and transform of a patch then serve 128 channels).  Waves 0..3 transform, waves 4..NW-1 gather: 6 (NW 8) / 2 (NW 16) items each.
 constexpr int F4_PATCH_FLOATS = F4_SLOTS * CF_BK;   // 5248 floats = 20992 bytes per buffer
 constexpr int F4_PS = F4_NT * CF_BK;             // 256 floats between positions of V
 constexpr int F4_V_FLOATS = 36 * F4_PS;          // 9216
-constexpr int F4_M_FLOATS = 36 * 8 * F4_BN;      // 18432: one pass of the epilogue (36 positions x 8 tiles x 64 channels)
+constexpr int F4_M_FLOATS = 36 * 8 * 64;         // 18432: one pass of the epilogue of the 8-wave form (36 positions x 8 tiles x 64 channels)
 constexpr int F4_TAB = 256;                      // GroupNorm scale / shift rows of the image (cin <= 256)
 constexpr int F4_LDS_FLOATS = 2 * F4_PATCH_FLOATS + F4_V_FLOATS + 2 * F4_TAB;   // 80,896 bytes: two workgroups per CU
 static_assert(F4_M_FLOATS <= 2 * F4_PATCH_FLOATS + F4_V_FLOATS, "epilogue staging must fit the patch buffers + V");
 static_assert(F4_LDS_FLOATS * 4 <= 81920, "LDS budget of two workgroups per CU");
+constexpr int F4_LDS_FLOATS_16 = 2 * F4_M_FLOATS;   // 16-wave form: its epilogue pass stages 36 x 8 tiles x 128 channels = 147,456 bytes (the slab loop needs the 80,896 above)
+static_assert(F4_LDS_FLOATS_16 >= F4_LDS_FLOATS && F4_LDS_FLOATS_16 * 4 <= 163840, "LDS budget of the 16-wave form");
 
 typedef _Float16 f4_f16x4 __attribute__((ext_vector_type(4)));
 typedef float f4_f32x2 __attribute__((ext_vector_type(2)));
@@ -141,8 +142,13 @@ struct F4Args {
 // quad swizzle of V: tile row ty -> 0, 2, 3, 1
 __device__ __forceinline__ int f4_vs(int ty) { return (0x78 >> (2 * ty)) & 3; }
 
-template <int PRO, int EPI>
-__global__ __launch_bounds__(F4_THREADS, 4) void wf43_kernel(const F4Args a) {
+template <int PRO, int EPI, int NW>
+__global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
+  constexpr int F4_THREADS = NW * 64;
+  constexpr int F4_BN = NW * 8;                  // output channels per workgroup
+  constexpr int GT = F4_THREADS - 256;           // gather threads (waves 4..NW-1)
+  constexpr int F4_APT = NW == 8 ? 6 : 2;        // float4 gather items per gather thread: 384 pixel slots x 4 quads / GT
+  constexpr int PSTEP = GT / 4;                  // pixels between the items of a thread (64 / 192: multiples of 16, the swizzle period)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const V = smem + 2 * F4_PATCH_FLOATS;
   float* const tab = V + F4_V_FLOATS;  // [scale: F4_TAB][shift: F4_TAB]
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(F4_THREADS, 4) void wf43_kernel(const F4Args a) {
   const float act_s02 = 0.2f * act_s;  // LeakyReLU slope folded with the scale: fl(y * (0.2 s)) == fl(0.2 y) * s
 
   // ---- gather (waves 4..7; waves 0..3 spend the same interval on the input transform): item j of a thread is float4 #k4 of halo pixel
-  //      p = u + 64 j, u = (tid - 256) >> 2.  Everything per item -- the pixel's offset from the patch origin, whether it lies inside the
+  //      p = u + PSTEP j, u = (tid - 256) >> 2.  Everything per item -- the pixel's offset from the patch origin, whether it lies inside the
   //      image, its LDS slot -- is REBUILT per slab from the thread id (about ten integer instructions per item: these waves wait for
   //      the transform of waves 0..3 anyway) instead of being carried through the slab loop in registers. ----
   // p < 324: pixel (hy, hx) = (p / 18, p % 18); padding items (p >= 324, item 5 of most threads) and pixels outside the image are loaded
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(F4_THREADS, 4) void wf43_kernel(const F4Args a) {
   // (the swizzle repeats every 16 slots): one address + immediates.
   const int pix_origin = (y0 - 1) * a.w + (x0 - 1);  // (wave-uniform; negative on the top / left border: only invalid items would use it there)
   auto item = [&](unsigned u, int j, unsigned& rel, bool& valid) __attribute__((always_inline)) {
-    const unsigned p = u + 64u * (unsigned)j;
+    const unsigned p = u + (unsigned)(PSTEP * j);
     const unsigned hy = (p * 3641u) >> 16;  // p / 18 for p < 1024
     const unsigned hx = p - 18u * hy;
     const int iy = y0 - 1 + (int)hy, ix = x0 - 1 + (int)hx;
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(F4_THREADS, 4) void wf43_kernel(const F4Args a) {
     const bool first = c < a.c0;
     const unsigned cs = (unsigned)(first ? a.c0 : a.c1);
     const unsigned soff = (unsigned)(first ? c : c - a.c0) * 4u;
-    unsigned tl = (unsigned)tid & 255u;
+    unsigned tl = (unsigned)tid - 256u;
     asm volatile("" : "+v"(tl));  // opaque per slab (see above)
     const unsigned k4x = (tl & 3u) * 4u;
 #pragma unroll
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(F4_THREADS, 4) void wf43_kernel(const F4Args a) {
     }
   };
   auto store_patch = [&](int chunk) __attribute__((always_inline)) {
-    unsigned tl = (unsigned)tid & 255u;
+    unsigned tl = (unsigned)tid - 256u;
     asm volatile("" : "+v"(tl));
     const unsigned k4 = tl & 3u, slot = tl >> 2;
     char* const pb = reinterpret_cast<char*>(smem + (chunk & 1) * F4_PATCH_FLOATS) + (((slot & ~3u) | ((slot ^ (slot >> 2)) & 3u)) * 64u + k4 * 16u);
@@ -255,8 +261,8 @@ __global__ __launch_bounds__(F4_THREADS, 4) void wf43_kernel(const F4Args a) {
         if (PRO == CF_PRO_NONE) y = y * act_s;
         v[e] = valid ? y : 0.f;
       }
-      // item 5 covers pixels 320..383 of which 320..323 exist (lanes 0..15 of wave 4); the others would land past the buffer: skipped
-      if (j < 5 || tl < 16u) *reinterpret_cast<f32x4*>(pb + j * 4096) = v;
+      // the last item covers pixels up to 383 of which 0..323 exist (+ four spare slots); the others would land past the buffer: skipped
+      if (j < F4_APT - 1 || slot + (unsigned)(PSTEP * j) < (unsigned)F4_NPIX) *reinterpret_cast<f32x4*>(pb + j * (PSTEP * 64)) = v;
     }
   };
 
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(F4_THREADS, 4) void wf43_kernel(const F4Args a) {
   };
 
   // ---- MFMA interval: wave = (xi half m_g, 16-channel block m_nb) owns positions 18 m_g + i, i = 0..17 ----
-  const int m_g = wave >> 2, m_nb = wave & 3;
+  const int m_g = wave / (NW / 2), m_nb = wave % (NW / 2);
   f32x4 acc[18];
 #pragma unroll
   for (int i = 0; i < 18; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -439,7 +445,7 @@ __global__ __launch_bounds__(F4_THREADS, 4) void wf43_kernel(const F4Args a) {
     }
   };
   constexpr std::integral_constant<int, 4> na4{};
-  constexpr std::integral_constant<int, 2> na2{};
+  constexpr std::integral_constant<int, (NW == 8 ? 2 : 4)> na_gather{};   // (the 16-wave form carries 8 gather registers, not 24)
   auto feed = [&](int s) __attribute__((always_inline)) {  // waves 4..7: prologue + store of slab s (if any); its successor is requested inside the M interval
     if (s < n) {
 #if !(F4_ABLATE & 4)
@@ -498,7 +504,7 @@ __global__ __launch_bounds__(F4_THREADS, 4) void wf43_kernel(const F4Args a) {
       F4_T(1);
       __syncthreads();
       F4_T(2);
-      mma_stage(s, na2, [&]() __attribute__((always_inline)) { load_A(s + 2); });
+      mma_stage(s, na_gather, [&]() __attribute__((always_inline)) { load_A(s + 2); });
       __builtin_amdgcn_sched_barrier(0);
       F4_T(3);
       __syncthreads();
@@ -514,7 +520,7 @@ __global__ __launch_bounds__(F4_THREADS, 4) void wf43_kernel(const F4Args a) {
       F4_T(1);
       __syncthreads();
       F4_T(2);
-      mma_stage(s, na2, []() __attribute__((always_inline)) {});
+      mma_stage(s, na_gather, []() __attribute__((always_inline)) {});
       __builtin_amdgcn_sched_barrier(0);
       F4_T(3);
       __syncthreads();
@@ -529,7 +535,7 @@ __global__ __launch_bounds__(F4_THREADS, 4) void wf43_kernel(const F4Args a) {
   // staging: accumulator register r of position i is tile 4 lq + r (tile row lq = lane >> 4, tile column r), channel 16 m_nb + (lane & 15); pass th takes
   // r = 2 th, 2 th + 1 as staging tile tp = 2 lq + (r & 1).  item = (tp = wave, channel pair e_cp, output-row half e_rh).
   float* const Mst = smem;
-  const int e_cp = lane & 31, e_rh = lane >> 5;
+  const int e_cp = (lane & 31) + 32 * (wave >> 3), e_rh = lane >> 5, e_tp = wave & 7;   // (channel pair within the workgroup's F4_BN / 2)
   const float acc_s = a.acc_scale * act_is;                // (a product of powers of two: exact)
   const int nn = n0 + 2 * e_cp;
   f4_f32x2 bias2 = {0.f, 0.f};
@@ -551,7 +557,7 @@ __global__ __launch_bounds__(F4_THREADS, 4) void wf43_kernel(const F4Args a) {
     asm volatile("" : "+v"(e_zero));  // opaque 0 placed here: keeps hipcc from hoisting this pass's residual / SFT loads above the slab loop / the previous pass
     // lane part: the output-row half and the channel pair; scalar part: the tile of this wave and pass
     const unsigned voff0 = (unsigned)(2 * e_rh) * e_rowc + (unsigned)(2 * e_cp) * 4u + e_zero;
-    const unsigned soff0 = (unsigned)(y0 + 4 * (wave >> 1)) * e_rowc + (unsigned)(x0 + 4 * (2 * th + (wave & 1))) * e_px + (unsigned)n0 * 4u;
+    const unsigned soff0 = (unsigned)(y0 + 4 * (e_tp >> 1)) * e_rowc + (unsigned)(x0 + 4 * (2 * th + (e_tp & 1))) * e_px + (unsigned)n0 * 4u;
     // residual / SFT operands of this pass first: their latency overlaps the staging
     f4_f32x2 r0[2][4], r1[2][4];
 #pragma unroll
@@ -580,7 +586,7 @@ __global__ __launch_bounds__(F4_THREADS, 4) void wf43_kernel(const F4Args a) {
     F4_T(5);
     __syncthreads();
     F4_T(6);
-    const float* mq = Mst + wave * F4_BN + 2 * e_cp;
+    const float* mq = Mst + e_tp * F4_BN + 2 * e_cp;
     auto col = [&](int nu, f4_f32x2& tA, f4_f32x2& tB) __attribute__((always_inline)) {
       auto m = [&](int xi) __attribute__((always_inline)) { return *reinterpret_cast<const f4_f32x2*>(mq + ((xi * 6 + nu) * 8) * F4_BN); };
       const f4_f32x2 m1 = m(1), m2 = m(2), m3 = m(3), m4 = m(4);
@@ -657,19 +663,19 @@ __global__ __launch_bounds__(F4_THREADS, 4) void wf43_kernel(const F4Args a) {
     // the lanes of wave 0 that own a group: a 512x512 image then carries 1024 partials per group instead of 16384 (134 MB less to
     // write and to read back per 64-channel layer at sixteen faces)
     const int cpg = a.stats_cpg;
-    double* const sred = reinterpret_cast<double*>(smem);  // [8 waves][32 channel pairs][2]
+    double* const sred = reinterpret_cast<double*>(smem);  // [NW waves][32 channel pairs][2]
     __syncthreads();
     if (e_rh == 0) {
-      sred[(wave * 32 + e_cp) * 2] = psum;
-      sred[(wave * 32 + e_cp) * 2 + 1] = psq;
+      sred[(wave * 32 + (lane & 31)) * 2] = psum;
+      sred[(wave * 32 + (lane & 31)) * 2 + 1] = psq;
     }
     __syncthreads();
-    if (wave == 0 && e_rh == 0 && (nn % cpg) == 0) {
+    if (e_tp == 0 && e_rh == 0 && (nn % cpg) == 0) {  // (wave 0, and wave 8 for the second 64 channels of the 16-wave form)
       double s0 = 0.0, s1 = 0.0;
 #pragma unroll
       for (int wv = 0; wv < 8; ++wv) {
-        s0 += sred[(wv * 32 + e_cp) * 2];
-        s1 += sred[(wv * 32 + e_cp) * 2 + 1];
+        s0 += sred[((wave + wv) * 32 + (lane & 31)) * 2];
+        s1 += sred[((wave + wv) * 32 + (lane & 31)) * 2 + 1];
       }
       const int ng = a.cout / cpg;
       double* op = a.stats_out + (((size_t)b * ng + nn / cpg) * a.nparts + rt) * 2;
@@ -752,7 +758,7 @@ int cf_wf43_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query) 
   CF_REQUIRE(d->acc_scale > 0.f, "cf_conv2d(winograd 2): acc_scale must be the inverse of the pack-time weight scale (got %g)", (double)d->acc_scale);
   CF_REQUIRE(d->hout % F4_TH == 0 && d->wout % F4_TW == 0, "cf_conv2d(winograd 2): needs an output of %dx%d multiples (got %dx%d)", F4_TH,
              F4_TW, d->hout, d->wout);
-  CF_REQUIRE(d->cout % F4_BN == 0 && d->cout_pad == d->cout, "cf_conv2d(winograd 2): needs cout == cout_pad, a multiple of 64 (got %d / %d)",
+  CF_REQUIRE(d->cout % 64 == 0 && d->cout_pad == d->cout, "cf_conv2d(winograd 2): needs cout == cout_pad, a multiple of 64 (got %d / %d)",
              d->cout, d->cout_pad);
   CF_REQUIRE((long)d->hout * d->wout <= (1L << 21), "cf_conv2d(winograd 2): at most 2^21 pixels per image (got %dx%d)", d->hout, d->wout);
   CF_REQUIRE((long)d->hout * d->wout * (d->c0 > d->cout ? d->c0 : d->cout) * 4 < (1L << 31) && (long)d->hout * d->wout * d->c1 * 4 < (1L << 31),
@@ -793,22 +799,21 @@ int cf_wf43_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query) 
   a.tiles_x = d->wout / F4_TW;
   a.tiles_per_img = a.tiles_x * (d->hout / F4_TH);
   a.nparts = a.tiles_per_img;
-  a.ntn = d->cout / F4_BN;
+  const bool wide = d->cout % 128 == 0 && !getenv("CF_F43_NARROW");   // 16 waves x 128 channels where the layer has them (the variable: A/B only)
+  a.ntn = d->cout / (wide ? 128 : 64);
   if (parts_query) {
     *parts_query = a.nparts;
     return CF_OK;
   }
-#if F4_TIMING
-  const size_t lds = F4_LDS_FLOATS * sizeof(float) + (getenv("CF_F43_ONE_WG") ? 32768 : 0);   // experiment: one workgroup per CU
-#else
-  constexpr size_t lds = F4_LDS_FLOATS * sizeof(float);
-#endif
-  const dim3 grid(a.tiles_per_img * d->batch * a.ntn), block(F4_THREADS);
+  const size_t lds = (wide ? F4_LDS_FLOATS_16 : F4_LDS_FLOATS) * sizeof(float) + (F4_TIMING && !wide && getenv("CF_F43_ONE_WG") ? 32768 : 0);   // (timing builds: one workgroup per CU)
+  const dim3 grid(a.tiles_per_img * d->batch * a.ntn), block(wide ? 1024 : 512);
   // (cf_device_init sets the dynamic-LDS attribute of every instantiation on each device)
-#define F4_LAUNCH(P, E)                                                            \
-  do {                                                                             \
-    CF_LDS_ATTR((wf43_kernel<P, E>), F4_LDS_FLOATS * sizeof(float) + (F4_TIMING ? 32768 : 0));   \
-    hipLaunchKernelGGL((wf43_kernel<P, E>), grid, block, lds, stream, a);          \
+#define F4_LAUNCH(P, E)                                                                                                       \
+  do {                                                                                                                        \
+    CF_LDS_ATTR((wf43_kernel<P, E, 8>), F4_LDS_FLOATS * sizeof(float) + (F4_TIMING ? 32768 : 0));                             \
+    CF_LDS_ATTR((wf43_kernel<P, E, 16>), F4_LDS_FLOATS_16 * sizeof(float));                                                   \
+    if (wide) hipLaunchKernelGGL((wf43_kernel<P, E, 16>), grid, block, lds, stream, a);                                       \
+    else hipLaunchKernelGGL((wf43_kernel<P, E, 8>), grid, block, lds, stream, a);                                             \
   } while (0)
 #define F4_LAUNCH_EPI(P)                                                           \
   do {                                                                             \

@@ -21,12 +21,12 @@ e1.record()
 torch.cuda.synchronize()
 print(f'launch (instrumented build): {e0.elapsed_time(e1) / 10:.3f} ms' + ('  [one workgroup per CU]' if os.environ.get('CF_F43_ONE_WG') else ''))
 raw = ctypes.CDLL(L.LIB_PATH)
-buf = (ctypes.c_ulonglong * 128)()
+buf = (ctypes.c_ulonglong * 256)()
 assert raw.cf_debug_f4_timing(buf) == 0
 names = ['fill', 'T work', 'T barrier', 'M work', 'M barrier', 'epi load+stage', 'epi barriers', 'epi compute+store']
 n = int(buf[9])
 print(f'{cin}->{cout} @ {H}x{H} x {B}: {n} slabs; shader cycles summed over the patch (per slab in brackets for the slab stages)')
 print('wave  ' + '  '.join(f'{s:>17s}' for s in names) + '   total')
-for w in range(8):
+for w in range(16 if cout % 128 == 0 and not os.environ.get("CF_F43_NARROW") else 8):
     v = [int(buf[w * 16 + k]) for k in range(8)]
     print(f'  {w}:  ' + '  '.join((f'{t:9d} [{t // n:5d}]' if 1 <= k <= 4 else f'{t:17d}') for k, t in enumerate(v)) + f'   {int(buf[w * 16 + 8])}')

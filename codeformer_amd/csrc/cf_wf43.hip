@@ -95,6 +95,8 @@ static_assert(F4_M_FLOATS <= 2 * F4_PATCH_FLOATS + F4_V_FLOATS, "epilogue stagin
 static_assert(F4_LDS_FLOATS * 4 <= 81920, "LDS budget of two workgroups per CU");
 constexpr int F4_LDS_FLOATS_16 = 2 * F4_M_FLOATS;   // 16-wave form: its epilogue pass stages 36 x 8 tiles x 128 channels = 147,456 bytes (the slab loop needs the 80,896 above)
 static_assert(F4_LDS_FLOATS_16 >= F4_LDS_FLOATS && F4_LDS_FLOATS_16 * 4 <= 163840, "LDS budget of the 16-wave form");
+constexpr int F4_LDS_FLOATS_32 = 2 * F4_SLOTS * 32 + 36 * F4_NT * 32 + 2 * F4_TAB;   // 16 waves, 32-channel slabs: 159,744 bytes
+static_assert(F4_LDS_FLOATS_32 >= F4_LDS_FLOATS_16 && F4_LDS_FLOATS_32 * 4 <= 163840, "LDS budget of the 32-channel-slab form");
 
 typedef _Float16 f4_f16x4 __attribute__((ext_vector_type(4)));
 typedef float f4_f32x2 __attribute__((ext_vector_type(2)));
@@ -142,16 +144,28 @@ struct F4Args {
 // quad swizzle of V: tile row ty -> 0, 2, 3, 1
 __device__ __forceinline__ int f4_vs(int ty) { return (0x78 >> (2 * ty)) & 3; }
 
-template <int PRO, int EPI, int NW>
+// unit (8 bytes) of a 128-byte V row of the 32-channel-slab form that holds part p (0, 1: hi halves 0..3 / 4..7; 2, 3: lo) of octet lq of
+// tile t: a bijection (lq, p) -> 0..15 per tile, and for one p the 16 tiles x 2 octets a half-wave reads with ds_read_b64 cover all banks
+__device__ __forceinline__ unsigned f4_vu(unsigned lq, unsigned p, unsigned t) { return (lq & 1u) + 2u * (((t >> 1) + 4u * (lq >> 1) + p) & 7u); }
+
+// KS = channels per slab: 16 (v_mfma_f32_16x16x16_f16; both forms) or 32 (v_mfma_f32_16x16x32_f16 at twice the rate and half the barrier
+// intervals per input channel: the 16-wave form only -- its 157 KB of LDS hold two 41 KB patch buffers and a 72 KB V)
+template <int PRO, int EPI, int NW, int KS>
 __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
+  static_assert(KS == 16 || (KS == 32 && NW == 16), "32-channel slabs need the LDS of the 16-wave form");
   constexpr int F4_THREADS = NW * 64;
   constexpr int F4_BN = NW * 8;                  // output channels per workgroup
-  constexpr int GT = F4_THREADS - 256;           // gather threads (waves 4..NW-1)
-  constexpr int F4_APT = NW == 8 ? 6 : 2;        // float4 gather items per gather thread: 384 pixel slots x 4 quads / GT
-  constexpr int PSTEP = GT / 4;                  // pixels between the items of a thread (64 / 192: multiples of 16, the swizzle period)
+  constexpr int TWV = KS / 4;                    // transform waves: 256 (tile, channel pair, xi half) items per 16 channels
+  constexpr int QPP = KS / 4;                    // float4 items per halo pixel
+  constexpr int GT = F4_THREADS - TWV * 64;      // gather threads (waves TWV..NW-1)
+  constexpr int F4_APT = 384 * QPP / GT;         // float4 gather items per gather thread: 6 (8 waves) / 2 (16 waves) / 6 (16 waves, 32-channel slabs)
+  constexpr int PSTEP = GT / QPP;                // pixels between the items of a thread (64 / 192 / 64: multiples of 16, the swizzle period)
+  constexpr int SLOTB = KS * 4;                  // bytes per pixel slot of a patch buffer
+  constexpr int PATCHF = F4_SLOTS * KS;          // floats per patch buffer
+  constexpr int PSK = F4_NT * KS;                // floats between positions of V
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* const V = smem + 2 * F4_PATCH_FLOATS;
-  float* const tab = V + F4_V_FLOATS;  // [scale: F4_TAB][shift: F4_TAB]
+  float* const V = smem + 2 * PATCHF;
+  float* const tab = V + 36 * PSK;  // [scale: F4_TAB][shift: F4_TAB]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -170,7 +184,7 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
   const int tyw = rt / a.tiles_x;
   const int y0 = tyw * F4_TH;
   const int x0 = (rt - tyw * a.tiles_x) * F4_TW;
-  const int n = a.nchunks;
+  const int n = a.cin / KS;   // slabs
 #if F4_TIMING
   // slots: 0 fill, 1 T work, 2 T barrier, 3 M work, 4 M barrier, 5 epilogue load + stage, 6 epilogue barriers, 7 epilogue compute + store
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -213,42 +227,46 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
   // one descriptor per concatenated input, based at this image (the launch checks that an image stays below 2^31 bytes)
   const __amdgpu_buffer_rsrc_t rs_in0 = f4_rsrc(a.in0 + img0 * a.c0, img_px * (unsigned)a.c0 * 4u);
   const __amdgpu_buffer_rsrc_t rs_in1 = f4_rsrc(a.c1 ? a.in1 + img0 * a.c1 : a.in0, img_px * (unsigned)a.c1 * 4u);
-  f32x4 ra[F4_APT];
+  constexpr int RAN = KS == 32 ? F4_APT / 2 : F4_APT;   // gather registers: 32-channel slabs load and store a slab's items in two halves
+  f32x4 ra[RAN];
   // unconditional loads from clamped addresses; out-of-image items are zeroed at the store (see cf_winograd.hip)
-  auto load_A = [&](int chunk) __attribute__((always_inline)) {
+  auto load_A_range = [&](int chunk, auto j0c, auto j1c) __attribute__((always_inline)) {
+    constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value;
     // a slab lies in ONE of the concatenated inputs (c0 % 16 == 0): descriptor, channel stride and channel offset are wave-uniform
-    const int c = chunk * CF_BK;
+    const int c = chunk * KS;
     const bool first = c < a.c0;
     const unsigned cs = (unsigned)(first ? a.c0 : a.c1);
     const unsigned soff = (unsigned)(first ? c : c - a.c0) * 4u;
-    unsigned tl = (unsigned)tid - 256u;
+    unsigned tl = (unsigned)tid - (unsigned)(TWV * 64);
     asm volatile("" : "+v"(tl));  // opaque per slab (see above)
-    const unsigned k4x = (tl & 3u) * 4u;
+    const unsigned k4x = (tl % (unsigned)QPP) * 4u;
 #pragma unroll
-    for (int j = 0; j < F4_APT; ++j) {
+    for (int j = J0; j < J1; ++j) {
       unsigned rel;
       bool valid;
-      item(tl >> 2, j, rel, valid);
+      item(tl / (unsigned)QPP, j, rel, valid);
       const unsigned voff = (__umul24((unsigned)(pix_origin + (int)rel), cs) + k4x) * 4u;
-      ra[j] = first ? f4_ld128(rs_in0, voff, soff) : f4_ld128(rs_in1, voff, soff);
+      ra[j % RAN] = first ? f4_ld128(rs_in0, voff, soff) : f4_ld128(rs_in1, voff, soff);
     }
   };
-  auto store_patch = [&](int chunk) __attribute__((always_inline)) {
-    unsigned tl = (unsigned)tid - 256u;
+  auto load_A = [&](int chunk) __attribute__((always_inline)) { load_A_range(chunk, std::integral_constant<int, 0>{}, std::integral_constant<int, F4_APT>{}); };
+  auto store_patch_range = [&](int chunk, auto j0c, auto j1c) __attribute__((always_inline)) {
+    constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value;
+    unsigned tl = (unsigned)tid - (unsigned)(TWV * 64);
     asm volatile("" : "+v"(tl));
-    const unsigned k4 = tl & 3u, slot = tl >> 2;
-    char* const pb = reinterpret_cast<char*>(smem + (chunk & 1) * F4_PATCH_FLOATS) + (((slot & ~3u) | ((slot ^ (slot >> 2)) & 3u)) * 64u + k4 * 16u);
+    const unsigned k4 = tl % (unsigned)QPP, slot = tl / (unsigned)QPP;
+    char* const pb = reinterpret_cast<char*>(smem + (chunk & 1) * PATCHF) + (((slot & ~3u) | ((slot ^ (slot >> 2)) & 3u)) * (unsigned)SLOTB + k4 * 16u);
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (affine) {
-      sc = *reinterpret_cast<const f32x4*>(tab + chunk * CF_BK + k4 * 4);
-      sh = *reinterpret_cast<const f32x4*>(tab + F4_TAB + chunk * CF_BK + k4 * 4);
+      sc = *reinterpret_cast<const f32x4*>(tab + chunk * KS + k4 * 4);
+      sh = *reinterpret_cast<const f32x4*>(tab + F4_TAB + chunk * KS + k4 * 4);
     }
 #pragma unroll
-    for (int j = 0; j < F4_APT; ++j) {
+    for (int j = J0; j < J1; ++j) {
       unsigned rel;
       bool valid;
       item(slot, j, rel, valid);
-      f32x4 v = ra[j];
+      f32x4 v = ra[j % RAN];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float y = v[e];
@@ -262,19 +280,22 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
         v[e] = valid ? y : 0.f;
       }
       // the last item covers pixels up to 383 of which 0..323 exist (+ four spare slots); the others would land past the buffer: skipped
-      if (j < F4_APT - 1 || slot + (unsigned)(PSTEP * j) < (unsigned)F4_NPIX) *reinterpret_cast<f32x4*>(pb + j * (PSTEP * 64)) = v;
+      if (j < F4_APT - 1 || slot + (unsigned)(PSTEP * j) < (unsigned)F4_NPIX) *reinterpret_cast<f32x4*>(pb + j * (PSTEP * SLOTB)) = v;
     }
   };
+
+  auto store_patch = [&](int chunk) __attribute__((always_inline)) { store_patch_range(chunk, std::integral_constant<int, 0>{}, std::integral_constant<int, F4_APT>{}); };
 
   // ---- input transform (waves 0..3): item = (xi half tg, tile (ty, tx), channel pair cp): V[18 tg + aa * 6 + nu], aa = 0..2, nu = 0..5 ----
   // Thread constants of the transform are REBUILT per slab from the lane id (a handful of integer instructions) instead of living
   // in registers across the slab loop: at 128 registers hipcc spills such values and every reload is a wait on vmcnt(0).
-  const int tg = (wave >> 1) & 1;
+  const int tg = (wave >> (KS == 32 ? 2 : 1)) & 1;
   // pixel (tile row r, tile column j) is slot 18 (4 ty + r) + 4 tx + j = 4 G + (q & 3) with q = 2 r + j and G = 18 ty + tx + 4 r + (q >> 2);
   // it is stored at low bits (q & 3) ^ (G & 3), G & 3 = (2 ty + tx + (q >> 2)) & 3: byte offset from the buffer =
   //   256 (18 ty + tx) + cp * 8  [t_base]  +  256 (4 r + (q >> 2))  [immediate]  +  (((q & 3) << 6) ^ sw[q >> 2]),  sw[k] = ((2 ty + tx + k) & 3) << 6
   // (t_base has bits 6, 7 clear, so the swizzle of window k folds into it: tk[k] = t_base | sw[k], and a read costs one xor with 64 (q & 3))
-  float* t_hi;  // hi word of channel pair cp: quad cp >> 1 (swizzled by the tile row), word cp & 1; lo word two words further
+  float* t_hi;  // hi word of channel pair cp: quad cp >> 1 (swizzled by the tile row), word cp & 1; lo word two words further (32-channel slabs: f4_vu)
+  float* t_lo;
   auto row_pass = [&](const f4_f32x2 (&zz)[6], int pos) __attribute__((always_inline)) {
     f4_f32x2 v[6];
     v[0] = (zz[0] + zz[4]) * 0.25f - zz[2] * 1.0625f;
@@ -291,28 +312,38 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
     for (int nu = 0; nu < 6; ++nu) {  // operand split, store: per (position, tile) four quads of [4 hi halves | 4 lo halves]
       float hi, lo;
       cf_split_pair(v[nu][0], v[nu][1], hi, lo);
-      t_hi[(pos + nu) * F4_PS] = hi;
-      t_hi[(pos + nu) * F4_PS + 2] = lo;
+      t_hi[(pos + nu) * PSK] = hi;
+      t_lo[(pos + nu) * PSK] = lo;
     }
   };
   // Two parts keep the live set small: first the single row of the half (xi 0 from tile rows 0, 2, 4 / xi 5 from rows 1, 3, 5), then
   // the even / odd pair (xi 1, 2 or 3, 4: tile rows 1..4).  `mid` runs between the two row passes of the second part (the slab's first
   // weight fragments are requested there: the first pass's column sums are dead, the live set is at its smallest).
   auto transform = [&](int chunk, auto mid) __attribute__((always_inline)) {
-    const char* const pb = reinterpret_cast<const char*>(smem + (chunk & 1) * F4_PATCH_FLOATS);
+    const char* const pb = reinterpret_cast<const char*>(smem + (chunk & 1) * PATCHF);
     unsigned ln = (unsigned)lane;
     asm volatile("" : "+v"(ln));  // opaque per slab (see above)
-    const unsigned t_tile = 8u * (unsigned)(wave & 1) + (ln >> 3), t_cp = ln & 7u;
+    // 16-channel slabs: wave = (xi half, tile half), lane = (tile, 8 channel pairs); 32-channel slabs: wave = (xi half, tile row), lane = (tile column, 16 pairs)
+    const unsigned t_tile = KS == 32 ? 4u * (unsigned)(wave & 3) + (ln >> 4) : 8u * (unsigned)(wave & 1) + (ln >> 3);
+    const unsigned t_cp = KS == 32 ? ln & 15u : ln & 7u;
     const unsigned t_ty = t_tile >> 2, t_tx = t_tile & 3u;
-    const unsigned t_base = 256u * (18u * t_ty + t_tx) + t_cp * 8u;
+    constexpr unsigned SH = KS == 32 ? 7 : 6;   // log2 of the slot size
+    const unsigned t_base = (4u << SH) * (18u * t_ty + t_tx) + t_cp * 8u;
     const unsigned tb0 = 2u * t_ty + t_tx;
     unsigned tk[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) tk[k] = t_base | (((tb0 + k) & 3u) << 6);
-    t_hi = V + (tg * 18) * F4_PS + t_tile * CF_BK + (((t_cp >> 1) ^ (unsigned)f4_vs((int)t_ty)) << 2) + (t_cp & 1u);
+    for (int k = 0; k < 4; ++k) tk[k] = t_base | (((tb0 + k) & 3u) << SH);
+    if (KS == 32) {
+      const unsigned lq = t_cp >> 2, e = t_cp & 3u;
+      t_hi = V + (tg * 18) * PSK + t_tile * 32 + f4_vu(lq, e >> 1, t_tile) * 2u + (e & 1u);
+      t_lo = V + (tg * 18) * PSK + t_tile * 32 + f4_vu(lq, 2u + (e >> 1), t_tile) * 2u + (e & 1u);
+    } else {
+      t_hi = V + (tg * 18) * PSK + t_tile * CF_BK + (((t_cp >> 1) ^ (unsigned)f4_vs((int)t_ty)) << 2) + (t_cp & 1u);
+      t_lo = t_hi + 2;
+    }
     auto px = [&](int r, int j) __attribute__((always_inline)) {  // (r, j compile-time after unrolling)
       const int q = 2 * r + j;
-      return *reinterpret_cast<const f4_f32x2*>(pb + 256 * (4 * r + (q >> 2)) + (tk[q >> 2] ^ (((unsigned)q & 3u) << 6)));
+      return *reinterpret_cast<const f4_f32x2*>(pb + (4 << SH) * (4 * r + (q >> 2)) + (tk[q >> 2] ^ (((unsigned)q & 3u) << SH)));
     };
     if (tg == 0) {
       {  // xi = 0: .25 (d0 + d4) - 1.0625 d2
@@ -376,14 +407,15 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
   for (int i = 0; i < 18; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   // weight fragments: descriptor over the packed tensor, lane offset 16 lane bytes, everything else in the scalar offset
   const __amdgpu_buffer_rsrc_t rs_w = f4_rsrc(a.weight, 36u * (unsigned)a.cin * (unsigned)a.cout * 4u);
-  const unsigned w_pos = (unsigned)(a.nchunks * a.cout * CF_BK) * 4u;                                 // bytes between positions
-  const unsigned w_s0 = (unsigned)(18 * m_g) * w_pos + (unsigned)(n0 / 16 + m_nb) * 1024u;          // (wave-uniform)
+  const unsigned w_pos = (unsigned)a.cin * (unsigned)a.cout * 4u;                                        // bytes between positions
+  const unsigned w_chunk = (unsigned)(a.cout * KS) * 4u;                                                 // ... between slabs
+  const unsigned w_s0 = (unsigned)(18 * m_g) * w_pos + (unsigned)(n0 / 16 + m_nb) * (unsigned)(64 * KS); // (wave-uniform; a fragment: 64 lanes x KS bytes)
   constexpr std::integral_constant<int, 4> nb4{};
   unsigned lane16;   // (rebuilt per slab, as a_base: see the transform)
   f32x4 bq[4];  // ring of weight fragments: hi | lo
   auto load_B = [&](int chunk, int i, auto nb) __attribute__((always_inline)) {
 #if !(F4_ABLATE & 16)
-    bq[i % decltype(nb)::value] = f4_ld128(rs_w, lane16, w_s0 + (unsigned)i * w_pos + (unsigned)chunk * (unsigned)(a.cout * CF_BK * 4));
+    bq[i % decltype(nb)::value] = f4_ld128(rs_w, lane16, w_s0 + (unsigned)i * w_pos + (unsigned)chunk * w_chunk);
 #endif
   };
   auto set_lane16 = [&]() __attribute__((always_inline)) {
@@ -410,10 +442,10 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
       unsigned ln = (unsigned)lane;
       asm volatile("" : "+v"(ln));
       const unsigned t15 = ln & 15u;
-      a_base = V + (18 * m_g) * F4_PS + t15 * CF_BK + (((ln >> 4) ^ (unsigned)f4_vs((int)(t15 >> 2))) << 2);
+      a_base = V + (18 * m_g) * PSK + t15 * CF_BK + (((ln >> 4) ^ (unsigned)f4_vs((int)(t15 >> 2))) << 2);
       lane16 = ln * 16u;
     }
-    auto read_A = [&](int i) __attribute__((always_inline)) { va[i % NA] = *reinterpret_cast<const f32x4*>(a_base + i * F4_PS); };
+    auto read_A = [&](int i) __attribute__((always_inline)) { va[i % NA] = *reinterpret_cast<const f32x4*>(a_base + i * PSK); };
     read_A(0);
     read_A(1);
 #pragma unroll
@@ -444,6 +476,58 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+  // 32-channel slabs: one position at a time (an A fragment is four ds_read_b64 = 8 hi + 8 lo halves, a B fragment two 16-byte loads);
+  // one A register set, B ring of three positions (what 128 registers hold beside 72 accumulators), positions 0..2 requested in the T interval
+  typedef _Float16 f4_f16x8 __attribute__((ext_vector_type(8)));
+  f32x4 xb[3][2], xa[1][2];
+  auto load_B32 = [&](int chunk, int i) __attribute__((always_inline)) {
+#if !(F4_ABLATE & 16)
+    const unsigned so = w_s0 + (unsigned)i * w_pos + (unsigned)chunk * w_chunk;
+    xb[i % 3][0] = f4_ld128(rs_w, lane16, so);
+    xb[i % 3][1] = f4_ld128(rs_w, lane16 + 16u, so);
+#endif
+  };
+  auto mma_stage32 = [&](int chunk) __attribute__((always_inline)) {
+    unsigned ao[4];
+    {
+      unsigned ln = (unsigned)lane;
+      asm volatile("" : "+v"(ln));
+      const unsigned t15 = ln & 15u, lq = ln >> 4;
+#pragma unroll
+      for (unsigned pp = 0; pp < 4; ++pp) ao[pp] = ((unsigned)(18 * m_g) * (unsigned)PSK + t15 * 32u + f4_vu(lq, pp, t15) * 2u) * 4u;   // bytes from V
+      lane16 = ln * 32u;
+    }
+    const char* const vb = reinterpret_cast<const char*>(V);
+    auto read_A = [&](int i) __attribute__((always_inline)) {
+      const f4_f32x2 p0 = *reinterpret_cast<const f4_f32x2*>(vb + ao[0] + i * (PSK * 4)), p1 = *reinterpret_cast<const f4_f32x2*>(vb + ao[1] + i * (PSK * 4));
+      const f4_f32x2 p2 = *reinterpret_cast<const f4_f32x2*>(vb + ao[2] + i * (PSK * 4)), p3 = *reinterpret_cast<const f4_f32x2*>(vb + ao[3] + i * (PSK * 4));
+      xa[0][0] = f32x4{p0[0], p0[1], p1[0], p1[1]};
+      xa[0][1] = f32x4{p2[0], p2[1], p3[0], p3[1]};
+    };
+    auto mf = [&](f32x4 av, f32x4 bv, f32x4& c) __attribute__((always_inline)) {
+#if F4_ABLATE & 1
+      c[0] += av[0] + bv[1];
+#else
+      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f4_f16x8, av), __builtin_bit_cast(f4_f16x8, bv), c, 0, 0, 0);
+#endif
+    };
+    read_A(0);
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+      __builtin_amdgcn_sched_barrier(0);
+      mf(xa[0][1], xb[i % 3][0], acc[i]);
+      mf(xa[0][0], xb[i % 3][1], acc[i]);
+      mf(xa[0][0], xb[i % 3][0], acc[i]);
+      if (i + 1 < 18) read_A(i + 1);   // (one register set: the next fragment is read once this position's MFMAs are issued -- 128 registers)
+      if (i + 3 < 18) load_B32(chunk, i + 3);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto set_lane32 = [&]() __attribute__((always_inline)) {
+    unsigned ln = (unsigned)lane;
+    asm volatile("" : "+v"(ln));
+    lane16 = ln * 32u;
+  };
   constexpr std::integral_constant<int, 4> na4{};
   constexpr std::integral_constant<int, (NW == 8 ? 2 : 4)> na_gather{};   // (the 16-wave form carries 8 gather registers, not 24)
   auto feed = [&](int s) __attribute__((always_inline)) {  // waves 4..7: prologue + store of slab s (if any); its successor is requested inside the M interval
@@ -456,7 +540,81 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
 
   // ---- slab loop: two barrier intervals per slab; one loop per wave role (a common loop would keep the gather registers of waves 4..7
   //      alive through the transform of waves 0..3: the allocator is per kernel, not per wave) ----
-  if (wave < 4) {
+  if constexpr (KS == 32) {
+    // 32-channel slabs: waves 0..7 transform, waves 8..15 gather; the gather request of slab s + 2 follows the M interval of slab s
+    // (its registers would not fit beside the fragment rings) and has the transform interval of the other waves to land
+    if (wave < TWV) {
+      __syncthreads();
+      __syncthreads();  // patch(0) visible
+      F4_T(0);
+      for (int s = 0; s < n; ++s) {
+#if !(F4_ABLATE & 2)
+        transform(s, [&]() __attribute__((always_inline)) {
+          set_lane32();
+          load_B32(s, 0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        load_B32(s, 1);
+        load_B32(s, 2);
+#else
+        set_lane32();
+        for (int i = 0; i < 3; ++i) load_B32(s, i);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        F4_T(1);
+        __syncthreads();  // V(s) and patch(s + 1) visible
+        F4_T(2);
+        mma_stage32(s);
+        __builtin_amdgcn_sched_barrier(0);
+        F4_T(3);
+        __syncthreads();  // V and patch(s) are free
+        F4_T(4);
+      }
+    } else {
+      // the gather of a slab in two halves of three items (12 registers): half 0 is requested behind the M interval and stored at the top of
+      // the next T interval, half 1 requested there and stored at its end -- these waves wait for the transform of the others anyway
+      constexpr std::integral_constant<int, 0> h0{};
+      constexpr std::integral_constant<int, F4_APT / 2> h1{};
+      constexpr std::integral_constant<int, F4_APT> h2{};
+      auto feed2 = [&](int s) __attribute__((always_inline)) {  // patch(s): half 0 is in flight
+        if (s < n) {
+#if !(F4_ABLATE & 4)
+          store_patch_range(s, h0, h1);
+#endif
+          __builtin_amdgcn_sched_barrier(0);
+          load_A_range(s, h1, h2);
+          __builtin_amdgcn_sched_barrier(0);
+#if !(F4_ABLATE & 4)
+          store_patch_range(s, h1, h2);
+#endif
+        }
+      };
+      load_A_range(0, h0, h1);
+      __syncthreads();  // (the GroupNorm rows are in LDS)
+      feed2(0);
+      if (n > 1) load_A_range(1, h0, h1);
+      __syncthreads();
+      F4_T(0);
+      for (int s = 0; s < n; ++s) {
+        feed2(s + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        set_lane32();
+#pragma unroll
+        for (int i = 0; i < 3; ++i) load_B32(s, i);
+        __builtin_amdgcn_sched_barrier(0);
+        F4_T(1);
+        __syncthreads();
+        F4_T(2);
+        mma_stage32(s);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < n) load_A_range(s + 2, h0, h1);
+        __builtin_amdgcn_sched_barrier(0);
+        F4_T(3);
+        __syncthreads();
+        F4_T(4);
+      }
+    }
+  } else if (wave < 4) {
     __syncthreads();
     __syncthreads();  // patch(0) visible
     F4_T(0);
@@ -697,11 +855,13 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
 // [pos = xi*6 + nu][cin_pad/16][cout_pad/16][lane 64][4 words: hi, hi, lo, lo]; a lane's 16 bytes are the hi and the lo halves of
 // U'[n = block*16 + (lane&15)][c = chunk*16 + (lane>>4)*4 + 0..3]  (v_mfma_f32_16x16x16_f16 B operand, hi | lo in one dwordx4).
 __global__ void pack_weight_wf43_kernel(const float* __restrict__ w, int cout, int cin, int cout_pad, int nchunks, float scale,
-                                        unsigned* __restrict__ packed, long total) {
+                                        unsigned* __restrict__ packed, long total, int k32) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one 32-bit word = two halves
   if (i >= total) return;
-  const int e = (int)(i & 1), part = (int)((i >> 1) & 1), ln = (int)((i >> 2) & 63);
-  long r = i >> 8;
+  // 16-channel slabs: a lane's 16 bytes = [hi k0..3 | lo k0..3]; 32-channel slabs (k32): a lane's 32 bytes = [hi k0..7 | lo k0..7]
+  const int e = k32 ? (int)(i & 3) : (int)(i & 1), part = k32 ? (int)((i >> 2) & 1) : (int)((i >> 1) & 1);
+  const int ln = k32 ? (int)((i >> 3) & 63) : (int)((i >> 2) & 63);
+  long r = k32 ? i >> 9 : i >> 8;
   const int ntiles = cout_pad / 16;
   const int nn = (int)(r % ntiles) * 16 + (ln & 15);
   r /= ntiles;
@@ -714,7 +874,7 @@ __global__ void pack_weight_wf43_kernel(const float* __restrict__ w, int cout, i
   unsigned out = 0;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    const int c = chunk * CF_BK + (ln >> 4) * 4 + e * 2 + h;
+    const int c = k32 ? chunk * 32 + (ln >> 4) * 8 + e * 2 + h : chunk * CF_BK + (ln >> 4) * 4 + e * 2 + h;
     float val = 0.f;
     if (nn < cout && c < cin) {
       const float* g = w + ((long)nn * cin + c) * 9;
@@ -745,8 +905,10 @@ extern "C" int cf_pack_conv_weight_winograd43_f16x2(const float* w, int cout, in
   int ex = 0;
   CF_REQUIRE(scale > 0.f && frexpf(scale, &ex) == 0.5f, "cf_pack_conv_weight_winograd43_f16x2: scale %g is not a power of two", (double)scale);
   const long total = 36L * cin_pad * cout_pad;  // 32-bit words: hi + lo half per weight
+  // the layout follows the form cf_conv2d will run (cf_wf43_form below): 32-channel slabs for the 16-wave form where cin allows
+  const int k32 = cout_pad % 128 == 0 && cin_pad % 32 == 0;
   hipLaunchKernelGGL(pack_weight_wf43_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, cout, cin,
-                     cout_pad, cin_pad / CF_BK, scale, reinterpret_cast<unsigned*>(packed), total);
+                     cout_pad, cin_pad / (k32 ? 32 : CF_BK), scale, reinterpret_cast<unsigned*>(packed), total, k32);
   CF_CHECK_LAUNCH("cf_pack_conv_weight_winograd43_f16x2");
   return CF_OK;
 }
@@ -799,21 +961,25 @@ int cf_wf43_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query) 
   a.tiles_x = d->wout / F4_TW;
   a.tiles_per_img = a.tiles_x * (d->hout / F4_TH);
   a.nparts = a.tiles_per_img;
-  const bool wide = d->cout % 128 == 0 && !getenv("CF_F43_NARROW");   // 16 waves x 128 channels where the layer has them (the variable: A/B only)
+  const bool wide = d->cout % 128 == 0;                      // 16 waves x 128 channels where the layer has them ...
+  const bool k32 = wide && (d->c0 + d->c1) % 32 == 0 && d->c0 % 32 == 0;   // ... on 32-channel slabs where the inputs allow (the weight layout of the pack function follows the same rule)
+  CF_REQUIRE(!wide || k32 || (d->c0 + d->c1) % 32 != 0, "cf_conv2d(winograd 2): a 128-channel layer with cin %% 32 == 0 needs c0 %% 32 == 0 (got %d + %d)", d->c0, d->c1);
   a.ntn = d->cout / (wide ? 128 : 64);
   if (parts_query) {
     *parts_query = a.nparts;
     return CF_OK;
   }
-  const size_t lds = (wide ? F4_LDS_FLOATS_16 : F4_LDS_FLOATS) * sizeof(float) + (F4_TIMING && !wide && getenv("CF_F43_ONE_WG") ? 32768 : 0);   // (timing builds: one workgroup per CU)
+  const size_t lds = (k32 ? F4_LDS_FLOATS_32 : wide ? F4_LDS_FLOATS_16 : F4_LDS_FLOATS) * sizeof(float) + (F4_TIMING && !wide && getenv("CF_F43_ONE_WG") ? 32768 : 0);   // (timing builds: one workgroup per CU)
   const dim3 grid(a.tiles_per_img * d->batch * a.ntn), block(wide ? 1024 : 512);
   // (cf_device_init sets the dynamic-LDS attribute of every instantiation on each device)
 #define F4_LAUNCH(P, E)                                                                                                       \
   do {                                                                                                                        \
-    CF_LDS_ATTR((wf43_kernel<P, E, 8>), F4_LDS_FLOATS * sizeof(float) + (F4_TIMING ? 32768 : 0));                             \
-    CF_LDS_ATTR((wf43_kernel<P, E, 16>), F4_LDS_FLOATS_16 * sizeof(float));                                                   \
-    if (wide) hipLaunchKernelGGL((wf43_kernel<P, E, 16>), grid, block, lds, stream, a);                                       \
-    else hipLaunchKernelGGL((wf43_kernel<P, E, 8>), grid, block, lds, stream, a);                                             \
+    CF_LDS_ATTR((wf43_kernel<P, E, 8, 16>), F4_LDS_FLOATS * sizeof(float) + (F4_TIMING ? 32768 : 0));                         \
+    CF_LDS_ATTR((wf43_kernel<P, E, 16, 16>), F4_LDS_FLOATS_16 * sizeof(float));                                               \
+    CF_LDS_ATTR((wf43_kernel<P, E, 16, 32>), F4_LDS_FLOATS_32 * sizeof(float));                                               \
+    if (k32) hipLaunchKernelGGL((wf43_kernel<P, E, 16, 32>), grid, block, lds, stream, a);                                    \
+    else if (wide) hipLaunchKernelGGL((wf43_kernel<P, E, 16, 16>), grid, block, lds, stream, a);                              \
+    else hipLaunchKernelGGL((wf43_kernel<P, E, 8, 16>), grid, block, lds, stream, a);                                         \
   } while (0)
 #define F4_LAUNCH_EPI(P)                                                           \
   do {                                                                             \

@@ -99,11 +99,12 @@ def winograd_ok(cin, cout, hout, wout):
 
 
 # Which layers a SPLIT_F43 request puts on the F(4x4,3x3) kernel: 'auto' (default) = the shapes where it measured faster than the
-# F(2x2,3x3) kernels inside the network at sixteen faces (profiles/r04_f43_per_shape.txt): every covered layer with 64 output channels (the
-# 8-wave form, two workgroups per CU) and the layers with a multiple of 128 output channels from 128x128 pixels up (the 16-wave form;
-# at 64x64 and below it loses: few patches per image, 0.169 vs 0.189 ms on 256 -> 256 @ 64x64); 'c64' = the first group only; 'all' =
-# every covered shape; '0' = none (A/B).
+# F(2x2,3x3) kernels at sixteen faces (profiles/r04_f43_per_shape.txt, tools/f43_check.py time): every covered layer with 64 output
+# channels (the 8-wave form, two workgroups per CU: x1.0-1.17) and the layers with a multiple of 128 output channels from 64x64 pixels up
+# (the 16-wave form on 32-channel slabs: x1.08-1.16; at 32x32 it loses, x0.6: 4 patches per image); 'c64' = the first group only;
+# 'all' = every covered shape; '0' = none (A/B).
 F43_LAYERS = os.environ.get('CODEFORMER_HIP_F43', 'auto')
+F43_WIDE_MIN_PIXELS = int(os.environ.get('CODEFORMER_HIP_F43_MINPIX', 64 * 64))   # smallest image of the 16-wave form under 'auto'
 
 
 def f43_ok(cin, cout, hout, wout):
@@ -111,7 +112,7 @@ def f43_ok(cin, cout, hout, wout):
     input channels (the GroupNorm rows of an image sit in LDS) -- narrowed by F43_LAYERS to where it pays."""
     if F43_LAYERS == '0' or (F43_LAYERS == 'c64' and cout != 64):
         return False
-    if F43_LAYERS == 'auto' and cout != 64 and (cout % 128 or hout * wout < 128 * 128):
+    if F43_LAYERS == 'auto' and cout != 64 and (cout % 128 or hout * wout < F43_WIDE_MIN_PIXELS):
         return False
     return cin % 16 == 0 and cin <= 256 and cout % 64 == 0 and hout % 16 == 0 and wout % 16 == 0
 

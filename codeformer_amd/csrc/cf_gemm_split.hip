@@ -14,6 +14,7 @@
 //     fp32 split-K GEMM): the bits do not depend on how many workgroups (1, 2, 4, 8) share a tile, so the host picks the split
 //     count from the tiles in flight and results stay bitwise batch-invariant;
 //   * epilogue: bias, exact-erf GELU or residual, 128-byte row segments per store instruction.
+#include <cstdlib>
 #include <type_traits>
 
 #include "cf_common.h"
@@ -138,6 +139,167 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GsArgs g) {
   }
 }
 
+// ---- the same GEMM with the token tile staged through LDS (round 4): 128 tokens x BN (64 / 128) columns per workgroup ------------
+// The kernel above gathers its A fragments per lane (32 rows x 64 bytes per instruction) and keeps ONE MFMA tile per wave: at 4096 tokens
+// it runs at 50-60 TFLOP/s, bound by the L2 latency of its 32-64 dependent k steps.  Here
+//   * the 128 x 32 token tile of a stage is read coalesced (a row's 128 bytes by 8 threads), split ONCE into hi / lo halves and written
+//     to LDS in operand order ([k step][row][half 0 hi | half 1 hi | half 0 lo | half 1 lo], 16-byte chunk c at c ^ ((row >> 2) & 3):
+//     conflict-free ds_read_b128), double-buffered, one barrier per stage;
+//   * a wave owns 64 tokens x BN / 2 columns (2 x NI MFMA tiles): a B fragment feeds two MFMA triples, an A fragment NI;
+//   * B fragments straight from L2 in the packed operand order, one stage (two k steps) ahead in registers.
+// Per output element the arithmetic is that of gemm_split_kernel with nsplit = 1 -- virtual chunks of 128 K values summed from zero in
+// k order (lo*hi, hi*lo, hi*hi per step), chunk sums added in chunk order, the same epilogue expression -- so the two kernels agree
+// BITWISE and the host picks by shape (this one: M % 128 == 0, no split) without touching batch invariance.
+template <int NI>
+__global__ __launch_bounds__(256) void gemm_split_tile_kernel(const GsArgs g) {
+  constexpr int BN = 64 * NI;
+  __shared__ __attribute__((aligned(16))) float As[2][2][128][16];  // [buffer][k step][row][16 words]: 32 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int ntn = g.N / BN;
+  const int nt = blockIdx.x % ntn, mt = blockIdx.x / ntn;
+  const int m0 = mt * 128, n0 = nt * BN + wn * (32 * NI);
+  const int nst = g.K >> 5;  // stages of 32 K values
+
+  // staging: item j of this thread is float4 #q of row (tid + 256 j) >> 3 of the tile's stage (k = 4 q .. 4 q + 3)
+  const float* const asrc = g.a + (size_t)(m0 + (tid >> 3)) * g.K + (tid & 7) * 4;
+  // Operands in flight: THREE stages ahead in a ring of four register sets (a stage's MFMAs last ~0.2 us, a load 1-2 us: with one
+  // stage ahead every stage waited for its operands -- 29.6 us on 4096 x 512 x 512, no better than the untiled kernel)
+  f32x4 rg[4][4];
+  auto load_stage = [&](int st, auto buf) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(buf)::value;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rg[BUF][j] = *reinterpret_cast<const f32x4*>(asrc + (size_t)(32 * j) * g.K + st * 32);
+  };
+  typedef float gs_f32x2 __attribute__((ext_vector_type(2)));
+  auto store_stage = [&](int lbuf, auto buf) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(buf)::value;
+    const int q = tid & 7, ks = q >> 2, hf = (q >> 1) & 1, sub = q & 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = (tid >> 3) + 32 * j;
+      const int swz = (row >> 2) & 3;
+      float h0, l0, h1, l1;
+      cf_split_pair(rg[BUF][j][0], rg[BUF][j][1], h0, l0);
+      cf_split_pair(rg[BUF][j][2], rg[BUF][j][3], h1, l1);
+      float* base = &As[lbuf][ks][row][0];
+      *reinterpret_cast<gs_f32x2*>(base + ((hf ^ swz) << 2) + sub * 2) = gs_f32x2{h0, h1};
+      *reinterpret_cast<gs_f32x2*>(base + (((2 + hf) ^ swz) << 2) + sub * 2) = gs_f32x2{l0, l1};
+    }
+  };
+  const size_t kstride = (size_t)(g.N >> 5) * 512;  // floats between consecutive k steps of the packed weights
+  const float* const wl = g.w + (size_t)(n0 >> 5) * 512 + lane * 4;
+  f32x4 rb[4][2][NI][2];  // [ring slot][k step][n tile][hi, lo]
+  auto load_B = [&](int st, auto buf) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(buf)::value;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const float* p = wl + (size_t)(st * 2 + s) * kstride + ni * 512;
+        rb[BUF][s][ni][0] = *reinterpret_cast<const f32x4*>(p);
+        rb[BUF][s][ni][1] = *reinterpret_cast<const f32x4*>(p + 256);
+      }
+  };
+  f32x16 acc[2][NI], tot[2][NI];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = tot[mi][ni][r] = 0.f;
+  auto compute = [&](int lbuf, auto buf) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(buf)::value;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      f32x4 ah[2], al[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int row = wm * 64 + mi * 32 + l31;
+        const int swz = (row >> 2) & 3;
+        ah[mi] = *reinterpret_cast<const f32x4*>(&As[lbuf][s][row][(half ^ swz) << 2]);
+        al[mi] = *reinterpret_cast<const f32x4*>(&As[lbuf][s][row][((2 + half) ^ swz) << 2]);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gs_f16x8, al[mi]), __builtin_bit_cast(gs_f16x8, rb[BUF][s][ni][0]), acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gs_f16x8, ah[mi]), __builtin_bit_cast(gs_f16x8, rb[BUF][s][ni][1]), acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gs_f16x8, ah[mi]), __builtin_bit_cast(gs_f16x8, rb[BUF][s][ni][0]), acc[mi][ni], 0, 0, 0);
+        }
+    }
+  };
+  using R0 = std::integral_constant<int, 0>;
+  using R1 = std::integral_constant<int, 1>;
+  using R2 = std::integral_constant<int, 2>;
+  using R3 = std::integral_constant<int, 3>;
+  // stage st: ring slot `cur` holds its B fragments, LDS buffer st & 1 its tokens; slot `nxt` (stage st + 1) is split into the other
+  // LDS buffer (its readers passed the barrier that opened this stage); the slot freed by stage st - 1 (`far`) takes stage st + 3
+  // (whether a stage requests / splits operands is a compile-time flag: under a run-time condition inside the loop hipcc's merged wait
+  //  counts make every stage wait for the loads it has just issued)
+  auto stage = [&](int st, auto cur, auto nxt, auto far, auto do_load, auto do_store) __attribute__((always_inline)) {
+    if constexpr (decltype(do_load)::value) {
+      load_stage(st + 3, far);
+      load_B(st + 3, far);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // (keep the prefetch ahead of the MFMAs)
+    compute(st & 1, cur);
+    if ((st & 3) == 3) {  // a virtual chunk of 128 K values is complete: fold it into the running sum, restart from zero
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            tot[mi][ni][r] += acc[mi][ni][r];
+            acc[mi][ni][r] = 0.f;
+          }
+    }
+    if constexpr (decltype(do_store)::value) store_stage((st + 1) & 1, nxt);
+    __syncthreads();
+  };
+  constexpr std::true_type Y{};
+  constexpr std::false_type NO{};
+  load_stage(0, R0{});
+  load_B(0, R0{});
+  load_stage(1, R1{});
+  load_B(1, R1{});
+  load_stage(2, R2{});
+  load_B(2, R2{});
+  store_stage(0, R0{});
+  __syncthreads();
+  int st = 0;
+  for (; st + 4 < nst; st += 4) {  // (K % 128 == 0: four stages per virtual chunk)
+    stage(st, R0{}, R1{}, R3{}, Y, Y);
+    stage(st + 1, R1{}, R2{}, R0{}, Y, Y);
+    stage(st + 2, R2{}, R3{}, R1{}, Y, Y);
+    stage(st + 3, R3{}, R0{}, R2{}, Y, Y);
+  }
+  stage(st, R0{}, R1{}, R3{}, Y, Y);   // the last chunk: one stage left to request, three to split
+  stage(st + 1, R1{}, R2{}, R0{}, NO, Y);
+  stage(st + 2, R2{}, R3{}, R1{}, NO, Y);
+  stage(st + 3, R3{}, R0{}, R2{}, NO, NO);
+
+  // ---- epilogue: lane holds column n of rows cf_acc_row(r, lane) of each of its tiles (the expression of gemm_split_kernel) ----
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = n0 + ni * 32 + l31;
+    const float bias = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const size_t o = (size_t)(m0 + wm * 64 + mi * 32 + cf_acc_row(r, lane)) * g.N + n;
+        float v = tot[mi][ni][r] * g.acc_scale + bias;
+        if (g.epilogue == CF_EPI_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        if (g.epilogue == CF_EPI_RESIDUAL) v += g.res[o];
+        g.out[o] = v;
+      }
+  }
+}
+
 // W' = scale * W as hi = f16(W'), lo = f16(W' - hi) in MFMA-operand order [K/16][N/32][hi, lo][lane 64][4 words]:
 // a lane's 16 bytes are the 8 halves of W'[n = tile*32 + (lane&31)][k = kstep*16 + (lane>>5)*8 + 0..7]
 __global__ void pack_linear_f16x2_kernel(const float* __restrict__ w, int N, int K, float scale, unsigned* __restrict__ packed, long total) {
@@ -214,6 +376,19 @@ int cf_gemm_split_launch(const cf_conv_desc* d, hipStream_t stream) {
   g.ws = d->workspace;
   g.counters = d->counters;
   g.nsplit = nsplit;
+  // token tiles of 128 rows staged through LDS where the shape allows and K is not split (bitwise the same result: see the kernel);
+  // the narrow form keeps a 128 x 64 grid at 256+ workgroups for N = 512
+  // CF_GEMM_TILE (A/B only): 0 the untiled kernel, 1 (default) 128 x 64 tiles, 2 also 128 x 128 tiles where they still give 256 workgroups
+  // (measured inside the step: 26.9 vs 29.6 us on 4096 x 512 x 1024 -- the narrow tile's 512 workgroups keep more loads in flight)
+  static const int tile_mode = getenv("CF_GEMM_TILE") ? atoi(getenv("CF_GEMM_TILE")) : 1;
+  if (nsplit == 1 && g.M % 128 == 0 && g.K % 64 == 0 && tile_mode != 0) {
+    if (tile_mode == 2 && g.N % 128 == 0 && (long)(g.M / 128) * (g.N / 128) >= 256)
+      hipLaunchKernelGGL(gemm_split_tile_kernel<2>, dim3((unsigned)((g.M / 128) * (g.N / 128))), dim3(256), 0, stream, g);
+    else
+      hipLaunchKernelGGL(gemm_split_tile_kernel<1>, dim3((unsigned)((g.M / 128) * (g.N / 64))), dim3(256), 0, stream, g);
+    CF_CHECK_LAUNCH("cf_conv2d(1x1, f16x2, token tiles)");
+    return CF_OK;
+  }
   hipLaunchKernelGGL(gemm_split_kernel, dim3((unsigned)(tiles * nsplit)), dim3(256), 0, stream, g);
   CF_CHECK_LAUNCH("cf_conv2d(1x1, f16x2)");
   return CF_OK;

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
   const __amdgpu_buffer_rsrc_t rs_in0 = f4_rsrc(a.in0 + img0 * a.c0, img_px * (unsigned)a.c0 * 4u);
   const __amdgpu_buffer_rsrc_t rs_in1 = f4_rsrc(a.c1 ? a.in1 + img0 * a.c1 : a.in0, img_px * (unsigned)a.c1 * 4u);
   constexpr int RAN = KS == 32 ? F4_APT / 2 : F4_APT;   // gather registers: 32-channel slabs load and store a slab's items in two halves
-  f32x4 ra[RAN];
+  f32x4 ra[RAN], rb[KS == 32 ? RAN : 1];   // (rb: the second half of the 32-channel-slab form, live inside the T interval only)
   // unconditional loads from clamped addresses; out-of-image items are zeroed at the store (see cf_winograd.hip)
   auto load_A_range = [&](int chunk, auto j0c, auto j1c) __attribute__((always_inline)) {
     constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
       bool valid;
       item(tl / (unsigned)QPP, j, rel, valid);
       const unsigned voff = (__umul24((unsigned)(pix_origin + (int)rel), cs) + k4x) * 4u;
-      ra[j % RAN] = first ? f4_ld128(rs_in0, voff, soff) : f4_ld128(rs_in1, voff, soff);
+      (KS == 32 && j >= RAN ? rb[j % RAN] : ra[j % RAN]) = first ? f4_ld128(rs_in0, voff, soff) : f4_ld128(rs_in1, voff, soff);
     }
   };
   auto load_A = [&](int chunk) __attribute__((always_inline)) { load_A_range(chunk, std::integral_constant<int, 0>{}, std::integral_constant<int, F4_APT>{}); };
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
       unsigned rel;
       bool valid;
       item(slot, j, rel, valid);
-      f32x4 v = ra[j % RAN];
+      f32x4 v = KS == 32 && j >= RAN ? rb[j % RAN] : ra[j % RAN];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float y = v[e];
@@ -571,18 +571,18 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
         F4_T(4);
       }
     } else {
-      // the gather of a slab in two halves of three items (12 registers): half 0 is requested behind the M interval and stored at the top of
-      // the next T interval, half 1 requested there and stored at its end -- these waves wait for the transform of the others anyway
+      // the gather of a slab in two halves of three items (12 registers): half 0 is requested behind the M interval (12 registers beside the fragment rings), half 1 at the top of the
+      // next T interval, where half 0 is stored first -- these waves wait for the transform of the others anyway
       constexpr std::integral_constant<int, 0> h0{};
       constexpr std::integral_constant<int, F4_APT / 2> h1{};
       constexpr std::integral_constant<int, F4_APT> h2{};
       auto feed2 = [&](int s) __attribute__((always_inline)) {  // patch(s): half 0 is in flight
         if (s < n) {
+          load_A_range(s, h1, h2);   // (its own registers: no fragment ring is live in the T interval)
+          __builtin_amdgcn_sched_barrier(0);
 #if !(F4_ABLATE & 4)
           store_patch_range(s, h0, h1);
 #endif
-          __builtin_amdgcn_sched_barrier(0);
-          load_A_range(s, h1, h2);
           __builtin_amdgcn_sched_barrier(0);
 #if !(F4_ABLATE & 4)
           store_patch_range(s, h1, h2);

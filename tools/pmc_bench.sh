@@ -17,7 +17,7 @@ for f in sorted(glob.glob('/tmp/pb*/**/*counter_collection.csv', recursive=True)
     seen = set()
     for r in csv.DictReader(open(f)):
         name = r['Kernel_Name']
-        if 'igemm' in name or 'gemm_split' in name or 'act_scale' in name or 'split_conv' in name or 'winograd' in name or 'wsplit' in name or 'few_c' in name or 'gn_' in name or 'attn' in name or 'layernorm' in name or 'argmax' in name or 'gather' in name:
+        if 'igemm' in name or 'gemm_split' in name or 'act_scale' in name or 'split_conv' in name or 'winograd' in name or 'wsplit' in name or 'wf43_kernel' in name or 'few_c' in name or 'gn_' in name or 'attn' in name or 'layernorm' in name or 'argmax' in name or 'gather' in name:
             key = name.replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0][:64]
             agg[key][r['Counter_Name']].append(float(r['Counter_Value']))
             if (f, r['Dispatch_Id']) not in seen and r['Counter_Name'] in ('GRBM_GUI_ACTIVE', 'FETCH_SIZE'):

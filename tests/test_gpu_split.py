@@ -329,3 +329,28 @@ def test_split_conv_1x1_streaming_against_fp64_and_the_exact_kernel(sc):
     # a token-sized image with this weight form is refused on the host (the C ABI would read it as a token-GEMM weight)
     with pytest.raises(ValueError, match='1x1'):
         ops.conv2d(torch.zeros(1, 16, 16, 512, device='cuda'), pw)
+
+
+def test_winograd_f43_forms_against_fp64(sc):
+    """cf_wf43.hip (cf_conv_desc.winograd = 2, generator / fusion layers only): the 8-wave 64-channel form, the 16-wave 128-channel form on
+    32-channel slabs and on 16-channel slabs (cin % 32 != 0), every prologue / epilogue / concat combination, extreme magnitudes behind
+    the pack-time weight scale and the per-image activation scale -- against fp64: max error <= 2e-5 * max(|ref| / 4, 1) (measured
+    0.8-1.5e-5: 5-8x the F(2,3) kernels, the conditioning of the larger transform), GroupNorm partials to 2e-6, bitwise repeatable;
+    and the per-image bits do not depend on the batch."""
+    import importlib.util
+    import torch
+    from codeformer_amd import ops
+    spec = importlib.util.spec_from_file_location('f43_check', os.path.join(ROOT, 'tools', 'f43_check.py'))
+    fc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fc)
+    assert len(fc.SMALL) >= 12
+    for c in fc.SMALL:
+        assert fc.case(**c), c
+    g = torch.Generator().manual_seed(3)
+    for cin, cout in ((64, 64), (128, 128), (48, 128)):
+        x = torch.randn(3, 32, 48, cin, generator=g).cuda()
+        pw = ops.pack_weight((torch.randn(cout, cin, 3, 3, generator=g) * 0.03).cuda(), torch.randn(cout, generator=g).cuda(), bf16=ops.WF43)
+        y = ops.conv2d(x, pw, emit_stats=True, act=ops.act_scale(x))
+        x1 = x[1:2].contiguous()
+        y1 = ops.conv2d(x1, pw, emit_stats=True, act=ops.act_scale(x1))
+        assert torch.equal(y[1:2], y1) and torch.equal(y._cf_stats.part.view(3, -1)[1:2], y1._cf_stats.part.view(1, -1))

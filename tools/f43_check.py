@@ -109,6 +109,8 @@ SMALL = [dict(B=1, H=16, W=32, cin=16, cout=64),
          dict(B=1, H=32, W=32, cin=256, cout=256, prologue=ops.PRO_AFFINE_SWISH, stats=True, seed=5),
          dict(B=3, H=16, W=64, cin=64, cout=64, c_split=48, seed=6),
          dict(B=1, H=32, W=32, cin=256, cout=64, prologue=ops.PRO_AFFINE_SWISH, seed=7),
+         dict(B=2, H=32, W=48, cin=48, cout=128, prologue=ops.PRO_AFFINE_SWISH, epilogue=ops.EPI_RESIDUAL, stats=True, seed=8),   # 16 waves on 16-channel slabs (cin % 32 != 0)
+         dict(B=1, H=48, W=32, cin=128, cout=256, c_split=64, prologue=ops.PRO_LEAKY, epilogue=ops.EPI_SFT, stats=True, seed=13),  # 16 waves, 32-channel slabs, two channel tiles, concat
          # magnitudes: the pack-time weight scale and the per-image activation scale must absorb them
          dict(B=1, H=16, W=32, cin=64, cout=64, wscale=300.0, seed=9),
          dict(B=2, H=16, W=32, cin=64, cout=64, wscale=1e-4, xscale=1e9, seed=10),

@@ -1,5 +1,7 @@
-// Winograd F(4x4,3x3) convolution with split-half operands: 16x16-pixel patches, 64 output channels per eight-wave workgroup, TWO
-// workgroups per CU (gfx950).
+// Winograd F(4x4,3x3) convolution with split-half operands on 16x16-pixel patches (gfx950), three instantiations of one kernel:
+//   <PRO, EPI, 8, 16>   64 output channels per eight-wave workgroup, TWO workgroups per CU (the text below describes this form)
+//   <PRO, EPI, 16, 32>  128 output channels per sixteen-wave workgroup on 32-channel slabs (see "The 16-wave form" at the end)
+//   <PRO, EPI, 16, 16>  the same on 16-channel slabs (cin % 32 != 0)
 //
 // Serves 3x3 stride-1 convolutions of GENERATOR and fusion (CFT) blocks (vqgan_arch.py:141-164,296-323, codeformer_arch.py:136-157) --
 // never the encoder, which decides the code indices and stays on F(2x2,3x3).
@@ -48,6 +50,16 @@
 //     four columns, applies acc_scale / bias / residual / SFT, stores 8-byte pairs (a half-wave writes 256 contiguous bytes per pixel) and
 //     accumulates the GroupNorm statistics of what it wrote (fp32 over four values, then fp64; fixed shuffle order, the waves joined
 //     through LDS in wave order: one partial per patch and group).
+//
+// The 16-wave form (layers with a multiple of 128 output channels): the same patch for 128 channels -- gather, prologue and transform of
+// a patch serve both channel halves -- at 1024 threads x 128 registers = the whole register file, one workgroup per CU, 159,744 bytes of
+// LDS.  32-channel slabs: v_mfma_f32_16x16x32_f16 at the full MFMA rate and half the barrier intervals per input channel; 128-byte pixel
+// slots (the same swizzle on bit 7); waves 0..7 transform (wave = (xi half, tile row), lane = (tile column, 16 channel pairs)), waves
+// 8..15 gather in two halves of three items (half 0 requested behind the M interval, half 1 inside the T interval, where no fragment
+// ring is live); V rows of 128 bytes in 8-byte units placed by f4_vu (four ds_read_b64 per A fragment without bank conflicts); B
+// fragments of 32 bytes per lane, ring of three positions, ONE A register set -- what 128 registers hold beside 72 accumulators (a ring
+// of two does not cover L2 latency: 0.79 vs 0.72 ms on 128 -> 128 @ 256x256 x 16).  Its M interval is bound by the weight stream: 36 x 32
+// x 128 x 4 B = 590 KB per slab through the CU's 64 B/clk vector-memory path (profiles/r04_f43_k32_stage_timing.txt).
 #include <cstdlib>
 #include <type_traits>
 
@@ -227,8 +239,9 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
   // one descriptor per concatenated input, based at this image (the launch checks that an image stays below 2^31 bytes)
   const __amdgpu_buffer_rsrc_t rs_in0 = f4_rsrc(a.in0 + img0 * a.c0, img_px * (unsigned)a.c0 * 4u);
   const __amdgpu_buffer_rsrc_t rs_in1 = f4_rsrc(a.c1 ? a.in1 + img0 * a.c1 : a.in0, img_px * (unsigned)a.c1 * 4u);
-  constexpr int RAN = KS == 32 ? F4_APT / 2 : F4_APT;   // gather registers: 32-channel slabs load and store a slab's items in two halves
-  f32x4 ra[RAN], rb[KS == 32 ? RAN : 1];   // (rb: the second half of the 32-channel-slab form, live inside the T interval only)
+  constexpr bool HALVES = F4_APT >= 6;                   // six items per gather thread: a slab's items are requested and stored in two halves
+  constexpr int RAN = HALVES ? F4_APT / 2 : F4_APT;     // gather registers that cross the M interval
+  f32x4 ra[RAN], rb[HALVES ? RAN : 1];                   // (rb: the second half, live inside the T interval only)
   // unconditional loads from clamped addresses; out-of-image items are zeroed at the store (see cf_winograd.hip)
   auto load_A_range = [&](int chunk, auto j0c, auto j1c) __attribute__((always_inline)) {
     constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value;
@@ -246,7 +259,7 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
       bool valid;
       item(tl / (unsigned)QPP, j, rel, valid);
       const unsigned voff = (__umul24((unsigned)(pix_origin + (int)rel), cs) + k4x) * 4u;
-      (KS == 32 && j >= RAN ? rb[j % RAN] : ra[j % RAN]) = first ? f4_ld128(rs_in0, voff, soff) : f4_ld128(rs_in1, voff, soff);
+      (HALVES && j >= RAN ? rb[j % RAN] : ra[j % RAN]) = first ? f4_ld128(rs_in0, voff, soff) : f4_ld128(rs_in1, voff, soff);
     }
   };
   auto load_A = [&](int chunk) __attribute__((always_inline)) { load_A_range(chunk, std::integral_constant<int, 0>{}, std::integral_constant<int, F4_APT>{}); };
@@ -266,7 +279,7 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
       unsigned rel;
       bool valid;
       item(slot, j, rel, valid);
-      f32x4 v = KS == 32 && j >= RAN ? rb[j % RAN] : ra[j % RAN];
+      f32x4 v = HALVES && j >= RAN ? rb[j % RAN] : ra[j % RAN];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float y = v[e];
@@ -529,7 +542,7 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
     lane16 = ln * 32u;
   };
   constexpr std::integral_constant<int, 4> na4{};
-  constexpr std::integral_constant<int, (NW == 8 ? 2 : 4)> na_gather{};   // (the 16-wave form carries 8 gather registers, not 24)
+  constexpr std::integral_constant<int, 4> na_gather{};   // (12 gather registers at most cross the M interval: room for the A prefetch)
   auto feed = [&](int s) __attribute__((always_inline)) {  // waves 4..7: prologue + store of slab s (if any); its successor is requested inside the M interval
     if (s < n) {
 #if !(F4_ABLATE & 4)
@@ -643,17 +656,36 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
       F4_T(4);
     }
   } else {
-    load_A(0);
+    // With six items per thread (the 8-wave form) a slab's gather goes in two halves of three, as in the 32-channel-slab form: half 0
+    // behind the slab's last weight-fragment request inside the M interval (12 registers beside the rings), half 1 at the top of the
+    // T interval, where half 0 is stored first.
+    constexpr std::integral_constant<int, 0> h0{};
+    constexpr std::integral_constant<int, (HALVES ? F4_APT / 2 : F4_APT)> h1{};
+    constexpr std::integral_constant<int, F4_APT> h2{};
+    auto feedh = [&](int s) __attribute__((always_inline)) {  // patch(s): the items [h0, h1) are in flight
+      if (s < n) {
+        if (HALVES) load_A_range(s, h1, h2);
+        __builtin_amdgcn_sched_barrier(0);
+#if !(F4_ABLATE & 4)
+        store_patch_range(s, h0, h1);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+#if !(F4_ABLATE & 4)
+        if (HALVES) store_patch_range(s, h1, h2);
+#endif
+      }
+    };
+    load_A_range(0, h0, h1);
     __syncthreads();  // (the GroupNorm rows are in LDS)
-    feed(0);
-    if (n > 1) load_A(1);
+    feedh(0);
+    if (n > 1) load_A_range(1, h0, h1);
     __syncthreads();
     F4_T(0);
     // (two loops: with the gather request under a condition inside one loop, hipcc's wait for the weight fragments requested before
     //  it must also be right for the path without the request -- and then waits for the gather as well)
     int s = 0;
     for (; s + 2 < n; ++s) {
-      feed(s + 1);
+      feedh(s + 1);
       __builtin_amdgcn_sched_barrier(0);
       set_lane16();
 #pragma unroll
@@ -662,14 +694,14 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
       F4_T(1);
       __syncthreads();
       F4_T(2);
-      mma_stage(s, na_gather, [&]() __attribute__((always_inline)) { load_A(s + 2); });
+      mma_stage(s, na_gather, [&]() __attribute__((always_inline)) { load_A_range(s + 2, h0, h1); });
       __builtin_amdgcn_sched_barrier(0);
       F4_T(3);
       __syncthreads();
       F4_T(4);
     }
     for (; s < n; ++s) {  // the last two slabs: nothing left to request
-      feed(s + 1);
+      feedh(s + 1);
       __builtin_amdgcn_sched_barrier(0);
       set_lane16();
 #pragma unroll

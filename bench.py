@@ -16,8 +16,8 @@ generator and fusion blocks as Winograd F(2x2,3x3) / F(4x4,3x3), stride 2 as a 2
 upsample convolutions), the image-sized 1x1 skip convolutions and 46 of the 47 Linear launches of the Transformer (those whose input
 is bounded by a LayerNorm one Linear layer back).  That is NARROWER than IEEE fp32: the headline of this mode is not "fp32"; it
 meets the config's gates (pixels 1e-3, logits 1e-4, code indices exact; `parity`).  'fp32' is the IEEE-fp32 evaluation (Winograd
-F(2x2,3x3) on fp32 MFMA: the same function, a different summation order than ATen's); at N=1 the default run times it too and reports
-it under `exact_fp32` WITH ITS OWN roofline object -- that leg is BASELINE config 2 to the letter.  `config3_rank` is one rank's share of
+F(2x2,3x3) / F(4x4,3x3) on fp32 MFMA operands: the same function, a different summation order than ATen's); at N=1 the default run gates
+and times it too and reports it under `exact_fp32` WITH ITS OWN parity and roofline objects -- that leg is BASELINE config 2 to the letter.  `config3_rank` is one rank's share of
 BASELINE config 3 (batch 16 per GPU, w = 0.7, precision 'bf16': single bf16 operands in generator + fusion blocks), timed after its
 own gate (indices exact, logits 1e-4, pixels within the stated bf16 gate of the reference golden at w = 0.7).
 
@@ -100,6 +100,11 @@ def recorded_traffic(prefixes=('wsplit_kernel',)):
     return {'bytes_per_launch': round(tot / n), 'source': os.path.relpath(files[-1], ROOT)} if n else None
 
 
+def wf43_names(f32):
+    """Instantiation names of wf43_kernel<PRO, EPI, NW, KS, F32> for one operand type (the template argument is the LAST one: no common prefix)."""
+    return tuple(f'wf43_kernel<{p}, {e}, {nw}, {ks}, {f32}>' for p in range(4) for e in range(3) for nw, ks in ((8, 16), (16, 16), (16, 32)))
+
+
 def roofline_leg(net, x, w):
     """Per-launch event timing of every implicit-GEMM launch of one forward; returns the roofline object + a table."""
     from codeformer_amd import ops
@@ -142,7 +147,9 @@ def roofline_leg(net, x, w):
         'conv3x3_wino_f16x2': ('winograd_kernel<.,true> (the same on the four-wave 64-channel kernel: 64-channel layers and the 16x16 latents)',
                                3.0 * 4.0 / 9.0, F16_MFMA_PEAK_TFLOPS, ('winograd_kernel<false, true', 'winograd_kernel<true, true')),
         'conv3x3_wino43_f16x2': ('wf43_kernel (3x3 s1 as Winograd F(4x4,3x3) on 16x16 patches, generator / fusion layers only: 64 output channels per 8-wave workgroup (two per CU) '
-                                 'or 128 per 16-wave workgroup; U and V as hi+lo halves: 36 transform-domain products per 16 outputs x 3 f16 MFMAs)', 3.0 * 2.25 / 9.0, F16_MFMA_PEAK_TFLOPS, ('wf43_kernel',)),
+                                 'or 128 per 16-wave workgroup; U and V as hi+lo halves: 36 transform-domain products per 16 outputs x 3 f16 MFMAs)', 3.0 * 2.25 / 9.0, F16_MFMA_PEAK_TFLOPS, wf43_names('false')),
+        'conv3x3_wino43': ('wf43_kernel<..., true> (the same kernel with IEEE-fp32 operands: 36 transform-domain products per 16 outputs on v_mfma_f32_16x16x4_f32; '
+                           "precision 'fp32')", 2.25 / 9.0, FP32_MFMA_PEAK_TFLOPS, wf43_names('true')),
         'conv3x3': ('igemm_kernel<9,1,...> (direct 3x3 s1 implicit GEMM, fp32 MFMA)', 1.0, FP32_MFMA_PEAK_TFLOPS, ('igemm_kernel<9, 1',)),
         'conv3x3_io': ('conv3x3_few_cin / conv3x3_few_cout (3->64 and 64->3 at 512x512 on the vector ALU: write- / read-bound)', 0.0, HBM_PEAK_GBS, ('conv3x3_few_c',)),
         'conv_up2x': ('igemm_kernel<4,1,...> (folded nearest-x2 + 3x3, fp32 MFMA)', 1.0, FP32_MFMA_PEAK_TFLOPS, ('igemm_kernel<4, 1',)),
@@ -381,11 +388,14 @@ def main():
         if world == 1 and args.precision == 'f16x2' and not args.no_exact_leg:
             y_split = net(x, w=args.w, adain=True)
             net.precision = 'fp32'
+            gate2 = None if args.no_parity_gate else parity_gate(net, sd_cpu, weights, args.w)   # the same gate as the headline, before this leg is timed
             y_exact = net(x, w=args.w, adain=True)
             dt1 = timed(args.w)
             line['exact_fp32'] = {'value': round(args.steps * total / dt1, 2), 'unit': 'faces/s', 'ms_per_step': round(dt1 / args.steps * 1e3, 3),
-                                  'what': 'the same step with precision=fp32 -- BASELINE config 2 to the letter: every convolution on exact fp32 MFMA '
-                                          '(Winograd F(2x2,3x3) where eligible: the same function, another summation order than ATen)',
+                                  'what': 'the same step with precision=fp32 -- BASELINE config 2 to the letter: every product of every convolution / Linear on '
+                                          'IEEE-fp32 MFMA operands (Winograd where eligible -- F(2x2,3x3) in the encoder, F(4x4,3x3) in generator + fusion layers that '
+                                          'cf_wf43.hip covers: the same function, another summation order than ATen)',
+                                  'parity': gate2,
                                   'max_abs_pixel_diff_vs_default': float((y_split[0] - y_exact[0]).abs().max()),
                                   'max_abs_logit_diff_vs_default': float((y_split[1] - y_exact[1]).abs().max()),
                                   'code_indices_equal': bool(torch.equal(y_split[1].argmax(-1), y_exact[1].argmax(-1)))}

@@ -217,7 +217,7 @@ class CodeFormer(VQAutoEncoder):
         #            the fp64-error of the exact kernels; whole network vs the reference on real crops: pixels 7.2e-5 (exact path
         #            7.1e-5; tolerance 1e-3), logits 6.7e-6 (exact: 7.6e-6; tolerance 1e-4), code indices identical.  1.5x the exact
         #            path's faces/s.
-        #   'fp32':  everything on exact fp32 MFMA (Winograd F(2x2,3x3) where eligible, see below).
+        #   'fp32':  everything on exact fp32 MFMA operands (Winograd where eligible: F(2x2,3x3), and F(4x4,3x3) in generator / CFT, see below).
         #   'bf16' (BASELINE configs 3/5) / 'fp16': single 16-bit operands with fp32 accumulate in generator + CFT -- in the Winograd domain
         #            (one MFMA per transform-domain product, cf_wsplit.hip) for the 128-channel-tile layers from 32x32 up, the direct 16-bit
         #            kernel elsewhere; the encoder runs as in the default mode (split halves, fp32-grade), so logits and code indices are
@@ -227,8 +227,8 @@ class CodeFormer(VQAutoEncoder):
         # stride-1 convolutions with Winograd F(2x2,3x3) -- the same function in fp32 with 2.25x fewer multiplies (cf_winograd.hip).
         # Set False (or CODEFORMER_HIP_WINOGRAD=0) for the direct evaluation everywhere.
         self.winograd = os.environ.get('CODEFORMER_HIP_WINOGRAD', '1') != '0'
-        # precision 'f16x2' only: generator / CFT layers the F(4x4,3x3) kernel covers (ops.f43_ok; which shapes: CODEFORMER_HIP_F43) run
-        # there -- 2.25 instead of 4 transform-domain products per output.  Its error against fp64 is ~5x that of F(2x2,3x3): far inside
+        # precision 'f16x2' and 'fp32': generator / CFT layers the F(4x4,3x3) kernel covers (ops.f43_ok; which shapes: CODEFORMER_HIP_F43) run
+        # there (split-half / IEEE-fp32 operands) -- 2.25 instead of 4 transform-domain products per output.  Its error against fp64 is ~5x that of F(2x2,3x3): far inside
         # the pixel tolerance, never used in the encoder.  False / CODEFORMER_HIP_F43=0: F(2x2,3x3) everywhere.
         self.winograd_f43 = ops.F43_LAYERS != '0'
         # Also evaluate the ENCODER's 3x3 stride-1 convolutions with Winograd, in every precision mode (the encoder is always
@@ -338,6 +338,8 @@ class CodeFormer(VQAutoEncoder):
             bf16 = ops.WINOGRAD
         if bf16 == ops.SPLIT and not self.winograd:
             bf16 = ops.SPLIT_DIRECT
+        if bf16 == ops.WINOGRAD and self.winograd_f43:
+            bf16 = ops.WINOGRAD_F43   # the same layers on fp32 operands (four v_mfma_f32_16x16x4_f32 per 16 channels instead of three f16 MFMAs)
         if bf16 == ops.SPLIT and self.winograd_f43:
             bf16 = ops.SPLIT_F43   # generator + CFT only (this code never reaches the encoder, which decides the indices)
         gen_taps = None

@@ -36,7 +36,7 @@ class HipModule(nn.Module):
         shapes they do not cover fall back as ops.conv_code says."""
         conv = getattr(self, name) if isinstance(name, str) else name
         code = 2 if f16 else int(bf16)
-        if code in (ops.WINOGRAD,) + ops.SPLIT_CODES or (code in (1, 2) and hw is not None and not up2x):
+        if code in (ops.WINOGRAD, ops.WINOGRAD_F43) + ops.SPLIT_CODES or (code in (1, 2) and hw is not None and not up2x):
             cout, cin = conv.weight.shape[:2]
             if hw is None or tuple(conv.weight.shape[2:]) != (3, 3):
                 code = 0
@@ -50,7 +50,7 @@ class HipModule(nn.Module):
         replacement when |gamma| * sqrt(n - 1) + |beta| could leave the IEEE-half operand range (ops.gn_range_ok).  The two maxima are
         read back once per parameter version."""
         code = int(code)
-        if code in (0, 1, ops.WINOGRAD):
+        if code in (0, 1, ops.WINOGRAD, ops.WINOGRAD_F43):
             return code
         gmax, bmax = self._packed(('gn_range', id(norm)),
                                   lambda: (float(norm.weight.detach().abs().max()), float(norm.bias.detach().abs().max())),

@@ -25,18 +25,19 @@ extern "C" const char* cf_build_id(void) { return g_build_id + 12; }
 extern "C" const char* cf_last_error(void) { return g_err; }
 // Table of the kernels that need the dynamic-LDS attribute (cf_common.h): filled by static initialisers while the library loads, constant
 // afterwards.  Zero-initialised storage, so the order of the initialisers across translation units does not matter.
-static const void* g_lds_kernel[128];
-static int g_lds_bytes[128];
+constexpr int CF_LDS_TABLE = 256;
+static const void* g_lds_kernel[CF_LDS_TABLE];
+static int g_lds_bytes[CF_LDS_TABLE];
 static int g_lds_count;
 int cf_register_kernel_lds(const void* kernel, int lds_bytes) {
-  if (g_lds_count < 128) {
+  if (g_lds_count < CF_LDS_TABLE) {
     g_lds_kernel[g_lds_count] = kernel;
     g_lds_bytes[g_lds_count] = lds_bytes;
   }
   return g_lds_count++;
 }
 extern "C" int cf_device_init(void) {
-  CF_REQUIRE(g_lds_count <= 128, "cf_device_init: kernel table overflow (%d entries)", g_lds_count);
+  CF_REQUIRE(g_lds_count <= CF_LDS_TABLE, "cf_device_init: kernel table overflow (%d entries)", g_lds_count);
   for (int i = 0; i < g_lds_count; ++i) {
     const hipError_t e = hipFuncSetAttribute(g_lds_kernel[i], hipFuncAttributeMaxDynamicSharedMemorySize, g_lds_bytes[i]);
     if (e != hipSuccess) {

@@ -162,7 +162,10 @@ __device__ __forceinline__ unsigned f4_vu(unsigned lq, unsigned p, unsigned t) {
 
 // KS = channels per slab: 16 (v_mfma_f32_16x16x16_f16; both forms) or 32 (v_mfma_f32_16x16x32_f16 at twice the rate and half the barrier
 // intervals per input channel: the 16-wave form only -- its 157 KB of LDS hold two 41 KB patch buffers and a 72 KB V)
-template <int PRO, int EPI, int NW, int KS>
+// F32 = IEEE-fp32 operands on v_mfma_f32_16x16x4_f32 (precision 'fp32': BASELINE config 2 to the letter) instead of hi + lo halves: the SAME
+// data movement -- a lane's A and B fragments are 16 (32) bytes either way: four (eight) fp32 values k = 4 j + (lane >> 4) instead of
+// [4 hi halves | 4 lo halves] -- with four (eight) fp32 MFMAs per position instead of three f16 ones; no weight / activation scale.
+template <int PRO, int EPI, int NW, int KS, bool F32>
 __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
   static_assert(KS == 16 || (KS == 32 && NW == 16), "32-channel slabs need the LDS of the 16-wave form");
   constexpr int F4_THREADS = NW * 64;
@@ -323,10 +326,15 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
     v[5] = (zz[1] + zz[5]) * 0.25f - zz[3] * 1.0625f;
 #pragma unroll
     for (int nu = 0; nu < 6; ++nu) {  // operand split, store: per (position, tile) four quads of [4 hi halves | 4 lo halves]
-      float hi, lo;
-      cf_split_pair(v[nu][0], v[nu][1], hi, lo);
-      t_hi[(pos + nu) * PSK] = hi;
-      t_lo[(pos + nu) * PSK] = lo;
+      if (F32) {  // fp32 operands: the pair's two channels go to their own k-group slots (t_hi / t_lo point there)
+        t_hi[(pos + nu) * PSK] = v[nu][0];
+        t_lo[(pos + nu) * PSK] = v[nu][1];
+      } else {
+        float hi, lo;
+        cf_split_pair(v[nu][0], v[nu][1], hi, lo);
+        t_hi[(pos + nu) * PSK] = hi;
+        t_lo[(pos + nu) * PSK] = lo;
+      }
     }
   };
   // Two parts keep the live set small: first the single row of the half (xi 0 from tile rows 0, 2, 4 / xi 5 from rows 1, 3, 5), then
@@ -346,7 +354,19 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
     unsigned tk[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) tk[k] = t_base | (((tb0 + k) & 3u) << SH);
-    if (KS == 32) {
+    if (F32) {
+      // fp32 operands: channel c of the slab is k-group j = c >> 2 of lane quad lq = c & 3; the pair (2 cp, 2 cp + 1) shares j = cp >> 1 and
+      // sits in quads lq0 = (2 cp) & 3 and lq0 + 1.  16-channel slabs: quad lq of a tile = its 16-byte chunk (word j); 32-channel slabs:
+      // unit p = j >> 1 of quad lq (f4_vu), word j & 1
+      const unsigned lq0 = (2u * t_cp) & 3u, j = t_cp >> 1;
+      if (KS == 32) {
+        t_hi = V + (tg * 18) * PSK + t_tile * 32 + f4_vu(lq0, j >> 1, t_tile) * 2u + (j & 1u);
+        t_lo = V + (tg * 18) * PSK + t_tile * 32 + f4_vu(lq0 + 1u, j >> 1, t_tile) * 2u + (j & 1u);
+      } else {
+        t_hi = V + (tg * 18) * PSK + t_tile * CF_BK + ((lq0 ^ (unsigned)f4_vs((int)t_ty)) << 2) + j;
+        t_lo = V + (tg * 18) * PSK + t_tile * CF_BK + (((lq0 + 1u) ^ (unsigned)f4_vs((int)t_ty)) << 2) + j;
+      }
+    } else if (KS == 32) {
       const unsigned lq = t_cp >> 2, e = t_cp & 3u;
       t_hi = V + (tg * 18) * PSK + t_tile * 32 + f4_vu(lq, e >> 1, t_tile) * 2u + (e & 1u);
       t_lo = V + (tg * 18) * PSK + t_tile * 32 + f4_vu(lq, 2u + (e >> 1), t_tile) * 2u + (e & 1u);
@@ -469,12 +489,25 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
       }
       __builtin_amdgcn_sched_barrier(0);
       const f32x4 a0 = va[i % NA], a1 = va[(i + 1) % NA], b0 = bq[i % 4], b1 = bq[(i + 1) % 4];
-      mfma(a0[2], a0[3], b0[0], b0[1], acc[i]);
-      mfma(a1[2], a1[3], b1[0], b1[1], acc[i + 1]);
-      mfma(a0[0], a0[1], b0[2], b0[3], acc[i]);
-      mfma(a1[0], a1[1], b1[2], b1[3], acc[i + 1]);
-      mfma(a0[0], a0[1], b0[0], b0[1], acc[i]);
-      mfma(a1[0], a1[1], b1[0], b1[1], acc[i + 1]);
+      if (F32) {  // k groups 0..3 in order, the two positions interleaved
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#if F4_ABLATE & 1
+          acc[i][0] += a0[j] + b0[j];
+          acc[i + 1][0] += a1[j] + b1[j];
+#else
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b0[j], acc[i], 0, 0, 0);
+          acc[i + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b1[j], acc[i + 1], 0, 0, 0);
+#endif
+        }
+      } else {
+        mfma(a0[2], a0[3], b0[0], b0[1], acc[i]);
+        mfma(a1[2], a1[3], b1[0], b1[1], acc[i + 1]);
+        mfma(a0[0], a0[1], b0[2], b0[3], acc[i]);
+        mfma(a1[0], a1[1], b1[2], b1[3], acc[i + 1]);
+        mfma(a0[0], a0[1], b0[0], b0[1], acc[i]);
+        mfma(a1[0], a1[1], b1[0], b1[1], acc[i + 1]);
+      }
       if (NA == 2 && i + 2 < 18) {
         read_A(i + 2);
         read_A(i + 3);
@@ -528,9 +561,20 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
 #pragma unroll
     for (int i = 0; i < 18; ++i) {
       __builtin_amdgcn_sched_barrier(0);
-      mf(xa[0][1], xb[i % 3][0], acc[i]);
-      mf(xa[0][0], xb[i % 3][1], acc[i]);
-      mf(xa[0][0], xb[i % 3][0], acc[i]);
+      if (F32) {  // eight k groups: xa / xb [0] = j 0..3, [1] = j 4..7
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#if F4_ABLATE & 1
+          acc[i][0] += xa[0][j >> 2][j & 3] + xb[i % 3][j >> 2][j & 3];
+#else
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0][j >> 2][j & 3], xb[i % 3][j >> 2][j & 3], acc[i], 0, 0, 0);
+#endif
+        }
+      } else {
+        mf(xa[0][1], xb[i % 3][0], acc[i]);
+        mf(xa[0][0], xb[i % 3][1], acc[i]);
+        mf(xa[0][0], xb[i % 3][0], acc[i]);
+      }
       if (i + 1 < 18) read_A(i + 1);   // (one register set: the next fragment is read once this position's MFMAs are issued -- 128 registers)
       if (i + 3 < 18) load_B32(chunk, i + 3);
       __builtin_amdgcn_sched_barrier(0);
@@ -887,9 +931,37 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
 // [pos = xi*6 + nu][cin_pad/16][cout_pad/16][lane 64][4 words: hi, hi, lo, lo]; a lane's 16 bytes are the hi and the lo halves of
 // U'[n = block*16 + (lane&15)][c = chunk*16 + (lane>>4)*4 + 0..3]  (v_mfma_f32_16x16x16_f16 B operand, hi | lo in one dwordx4).
 __global__ void pack_weight_wf43_kernel(const float* __restrict__ w, int cout, int cin, int cout_pad, int nchunks, float scale,
-                                        unsigned* __restrict__ packed, long total, int k32) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one 32-bit word = two halves
+                                        unsigned* __restrict__ packed, long total, int k32, int f32) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one 32-bit word = two halves (or one fp32 value)
   if (i >= total) return;
+  if (f32) {
+    // fp32 operands (v_mfma_f32_16x16x4_f32): word j of a lane's 16 (32) bytes = U'[n = block*16 + (lane&15)][c = chunk*KS + 4 j + (lane>>4)]
+    const int j = k32 ? (int)(i & 7) : (int)(i & 3), ln = k32 ? (int)((i >> 3) & 63) : (int)((i >> 2) & 63);
+    long r = k32 ? i >> 9 : i >> 8;
+    const int ntiles = cout_pad / 16;
+    const int nn = (int)(r % ntiles) * 16 + (ln & 15);
+    r /= ntiles;
+    const int chunk = (int)(r % nchunks), pos = (int)(r / nchunks);
+    const int c = chunk * (k32 ? 32 : CF_BK) + 4 * j + (ln >> 4);
+    const int xi = pos / 6, nu = pos % 6;
+    const double Gf[6][3] = {{4.0, 0.0, 0.0},           {-32.0 / 15.0, -16.0 / 15.0, -8.0 / 15.0}, {-32.0 / 15.0, 16.0 / 15.0, -8.0 / 15.0},
+                             {1.0 / 15.0, 2.0 / 15.0, 4.0 / 15.0}, {1.0 / 15.0, -2.0 / 15.0, 4.0 / 15.0},  {0.0, 0.0, 4.0}};
+    float val = 0.f;
+    if (nn < cout && c < cin) {
+      const float* g = w + ((long)nn * cin + c) * 9;
+      double u = 0.0;
+#pragma unroll
+      for (int y = 0; y < 3; ++y) {
+        double rowv = 0.0;
+#pragma unroll
+        for (int x = 0; x < 3; ++x) rowv += (double)g[y * 3 + x] * Gf[nu][x];
+        u += Gf[xi][y] * rowv;
+      }
+      val = (float)u;
+    }
+    packed[i] = __builtin_bit_cast(unsigned, val);
+    return;
+  }
   // 16-channel slabs: a lane's 16 bytes = [hi k0..3 | lo k0..3]; 32-channel slabs (k32): a lane's 32 bytes = [hi k0..7 | lo k0..7]
   const int e = k32 ? (int)(i & 3) : (int)(i & 1), part = k32 ? (int)((i >> 2) & 1) : (int)((i >> 1) & 1);
   const int ln = k32 ? (int)((i >> 3) & 63) : (int)((i >> 2) & 63);
@@ -929,6 +1001,15 @@ __global__ void pack_weight_wf43_kernel(const float* __restrict__ w, int cout, i
 
 }  // namespace
 
+// A/B switch (debug): CF_F43_K32=0 keeps the 16-wave form on 16-channel slabs (the one-interval loop) for every shape; packing and launch agree
+static bool f4_k32_enabled() {
+  static const int v = [] {
+    const char* e = getenv("CF_F43_K32");
+    return e ? atoi(e) : 1;
+  }();
+  return v != 0;
+}
+
 extern "C" int cf_pack_conv_weight_winograd43_f16x2(const float* w, int cout, int cin, int cout_pad, int cin_pad, float scale, void* packed,
                                                     cf_stream_t stream) {
   CF_REQUIRE(w && packed, "cf_pack_conv_weight_winograd43_f16x2: null pointer");
@@ -938,18 +1019,33 @@ extern "C" int cf_pack_conv_weight_winograd43_f16x2(const float* w, int cout, in
   CF_REQUIRE(scale > 0.f && frexpf(scale, &ex) == 0.5f, "cf_pack_conv_weight_winograd43_f16x2: scale %g is not a power of two", (double)scale);
   const long total = 36L * cin_pad * cout_pad;  // 32-bit words: hi + lo half per weight
   // the layout follows the form cf_conv2d will run (cf_wf43_form below): 32-channel slabs for the 16-wave form where cin allows
-  const int k32 = cout_pad % 128 == 0 && cin_pad % 32 == 0;
+  const int k32 = cout_pad % 128 == 0 && cin_pad % 32 == 0 && f4_k32_enabled();
   hipLaunchKernelGGL(pack_weight_wf43_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, cout, cin,
-                     cout_pad, cin_pad / (k32 ? 32 : CF_BK), scale, reinterpret_cast<unsigned*>(packed), total, k32);
+                     cout_pad, cin_pad / (k32 ? 32 : CF_BK), scale, reinterpret_cast<unsigned*>(packed), total, k32, 0);
   CF_CHECK_LAUNCH("cf_pack_conv_weight_winograd43_f16x2");
+  return CF_OK;
+}
+
+extern "C" int cf_pack_conv_weight_winograd43(const float* w, int cout, int cin, int cout_pad, int cin_pad, void* packed, cf_stream_t stream) {
+  CF_REQUIRE(w && packed, "cf_pack_conv_weight_winograd43: null pointer");
+  CF_REQUIRE(cin_pad % CF_BK == 0 && cin_pad >= cin && cout_pad >= cout && cout_pad % 64 == 0,
+             "cf_pack_conv_weight_winograd43: bad padding cin %d->%d cout %d->%d", cin, cin_pad, cout, cout_pad);
+  const long total = 36L * cin_pad * cout_pad;  // fp32 words
+  const int k32 = cout_pad % 128 == 0 && cin_pad % 32 == 0 && f4_k32_enabled();   // (the rule of the split-half packing: the form cf_conv2d will run)
+  hipLaunchKernelGGL(pack_weight_wf43_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, cout, cin,
+                     cout_pad, cin_pad / (k32 ? 32 : CF_BK), 1.f, reinterpret_cast<unsigned*>(packed), total, k32, 1);
+  CF_CHECK_LAUNCH("cf_pack_conv_weight_winograd43");
   return CF_OK;
 }
 
 // Called by cf_conv2d (cf_igemm.hip) for descriptors with winograd == 2; the common argument checks have run there.
 int cf_wf43_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query) {
-  CF_REQUIRE(d->taps == 9 && d->stride == 1 && !d->upsample && !d->in_nchw && !d->out_nchw && d->bf16_mfma == CF_OPERAND_F16X2,
-             "cf_conv2d(winograd 2): F(4x4,3x3) covers 3x3 stride-1 NHWC convolutions with split-half operands");
-  CF_REQUIRE(d->acc_scale > 0.f, "cf_conv2d(winograd 2): acc_scale must be the inverse of the pack-time weight scale (got %g)", (double)d->acc_scale);
+  CF_REQUIRE(d->taps == 9 && d->stride == 1 && !d->upsample && !d->in_nchw && !d->out_nchw &&
+                 (d->bf16_mfma == CF_OPERAND_F16X2 || d->bf16_mfma == CF_OPERAND_F32),
+             "cf_conv2d(winograd 2): F(4x4,3x3) covers 3x3 stride-1 NHWC convolutions with split-half or fp32 operands");
+  const bool f32 = d->bf16_mfma == CF_OPERAND_F32;
+  CF_REQUIRE(f32 || d->acc_scale > 0.f, "cf_conv2d(winograd 2): acc_scale must be the inverse of the pack-time weight scale (got %g)", (double)d->acc_scale);
+  CF_REQUIRE(!f32 || !d->act_scale, "cf_conv2d(winograd 2): fp32 operands take no activation range scale");
   CF_REQUIRE(d->hout % F4_TH == 0 && d->wout % F4_TW == 0, "cf_conv2d(winograd 2): needs an output of %dx%d multiples (got %dx%d)", F4_TH,
              F4_TW, d->hout, d->wout);
   CF_REQUIRE(d->cout % 64 == 0 && d->cout_pad == d->cout, "cf_conv2d(winograd 2): needs cout == cout_pad, a multiple of 64 (got %d / %d)",
@@ -985,7 +1081,7 @@ int cf_wf43_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query) 
   a.res = d->res;
   a.sft_scale = d->sft_scale;
   a.sft_w = d->sft_w;
-  a.acc_scale = d->acc_scale;
+  a.acc_scale = f32 ? 1.f : d->acc_scale;
   a.act_scale = d->act_scale;
   a.out = d->out;
   a.stats_out = d->stats_out;
@@ -994,8 +1090,8 @@ int cf_wf43_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query) 
   a.tiles_per_img = a.tiles_x * (d->hout / F4_TH);
   a.nparts = a.tiles_per_img;
   const bool wide = d->cout % 128 == 0;                      // 16 waves x 128 channels where the layer has them ...
-  const bool k32 = wide && (d->c0 + d->c1) % 32 == 0 && d->c0 % 32 == 0;   // ... on 32-channel slabs where the inputs allow (the weight layout of the pack function follows the same rule)
-  CF_REQUIRE(!wide || k32 || (d->c0 + d->c1) % 32 != 0, "cf_conv2d(winograd 2): a 128-channel layer with cin %% 32 == 0 needs c0 %% 32 == 0 (got %d + %d)", d->c0, d->c1);
+  const bool k32 = wide && (d->c0 + d->c1) % 32 == 0 && f4_k32_enabled();   // ... on 32-channel slabs where cin allows: the rule the pack functions lay the weight out by
+  CF_REQUIRE(!k32 || d->c0 % 32 == 0, "cf_conv2d(winograd 2): with cout %% 128 == 0 and cin %% 32 == 0 the concat boundary must be a multiple of 32 (c0 = %d)", d->c0);
   a.ntn = d->cout / (wide ? 128 : 64);
   if (parts_query) {
     *parts_query = a.nparts;
@@ -1004,14 +1100,19 @@ int cf_wf43_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query) 
   const size_t lds = (k32 ? F4_LDS_FLOATS_32 : wide ? F4_LDS_FLOATS_16 : F4_LDS_FLOATS) * sizeof(float) + (F4_TIMING && !wide && getenv("CF_F43_ONE_WG") ? 32768 : 0);   // (timing builds: one workgroup per CU)
   const dim3 grid(a.tiles_per_img * d->batch * a.ntn), block(wide ? 1024 : 512);
   // (cf_device_init sets the dynamic-LDS attribute of every instantiation on each device)
-#define F4_LAUNCH(P, E)                                                                                                       \
+#define F4_LAUNCH_OP(P, E, O)                                                                                                 \
   do {                                                                                                                        \
-    CF_LDS_ATTR((wf43_kernel<P, E, 8, 16>), F4_LDS_FLOATS * sizeof(float) + (F4_TIMING ? 32768 : 0));                         \
-    CF_LDS_ATTR((wf43_kernel<P, E, 16, 16>), F4_LDS_FLOATS_16 * sizeof(float));                                               \
-    CF_LDS_ATTR((wf43_kernel<P, E, 16, 32>), F4_LDS_FLOATS_32 * sizeof(float));                                               \
-    if (k32) hipLaunchKernelGGL((wf43_kernel<P, E, 16, 32>), grid, block, lds, stream, a);                                    \
-    else if (wide) hipLaunchKernelGGL((wf43_kernel<P, E, 16, 16>), grid, block, lds, stream, a);                              \
-    else hipLaunchKernelGGL((wf43_kernel<P, E, 8, 16>), grid, block, lds, stream, a);                                         \
+    CF_LDS_ATTR((wf43_kernel<P, E, 8, 16, O>), F4_LDS_FLOATS * sizeof(float) + (F4_TIMING ? 32768 : 0));                      \
+    CF_LDS_ATTR((wf43_kernel<P, E, 16, 16, O>), F4_LDS_FLOATS_16 * sizeof(float));                                            \
+    CF_LDS_ATTR((wf43_kernel<P, E, 16, 32, O>), F4_LDS_FLOATS_32 * sizeof(float));                                            \
+    if (k32) hipLaunchKernelGGL((wf43_kernel<P, E, 16, 32, O>), grid, block, lds, stream, a);                                 \
+    else if (wide) hipLaunchKernelGGL((wf43_kernel<P, E, 16, 16, O>), grid, block, lds, stream, a);                           \
+    else hipLaunchKernelGGL((wf43_kernel<P, E, 8, 16, O>), grid, block, lds, stream, a);                                      \
+  } while (0)
+#define F4_LAUNCH(P, E)                  \
+  do {                                   \
+    if (f32) F4_LAUNCH_OP(P, E, true);   \
+    else F4_LAUNCH_OP(P, E, false);      \
   } while (0)
 #define F4_LAUNCH_EPI(P)                                                           \
   do {                                                                             \
@@ -1027,6 +1128,7 @@ int cf_wf43_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query) 
   }
 #undef F4_LAUNCH_EPI
 #undef F4_LAUNCH
+#undef F4_LAUNCH_OP
   CF_CHECK_LAUNCH("cf_conv2d(winograd F(4,3) f16x2)");
   return CF_OK;
 }

@@ -69,6 +69,8 @@ WF16 = 8       # ... Winograd F(2x2,3x3) with SINGLE IEEE-half operands (eight-w
 WBF16 = 9      # ... the same with single bf16 operands (precision 'bf16')
 SPLIT_F43 = 10  # ... REQUEST: SPLIT, with Winograd F(4x4,3x3) where its kernel applies (generator / CFT layers only: ~5x the error of F(2,3))
 WF43 = 11      # ... Winograd F(4x4,3x3) with split-half operands (cf_wf43.hip; cf_conv_desc.winograd = 2)
+WINOGRAD_F43 = 12   # ... REQUEST: WINOGRAD (exact fp32), with Winograd F(4x4,3x3) on fp32 operands where its kernel applies (generator / CFT only)
+WF43F = 13     # ... Winograd F(4x4,3x3) with IEEE-fp32 operands (cf_wf43.hip on v_mfma_f32_16x16x4_f32; winograd = 2, operand fp32)
 OPERAND_F16X2 = 3   # enum cf_operand value behind SPLIT / WSPLIT / GSPLIT / WF43
 SPLIT_CODES = (SPLIT, SPLIT_DIRECT, SPLIT_F43)   # requested codes that put un-normalised inputs / stride-2 / 1x1 layers on the split-half kernels
 # SPLIT layers that the Winograd kernel covers take its split-half form (4/9 of the MFMA work); CODEFORMER_HIP_SPLIT_WINOGRAD=0
@@ -143,8 +145,13 @@ def conv_code(code, cin, cout, h, w, up2x=False, c_split=None, plain=True):
     SPLIT falls back to WINOGRAD and WINOGRAD to the direct fp32 kernel where their kernels do not apply; the decision depends
     on the per-image shape only (never on the batch), so results stay batch-invariant."""
     code = int(code)
+    f43_slab = 32 if (cout % 128 == 0 and cin % 32 == 0) else 16   # slab of the form cf_conv2d runs: a concat boundary must not cut one
+    if code == WINOGRAD_F43:
+        if plain and not up2x and c_split_ok(c_split, f43_slab) and f43_ok(cin, cout, h, w):
+            return WF43F
+        code = WINOGRAD
     if code == SPLIT_F43:
-        if plain and not up2x and c_split_ok(c_split, 16) and f43_ok(cin, cout, h, w):
+        if plain and not up2x and c_split_ok(c_split, f43_slab) and f43_ok(cin, cout, h, w):
             return WF43
         code = SPLIT
     if code in (SPLIT, SPLIT_DIRECT):
@@ -282,6 +289,13 @@ def pack_weight(weight, bias=None, bf16=False, up2x=False, f16=False, stride2=Fa
         L.check(lib.cf_pack_linear_weight_f16x2(L.ptr(w2.contiguous()), cout, cin, scale, L.ptr(packed, dtype=None), L.stream_ptr()),
                 'cf_pack_linear_weight_f16x2')
         return PackedWeight(packed, b, cout, cin, 1, cout, cin, bf16=OPERAND_F16X2, scale=scale)
+    if code == WF43F:
+        if up2x or w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or cin % 16 or cout % 64:
+            raise ValueError('winograd F(4,3) packing needs a 3x3 weight with cin % 16 == 0 and cout % 64 == 0 (no up2x)')
+        packed = torch.empty(36 * cin * cout, dtype=torch.float32, device=w.device)
+        L.check(lib.cf_pack_conv_weight_winograd43(L.ptr(w), cout, cin, cout, cin, L.ptr(packed, dtype=None), L.stream_ptr()),
+                'cf_pack_conv_weight_winograd43')
+        return PackedWeight(packed, b, cout, cin, 9, cout, cin, wino=2)
     if code == WF43:
         if up2x or w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or cin % 16 or cout % 64:
             raise ValueError('winograd F(4,3) f16x2 packing needs a 3x3 weight with cin % 16 == 0 and cout % 64 == 0 (no up2x)')
@@ -536,7 +550,7 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
     if pw.conv1:
         kind = 'conv1x1_stream_f16x2'   # 1x1 on images through the split-half convolution kernel (HBM-bound), not the token GEMM
     if pw.wino == 2:
-        kind = 'conv3x3_wino43_f16x2'   # F(4x4,3x3) on split halves (cf_wf43.hip)
+        kind = 'conv3x3_wino43_f16x2' if pw.bf16 else 'conv3x3_wino43'   # F(4x4,3x3) on split halves / on fp32 operands (cf_wf43.hip)
     elif pw.wino and pw.bf16 and pw.cout % 128 == 0 and Ho * Wo >= 1024 and not split_k:
         kind += '_8w'      # the eight-wave 128-channel kernel (cf_wsplit.hip; the rule of cf_wsplit_covers)
     PROFILE.append((kind, flops, nbytes, e0, e1, (B, H, W, cin, pw.cout)))

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 19
+#define CF_ABI_VERSION 20
 
 typedef void* cf_stream_t; /* hipStream_t */
 
@@ -164,7 +164,9 @@ typedef struct cf_conv_desc {
                              cin <= 256, an image of any of its tensors below 2^31 bytes; prologues / epilogues / statistics / act_scale as winograd 1, no split_k.  Its error
                              against fp64 is ~5x that of F(2x2,3x3) (the conditioning of the larger transform), far inside the
                              1e-3 pixel gate but too close for layers that decide code indices: the host uses it for generator /
-                             CFT convolutions only (vqgan_arch.py:296-323, codeformer_arch.py:136-157), never in the encoder */
+                             CFT convolutions only (vqgan_arch.py:296-323, codeformer_arch.py:136-157), never in the encoder.
+                             ABI v20: also with CF_OPERAND_F32 (`weight` from cf_pack_conv_weight_winograd43; acc_scale / act_scale
+                             unused, act_scale must be null): the same kernel with IEEE-fp32 operands on v_mfma_f32_16x16x4_f32 */
   float acc_scale;        /* CF_OPERAND_F16X2 only (direct or winograd): the accumulator is multiplied by this before the bias is added -- the exact
                              inverse of the power-of-two scale given to cf_pack_conv_weight_f16x2 (> 0) */
   /* Deterministic split-K for layers with few output tiles (one face: 16x16 .. 64x64 pixels), where latency is the serial K loop of
@@ -211,6 +213,10 @@ int cf_pack_conv_weight_winograd_f16x2(const float* w, int cout, int cin, int co
  * max|scale * U'| into [2^14, 2^15) (cf_conv_desc.acc_scale = 1 / scale) */
 int cf_pack_conv_weight_winograd43_f16x2(const float* w, int cout, int cin, int cout_pad, int cin_pad, float scale, void* packed,
                                          cf_stream_t stream);
+/* winograd == 2 + CF_OPERAND_F32 (ABI v20): U' in fp32, same tensor order with a lane's 16 (32) bytes = the four (eight) k groups
+ * c = slab * KS + 4 j + (lane >> 4) of output channel block * 16 + (lane & 15) (the 16x16x4 fp32 MFMA's B operand); KS = 32 when
+ * cout_pad % 128 == 0 and cin_pad % 32 == 0 (the form cf_conv2d runs for that shape), else 16.  36*cin_pad*cout_pad floats. */
+int cf_pack_conv_weight_winograd43(const float* w, int cout, int cin, int cout_pad, int cin_pad, void* packed, cf_stream_t stream);
 /* winograd + SINGLE 16-bit operands (cout % 128 == 0, at least 32x32 pixels per image: the eight-wave kernel of cf_wsplit.hip; the
  * network's 'fp16' / 'bf16' modes, BASELINE configs 3 and 5): one MFMA per transform-domain product.  CF_OPERAND_F16 reads the hi slot of
  * the split packing above as it is; CF_OPERAND_BF16 takes this buffer: bf16(scale * U) in the hi slot of the same layout, zeros in the

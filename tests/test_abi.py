@@ -33,7 +33,7 @@ def test_header_symbols_are_exported(native):
 
 
 def test_version_and_error_string(native):
-    assert native.cf_version() == lib.ABI_VERSION == 19
+    assert native.cf_version() == lib.ABI_VERSION == 20
     assert isinstance(lib.last_error(), str)
 
 
@@ -92,11 +92,14 @@ def test_argument_errors_are_reported_without_a_gpu(native):
     assert native.cf_act_scale_fused(None, 0, 1, 8, 1, 1024, 1, 4.0, 1, 1, None) == -1
     assert native.cf_act_scale_fused(None, 0, None, 0, 1, 1022, 1, 4.0, 1, 1, None) == -1 and 'multiple of 4' in lib.last_error()
     assert native.cf_act_scale_fused(1, 8, None, 0, None, 0, 1, 4.0, None, 1, None) == -1
-    # ABI v19: winograd == 2 (F(4x4,3x3), split-half operands only, 16x16 output patches, 64-wide channel tiles, cin <= 256) and its weight form
+    # ABI v19: winograd == 2 (F(4x4,3x3), 16x16 output patches, 64-wide channel tiles, cin <= 256) and its weight form; v20: split-half
+    # or fp32 operands (the latter without a range scale)
     d = lib.ConvDesc(in0=1, weight=1, out=1, taps=9, stride=1, batch=1, hin=32, win=32, hout=32, wout=32, c0=64, cout=64,
-                     cout_pad=64, bf16_mfma=0, acc_scale=1.0, winograd=2)
-    assert native.cf_conv2d(ctypes.byref(d), None) == -1 and 'split-half' in lib.last_error()
-    d.bf16_mfma, d.acc_scale = 3, 0.0
+                     cout_pad=64, bf16_mfma=1, acc_scale=1.0, winograd=2)
+    assert native.cf_conv2d(ctypes.byref(d), None) == -1 and 'split-half or fp32' in lib.last_error()
+    d.bf16_mfma, d.act_scale = 0, 1
+    assert native.cf_conv2d(ctypes.byref(d), None) == -1 and 'range scale' in lib.last_error()
+    d.bf16_mfma, d.act_scale, d.acc_scale = 3, None, 0.0
     assert native.cf_conv2d(ctypes.byref(d), None) == -1 and 'acc_scale' in lib.last_error()
     d.acc_scale, d.hout, d.hin = 1.0, 24, 24
     assert native.cf_conv2d(ctypes.byref(d), None) == -1 and '16x16' in lib.last_error()
@@ -108,6 +111,17 @@ def test_argument_errors_are_reported_without_a_gpu(native):
     assert native.cf_conv2d_stats_parts(ctypes.byref(d)) == 4        # one partial per 16x16 patch, four patches per 32x32 image
     assert native.cf_pack_conv_weight_winograd43_f16x2(1, 64, 64, 64, 64, 3.0, 1, None) == -1 and 'power of two' in lib.last_error()
     assert native.cf_pack_conv_weight_winograd43_f16x2(1, 64, 64, 96, 64, 2.0, 1, None) == -1 and 'padding' in lib.last_error()
+    assert native.cf_pack_conv_weight_winograd43(1, 64, 64, 96, 64, 1, None) == -1 and 'padding' in lib.last_error()
+
+
+def test_kernel_attribute_table_holds_every_instantiation(native):
+    """cf_device_init checks its table of (kernel, dynamic LDS bytes) entries before it touches the device: the count of kernel
+    instantiations that register themselves must fit (a GPU-less host fails later, at the first hipFuncSetAttribute)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('the table check is covered by every GPU test')
+    assert native.cf_device_init() != 0
+    assert 'overflow' not in lib.last_error(), lib.last_error()
 
 
 def test_missing_library_is_a_loud_error(monkeypatch, tmp_path):

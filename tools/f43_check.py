@@ -1,6 +1,7 @@
 """Winograd F(4x4,3x3) split-half kernel (cf_wf43.hip, cf_conv_desc.winograd = 2) against an fp64 reference, next to the F(2x2,3x3)
 split-half kernels (accuracy, GroupNorm partials, time).  GPU box only.
-usage: python tools/f43_check.py [check] [time] [big]      (default: check time)"""
+usage: python tools/f43_check.py [check] [time] [big] [fp32]      (default: check time; fp32: the IEEE-fp32-operand forms against the
+fp32 F(2x2,3x3) kernel instead of the split-half ones)"""
 import os
 import sys
 
@@ -71,11 +72,11 @@ def stats_err(y, B, H, W):
     return float(((got - want).abs() / want.abs().clamp_min(1e-6)).max())
 
 
-def case(B, H, W, cin, cout, timing=False, check=True, **kwargs):
+def case(B, H, W, cin, cout, timing=False, check=True, fp32=False, **kwargs):
     x1, x2, w, b, kw, want = make(B, H, W, cin, cout, ref=check, **kwargs)
-    pw4 = ops.pack_weight(w, b, bf16=ops.WF43)
-    pw2 = ops.pack_weight(w, b, bf16=ops.WSPLIT)
-    msg = f'B{B} {H}x{W} {cin}->{cout} pro{kw["prologue"]} epi{kw["epilogue"]}{" cat" if x2 is not None else ""}:'
+    pw4 = ops.pack_weight(w, b, bf16=ops.WF43F if fp32 else ops.WF43)
+    pw2 = ops.pack_weight(w, b, bf16=ops.WINOGRAD if fp32 else ops.WSPLIT)
+    msg = f'{"fp32 " if fp32 else ""}B{B} {H}x{W} {cin}->{cout} pro{kw["prologue"]} epi{kw["epilogue"]}{" cat" if x2 is not None else ""}:'
     ok = True
     if check:
         y4 = ops.conv2d(x1, pw4, x2=x2, **kw)
@@ -83,7 +84,8 @@ def case(B, H, W, cin, cout, timing=False, check=True, **kwargs):
         d4, d2 = (y4.cpu().double() - want).abs(), (y2.cpu().double() - want).abs()
         scale = float(want.abs().max())
         msg += f' F(4,3) max {float(d4.max()):.2e} mean {float(d4.mean()):.2e} | F(2,3) max {float(d2.max()):.2e} mean {float(d2.mean()):.2e} (ref max {scale:.3g})'
-        ok = float(d4.max()) <= 2e-5 * max(scale / 4.0, 1.0) and bool(torch.isfinite(y4).all())
+        # (fp32 operands: measured 1.1-2.8e-5 -- products rounded to 24 bits where the split-half sum of three carries ~32 -- bound 4e-5)
+        ok = float(d4.max()) <= (4e-5 if fp32 else 2e-5) * max(scale / 4.0, 1.0) and bool(torch.isfinite(y4).all())
         if kw['emit_stats']:
             e4 = stats_err(y4, B, H, W)
             msg += f' stats {e4:.1e}'
@@ -127,14 +129,16 @@ TIMED = [dict(B=16, H=512, W=512, cin=64, cout=64, prologue=ops.PRO_AFFINE_SWISH
 
 if __name__ == '__main__':
     modes = sys.argv[1:] or ['check', 'time']
-    good = True
+    if modes == ['fp32']:
+        modes += ['check', 'time']
+    good, f32 = True, 'fp32' in modes
     if 'check' in modes:
         for c in SMALL:
-            good &= case(**c)
+            good &= case(fp32=f32, **c)
     if 'big' in modes:      # accuracy at full size (fp64 reference on the host: slow)
         for c in TIMED[:1] + TIMED[3:4]:
-            good &= case(**dict(c, B=2))
+            good &= case(fp32=f32, **dict(c, B=2))
     if 'time' in modes:
         for c in TIMED:
-            case(timing=True, check=False, **c)
+            case(timing=True, check=False, fp32=f32, **c)
     sys.exit(0 if good else 1)

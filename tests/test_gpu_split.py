@@ -69,34 +69,6 @@ def test_split_conv_is_bitwise_repeatable_and_batch_invariant(sc):
         assert torch.equal(y[1:2], y1) and torch.equal(y._cf_stats.part.view(3, -1)[1:2], y1._cf_stats.part.view(1, -1))
 
 
-def test_winograd_f43_fp32_operands_against_fp64(sc):
-    """The same kernel with IEEE-fp32 operands (CF_OPERAND_F32 + winograd = 2, ABI v20: precision 'fp32' of the generator / fusion layers):
-    the same cases and batch invariance, bound 4e-5 * max(|ref| / 4, 1) (measured 1.1-2.8e-5); no weight / activation scale is involved
-    (act tables are ignored)."""
-    import importlib.util
-    import torch
-    from codeformer_amd import ops
-    spec = importlib.util.spec_from_file_location('f43_check', os.path.join(ROOT, 'tools', 'f43_check.py'))
-    fc = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(fc)
-    for c in fc.SMALL:
-        assert fc.case(fp32=True, **c), c
-    g = torch.Generator().manual_seed(4)
-    for cin, cout in ((64, 64), (128, 128), (48, 128)):
-        x = torch.randn(3, 32, 48, cin, generator=g).cuda()
-        pw = ops.pack_weight((torch.randn(cout, cin, 3, 3, generator=g) * 0.03).cuda(), torch.randn(cout, generator=g).cuda(), bf16=ops.WF43F)
-        assert pw.wino == 2 and not pw.bf16 and not ops.needs_act_scale(pw)
-        y = ops.conv2d(x, pw, emit_stats=True)
-        y1 = ops.conv2d(x[1:2].contiguous(), pw, emit_stats=True)
-        assert torch.equal(y[1:2], y1) and torch.equal(y._cf_stats.part.view(3, -1)[1:2], y1._cf_stats.part.view(1, -1))
-    # a single 16-channel slab (pipeline shorter than its depth) through the eight-wave kernel, against the exact Winograd kernel
-    xx = torch.randn(2, 32, 32, 16, generator=g).cuda()
-    w16 = (torch.randn(128, 16, 3, 3, generator=g) * 0.1).cuda()
-    yw = ops.conv2d(xx, ops.pack_weight(w16, b, bf16=ops.WSPLIT))
-    yf = ops.conv2d(xx, ops.pack_weight(w16, b, bf16=ops.WINOGRAD))
-    assert float((yw - yf).abs().max()) <= 1e-5
-
-
 def test_split_conv_refusals_and_overflow_is_loud(sc):
     import torch
     from codeformer_amd import ops

@@ -231,6 +231,10 @@ class CodeFormer(VQAutoEncoder):
         # there (split-half / IEEE-fp32 operands) -- 2.25 instead of 4 transform-domain products per output.  Its error against fp64 is ~5x that of F(2x2,3x3): far inside
         # the pixel tolerance, never used in the encoder.  False / CODEFORMER_HIP_F43=0: F(2x2,3x3) everywhere.
         self.winograd_f43 = ops.F43_LAYERS != '0'
+        # EXPERIMENT switch, off by default and not part of any shipped configuration: the same kernel for the encoder's covered layers (the
+        # 64-channel 512^2 and 128-channel 256^2 stages).  The encoder decides the code indices and F(4x4,3x3) carries ~5-8x the error of
+        # F(2x2,3x3); tools/f43_encoder_probe.py measures what that does to logits / indices (profiles/r04_f43_encoder_probe.txt).
+        self.winograd_f43_encoder = os.environ.get('CODEFORMER_HIP_F43_ENCODER', '0') == '1'
         # Also evaluate the ENCODER's 3x3 stride-1 convolutions with Winograd, in every precision mode (the encoder is always
         # fp32, so logits / indices stay bitwise identical across 'fp32' / 'bf16' / 'fp16').  Measured against the reference:
         # logits 4.3e-6 (direct kernel 5.5e-6), lq_feat 1.0e-5 (1.4e-5), indices exact on every seeded face incl. one whose
@@ -307,6 +311,8 @@ class CodeFormer(VQAutoEncoder):
         enc_code = ops.WINOGRAD if (self.winograd and self.winograd_encoder) else 0
         if self.encoder_precision == 'f16x2' or (self.encoder_precision == 'auto' and self.precision != 'fp32'):
             enc_code = ops.SPLIT if enc_code == ops.WINOGRAD else ops.SPLIT_DIRECT
+        if self.winograd_f43_encoder and self.winograd_f43:
+            enc_code = {ops.SPLIT: ops.SPLIT_F43, ops.WINOGRAD: ops.WINOGRAD_F43}.get(enc_code, enc_code)
         lq = self.encoder.forward_nhwc(x, enc_taps, bf16=enc_code)        # (B,16,16,256) channels-last
         T = lq.shape[1] * lq.shape[2]
         tokens = lq.view(B * T, lq.shape[3])
@@ -386,7 +392,7 @@ class CodeFormer(VQAutoEncoder):
     def _forward_graphed(self, x, w, code_only, adain):
         """Capture-once / replay-many execution of _forward_hip on the current stream.  Outputs are copies, so callers may
         keep them across calls.  A graph is re-captured when any packed weight was rebuilt since its capture."""
-        key = (tuple(x.shape), float(w), bool(code_only), bool(adain), self.precision, self.encoder_precision, self.gemm_precision, bool(self.winograd), bool(self.winograd_encoder), bool(self.winograd_f43), str(x.device), ops.switches())
+        key = (tuple(x.shape), float(w), bool(code_only), bool(adain), self.precision, self.encoder_precision, self.gemm_precision, bool(self.winograd), bool(self.winograd_encoder), bool(self.winograd_f43), bool(self.winograd_f43_encoder), str(x.device), ops.switches())
         ent = self._graphs.get(key)
         sig = self._param_signature()
         if ent is None or ent['epoch'] != PACK_EPOCH[0] or ent['sig'] != sig:

@@ -145,6 +145,14 @@ def test_f43_eligibility_rule(monkeypatch):
         assert ops.f43_ok(cin, cout, h, h) == want, (cin, cout, h)
         assert (ops.conv_code(ops.SPLIT_F43, cin, cout, h, h) == ops.WF43) == want
         assert ops.conv_code(ops.SPLIT, cin, cout, h, h) != ops.WF43
+        # the exact-fp32 request of precision='fp32' (generator / fusion only): the same rule, fp32 operands; a plain WINOGRAD request never gets it
+        assert (ops.conv_code(ops.WINOGRAD_F43, cin, cout, h, h) == ops.WF43F) == want
+        assert ops.conv_code(ops.WINOGRAD, cin, cout, h, h) != ops.WF43F
+        assert ops.conv_code(ops.WINOGRAD_F43, cin, cout, h, h, up2x=True) not in (ops.WF43, ops.WF43F)
+    # a concat boundary must not cut a slab of the form that runs: 32 channels where cout % 128 == 0 and cin % 32 == 0, else 16
+    assert ops.conv_code(ops.SPLIT_F43, 128, 128, 256, 256, c_split=64) == ops.WF43 and ops.conv_code(ops.SPLIT_F43, 128, 128, 256, 256, c_split=48) != ops.WF43
+    assert ops.conv_code(ops.SPLIT_F43, 128, 64, 256, 256, c_split=48) == ops.WF43 and ops.conv_code(ops.WINOGRAD_F43, 128, 64, 256, 256, c_split=40) == ops.WINOGRAD
+    assert ops.exact_code(ops.WINOGRAD_F43) == ops.WINOGRAD_F43 and not ops.needs_act_scale(ops.PackedWeight(None, None, 64, 64, 9, 64, 64, wino=2))
     monkeypatch.setattr(ops, 'F43_LAYERS', 'c64')
     assert ops.f43_ok(64, 64, 512, 512) and not ops.f43_ok(128, 128, 256, 256)
     monkeypatch.setattr(ops, 'F43_LAYERS', 'all')

@@ -100,21 +100,25 @@ def winograd_ok(cin, cout, hout, wout):
     return cin % 16 == 0 and cout % 64 == 0 and hout % 8 == 0 and wout % 16 == 0
 
 
-# Which layers a SPLIT_F43 request puts on the F(4x4,3x3) kernel: 'auto' (default) = the shapes where it measured faster than the
-# F(2x2,3x3) kernels at sixteen faces (profiles/r04_f43_per_shape.txt, tools/f43_check.py time): every covered layer with 64 output
-# channels (the 8-wave form, two workgroups per CU: x1.0-1.17) and the layers with a multiple of 128 output channels from 64x64 pixels up
-# (the 16-wave form on 32-channel slabs: x1.08-1.16; at 32x32 it loses, x0.6: 4 patches per image); 'c64' = the first group only;
-# 'all' = every covered shape; '0' = none (A/B).
+# Which layers a SPLIT_F43 / WINOGRAD_F43 request puts on the F(4x4,3x3) kernel: 'auto' (default) = the shapes where it pays
+# (profiles/r04_f43_per_shape.txt, r04_f43_fp32_check_time.txt, r04_latency_minpix.txt): every covered layer with 64 output channels (the
+# 8-wave form, two workgroups per CU: x1.0-1.17 at sixteen faces) and the layers with a multiple of 128 output channels (the 16-wave form)
+# from F43_WIDE_MIN_PIXELS up.  Split-half operands: 128x128 -- at 64x64 the form wins x1.11 at sixteen faces (0.15 ms of a 36 ms step) but a
+# 64x64 image has 16 patches, and at one face per call its 9 launches cost 0.5 ms of 7.1 (140 -> 150 faces/s with the limit at 128x128);
+# fp32 operands: 64x64 (x1.75 there: the fp32 MFMA work itself is the bound).  At 32x32 it loses at any batch (x0.6: 4 patches per image).
+# 'c64' = the 64-channel group only; 'all' = every covered shape; '0' = none (A/B).  The rule is a function of the per-image shape only:
+# results do not depend on the batch.
 F43_LAYERS = os.environ.get('CODEFORMER_HIP_F43', 'auto')
-F43_WIDE_MIN_PIXELS = int(os.environ.get('CODEFORMER_HIP_F43_MINPIX', 64 * 64))   # smallest image of the 16-wave form under 'auto'
+F43_WIDE_MIN_PIXELS = int(os.environ.get('CODEFORMER_HIP_F43_MINPIX', 128 * 128))        # smallest image of the 16-wave form under 'auto', split-half operands
+F43_WIDE_MIN_PIXELS_FP32 = int(os.environ.get('CODEFORMER_HIP_F43_MINPIX_FP32', 64 * 64))  # ... fp32 operands
 
 
-def f43_ok(cin, cout, hout, wout):
+def f43_ok(cin, cout, hout, wout, fp32=False):
     """Shapes the F(4x4,3x3) kernel covers (3x3 stride-1 dense NHWC): whole 16x16 output patches, 64-wide channel tiles, at most 256
-    input channels (the GroupNorm rows of an image sit in LDS) -- narrowed by F43_LAYERS to where it pays."""
+    input channels (the GroupNorm rows of an image sit in LDS) -- narrowed by F43_LAYERS to where it pays (fp32: the operand type)."""
     if F43_LAYERS == '0' or (F43_LAYERS == 'c64' and cout != 64):
         return False
-    if F43_LAYERS == 'auto' and cout != 64 and (cout % 128 or hout * wout < F43_WIDE_MIN_PIXELS):
+    if F43_LAYERS == 'auto' and cout != 64 and (cout % 128 or hout * wout < (F43_WIDE_MIN_PIXELS_FP32 if fp32 else F43_WIDE_MIN_PIXELS)):
         return False
     return cin % 16 == 0 and cin <= 256 and cout % 64 == 0 and hout % 16 == 0 and wout % 16 == 0
 
@@ -147,7 +151,7 @@ def conv_code(code, cin, cout, h, w, up2x=False, c_split=None, plain=True):
     code = int(code)
     f43_slab = 32 if (cout % 128 == 0 and cin % 32 == 0) else 16   # slab of the form cf_conv2d runs: a concat boundary must not cut one
     if code == WINOGRAD_F43:
-        if plain and not up2x and c_split_ok(c_split, f43_slab) and f43_ok(cin, cout, h, w):
+        if plain and not up2x and c_split_ok(c_split, f43_slab) and f43_ok(cin, cout, h, w, fp32=True):
             return WF43F
         code = WINOGRAD
     if code == SPLIT_F43:
@@ -182,7 +186,7 @@ HALF_LIMIT = 65504.0 / 4.0    # largest |activation| a Winograd-domain IEEE-half
 
 def switches():
     """The module-level A/B switches a captured forward depends on (part of the graph-replay key of the arch modules)."""
-    return (SPLIT_WINOGRAD, F43_LAYERS, WINOGRAD_16BIT, RANGE_SCALE, ACT_FUSED, SPLITK_MAX)
+    return (SPLIT_WINOGRAD, F43_LAYERS, F43_WIDE_MIN_PIXELS, F43_WIDE_MIN_PIXELS_FP32, WINOGRAD_16BIT, RANGE_SCALE, ACT_FUSED, SPLITK_MAX)
 
 
 def needs_act_scale(pw):

@@ -135,12 +135,12 @@ def test_winograd_eligibility_rule():
 def test_f43_eligibility_rule(monkeypatch):
     """Which generator / fusion layers a SPLIT_F43 request puts on the F(4x4,3x3) kernel (ops.f43_ok): a pure function of the layer
     shape -- whole 16x16 patches, cin % 16 == 0 and <= 256, cout % 64 == 0 -- narrowed by CODEFORMER_HIP_F43 ('auto': 64 output channels,
-    or a multiple of 128 from 64x64 pixels up; 'c64'; 'all'; '0'); conv_code falls back to the F(2x2,3x3) split-half kernel elsewhere
+    or a multiple of 128 from 128x128 pixels up (fp32 operands: 64x64); 'c64'; 'all'; '0'); conv_code falls back to the F(2x2,3x3) split-half kernel elsewhere
     and never returns WF43 for a plain SPLIT request (the encoder)."""
     from codeformer_amd import ops
     monkeypatch.setattr(ops, 'F43_LAYERS', 'auto')
     for cin, cout, h, want in ((64, 64, 512, True), (128, 64, 512, True), (128, 128, 256, True), (256, 128, 256, True), (128, 128, 128, True),
-                               (256, 256, 64, True), (256, 256, 32, False), (512, 256, 128, False), (64, 128, 24, False), (128, 192, 256, False),
+                               (256, 256, 128, True), (256, 256, 32, False), (512, 256, 128, False), (64, 128, 24, False), (128, 192, 256, False),
                                (48, 64, 32, True), (40, 64, 32, False)):
         assert ops.f43_ok(cin, cout, h, h) == want, (cin, cout, h)
         assert (ops.conv_code(ops.SPLIT_F43, cin, cout, h, h) == ops.WF43) == want
@@ -149,6 +149,9 @@ def test_f43_eligibility_rule(monkeypatch):
         assert (ops.conv_code(ops.WINOGRAD_F43, cin, cout, h, h) == ops.WF43F) == want
         assert ops.conv_code(ops.WINOGRAD, cin, cout, h, h) != ops.WF43F
         assert ops.conv_code(ops.WINOGRAD_F43, cin, cout, h, h, up2x=True) not in (ops.WF43, ops.WF43F)
+    # 64x64 images: the 16-wave form only with fp32 operands (split halves: from 128x128 up -- one-face latency)
+    assert not ops.f43_ok(256, 256, 64, 64) and ops.f43_ok(256, 256, 64, 64, fp32=True) and ops.f43_ok(256, 64, 64, 64)
+    assert ops.conv_code(ops.SPLIT_F43, 256, 256, 64, 64) == ops.WSPLIT and ops.conv_code(ops.WINOGRAD_F43, 256, 256, 64, 64) == ops.WF43F
     # a concat boundary must not cut a slab of the form that runs: 32 channels where cout % 128 == 0 and cin % 32 == 0, else 16
     assert ops.conv_code(ops.SPLIT_F43, 128, 128, 256, 256, c_split=64) == ops.WF43 and ops.conv_code(ops.SPLIT_F43, 128, 128, 256, 256, c_split=48) != ops.WF43
     assert ops.conv_code(ops.SPLIT_F43, 128, 64, 256, 256, c_split=48) == ops.WF43 and ops.conv_code(ops.WINOGRAD_F43, 128, 64, 256, 256, c_split=40) == ops.WINOGRAD

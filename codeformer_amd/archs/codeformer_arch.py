@@ -13,6 +13,7 @@ codeformer_amd/csrc with channels-last activations:
   -> generator with the controllable feature transform fused into conv gathers / epilogues.
 """
 import os
+import threading
 
 import math
 
@@ -25,6 +26,11 @@ from ..ops import EPI_GELU, EPI_RESIDUAL, EPI_SFT, PRO_LEAKY
 from ..utils.registry import ARCH_REGISTRY
 from .hip_module import PACK_EPOCH, HipModule
 from .vqgan_arch import ResBlock, VQAutoEncoder
+
+
+# Graphed forwards share static input / output buffers per captured shape, so capture and replay are serialised (one lock for the
+# process: module attributes must stay picklable / deep-copyable).  The eager path (more than `graph_max_batch` faces) is re-entrant.
+_GRAPH_LOCK = threading.RLock()
 
 
 def calc_mean_std(feat, eps=1e-5):
@@ -229,12 +235,18 @@ class CodeFormer(VQAutoEncoder):
         self.winograd = os.environ.get('CODEFORMER_HIP_WINOGRAD', '1') != '0'
         # precision 'f16x2' and 'fp32': generator / CFT layers the F(4x4,3x3) kernel covers (ops.f43_ok; which shapes: CODEFORMER_HIP_F43) run
         # there (split-half / IEEE-fp32 operands) -- 2.25 instead of 4 transform-domain products per output.  Its error against fp64 is ~5x that of F(2x2,3x3): far inside
-        # the pixel tolerance, never used in the encoder.  False / CODEFORMER_HIP_F43=0: F(2x2,3x3) everywhere.
+        # the pixel tolerance; the encoder's use of it has its own switch and gate (next attribute).  False / CODEFORMER_HIP_F43=0: F(2x2,3x3) everywhere.
         self.winograd_f43 = ops.F43_LAYERS != '0'
-        # EXPERIMENT switch, off by default and not part of any shipped configuration: the same kernel for the encoder's covered layers (the
-        # 64-channel 512^2 and 128-channel 256^2 stages).  The encoder decides the code indices and F(4x4,3x3) carries ~5-8x the error of
-        # F(2x2,3x3); tools/f43_encoder_probe.py measures what that does to logits / indices (profiles/r04_f43_encoder_probe.txt).
-        self.winograd_f43_encoder = os.environ.get('CODEFORMER_HIP_F43_ENCODER', '0') == '1'
+        # The same kernel for the ENCODER's covered layers (the 64-channel 512^2, 128-channel 256^2 / 128^2 stages and, for fp32 operands, the
+        # 256-channel 64^2 stage): on by default since round 5 (CODEFORMER_HIP_F43_ENCODER=0 / False: F(2x2,3x3) there, the round-2..4 encoder).
+        # The encoder decides the code indices and F(4x4,3x3) carries ~5x the per-layer error of F(2x2,3x3), so the switch was admitted on
+        # a measured margin, not on "no index changed": for every golden token whose reference top-2 gap is >= 1e-5 the ratio
+        # (reference gap) / (2 x max |our logit - reference logit|) must stay >= 5 (review of round 4) -- measured 7.0 (split halves) /
+        # 7.3 (fp32 operands) with the switch on against 9.9 / 8.7 with it off, over the seeded face, the three real crops, the masked face,
+        # the four range variants and the 32-face sweep; no index differs anywhere; logits move by 5-11e-6 (tolerance 1e-4).  It buys 4 % of
+        # the step in the default mode and 9 % in 'fp32'.  Gate: tests/test_gpu_real_images.py::test_encoder_logit_margin (tools/logit_margin.py,
+        # profiles/r05_logit_margin.txt).
+        self.winograd_f43_encoder = os.environ.get('CODEFORMER_HIP_F43_ENCODER', '1') == '1'
         # Also evaluate the ENCODER's 3x3 stride-1 convolutions with Winograd, in every precision mode (the encoder is always
         # fp32, so logits / indices stay bitwise identical across 'fp32' / 'bf16' / 'fp16').  Measured against the reference:
         # logits 4.3e-6 (direct kernel 5.5e-6), lq_feat 1.0e-5 (1.4e-5), indices exact on every seeded face incl. one whose
@@ -347,7 +359,7 @@ class CodeFormer(VQAutoEncoder):
         if bf16 == ops.WINOGRAD and self.winograd_f43:
             bf16 = ops.WINOGRAD_F43   # the same layers on fp32 operands (four v_mfma_f32_16x16x4_f32 per 16 channels instead of three f16 MFMAs)
         if bf16 == ops.SPLIT and self.winograd_f43:
-            bf16 = ops.SPLIT_F43   # generator + CFT only (this code never reaches the encoder, which decides the indices)
+            bf16 = ops.SPLIT_F43   # (the encoder gets this code through winograd_f43_encoder only, above)
         gen_taps = None
         if w > 0:
             def fuse(t):
@@ -392,55 +404,81 @@ class CodeFormer(VQAutoEncoder):
     def _forward_graphed(self, x, w, code_only, adain):
         """Capture-once / replay-many execution of _forward_hip on the current stream.  Outputs are copies, so callers may
         keep them across calls.  A graph is re-captured when any packed weight was rebuilt since its capture."""
-        key = (tuple(x.shape), float(w), bool(code_only), bool(adain), self.precision, self.encoder_precision, self.gemm_precision, bool(self.winograd), bool(self.winograd_encoder), bool(self.winograd_f43), bool(self.winograd_f43_encoder), str(x.device), ops.switches())
-        ent = self._graphs.get(key)
-        sig = self._param_signature()
-        if ent is None or ent['epoch'] != PACK_EPOCH[0] or ent['sig'] != sig:
-            static_x = x.float().contiguous().clone()
-            for _ in range(2):                      # warm-up: packs weights, sets kernel attributes, primes the allocator
-                self._forward_hip(static_x, w, code_only, adain)
-            torch.cuda.synchronize(x.device)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                outs = self._forward_hip(static_x, w, code_only, adain)
-            ent = {'graph': graph, 'x': static_x, 'outs': outs, 'epoch': PACK_EPOCH[0], 'sig': sig, 'idx': getattr(self, 'last_indices', None)}
-            self._graphs.pop(key, None)
-            while len(self._graphs) >= 4:           # oldest first: a graph pins the activations of its shape
-                self._graphs.pop(next(iter(self._graphs)))
-            self._graphs[key] = ent
-        ent['x'].copy_(x)
-        ent['graph'].replay()
-        if ent['idx'] is not None:
-            self.last_indices = ent['idx']
-        return tuple(o.clone() for o in ent['outs'])
+        with _GRAPH_LOCK:   # static buffers per shape: two threads replaying one graph would race on them
+            key = (tuple(x.shape), float(w), bool(code_only), bool(adain), self.precision, self.encoder_precision, self.gemm_precision, bool(self.winograd), bool(self.winograd_encoder), bool(self.winograd_f43), bool(self.winograd_f43_encoder), str(x.device), ops.switches())
+            ent = self._graphs.get(key)
+            sig = self._param_signature()
+            if ent is None or ent['epoch'] != PACK_EPOCH[0] or ent['sig'] != sig:
+                static_x = x.float().contiguous().clone()
+                for _ in range(2):                      # warm-up: packs weights, sets kernel attributes, primes the allocator
+                    self._forward_hip(static_x, w, code_only, adain)
+                torch.cuda.synchronize(x.device)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    outs = self._forward_hip(static_x, w, code_only, adain)
+                ent = {'graph': graph, 'x': static_x, 'outs': outs, 'epoch': PACK_EPOCH[0], 'sig': sig, 'idx': getattr(self, 'last_indices', None)}
+                self._graphs.pop(key, None)
+                while len(self._graphs) >= 4:           # oldest first: a graph pins the activations of its shape
+                    self._graphs.pop(next(iter(self._graphs)))
+                self._graphs[key] = ent
+            ent['x'].copy_(x)
+            ent['graph'].replay()
+            if ent['idx'] is not None:
+                self.last_indices = ent['idx'].clone()   # (a fresh tensor per call, as the eager path returns: the next replay overwrites the graph's own)
+            return tuple(o.clone() for o in ent['outs'])
 
     def _param_signature(self):
-        """(sum of versions, sum of storage addresses) over the parameters and buffers: changes with every versioned in-place update and
-        every re-allocation; the tensor list is cached (rebuilt by load_state_dict / _apply / invalidate_packed_weights)."""
-        ts = self.__dict__.get('_sig_tensors')
-        if ts is None:
-            ts = self.__dict__['_sig_tensors'] = list(self.parameters()) + list(self.buffers())
-        return (sum(t._version for t in ts), sum(t.data_ptr() for t in ts))
+        """(sum of versions, sum of storage addresses, sum of object ids) over the parameters and buffers CURRENTLY registered in the
+        module tree: changes with every versioned in-place update, every re-allocation and every replaced Parameter object
+        (`m.weight = nn.Parameter(...)`, parametrize, an EMA swap).  The list of modules is cached (rebuilt by load_state_dict / _apply /
+        invalidate_packed_weights, and here when a sub-module was replaced: the ids of all children are part of the walk); their
+        `_parameters` / `_buffers` dictionaries are read on every call (~0.15 ms)."""
+        for _ in range(2):
+            mods = self.__dict__.get('_sig_modules')
+            if mods is None:
+                mods = list(self.modules())
+                self.__dict__['_sig_modules'] = mods
+                self.__dict__['_sig_children'] = sum(id(c) for m in mods for c in m._modules.values() if c is not None)
+            ver = ptr = ident = kids = 0
+            for m in mods:
+                for t in m._parameters.values():
+                    if t is not None:
+                        ver += ops.tensor_version(t) or 0
+                        ptr += t.data_ptr()
+                        ident += id(t)
+                for t in m._buffers.values():
+                    if t is not None:
+                        ver += ops.tensor_version(t) or 0
+                        ptr += t.data_ptr()
+                        ident += id(t)
+                for c in m._modules.values():
+                    if c is not None:
+                        kids += id(c)
+            if kids == self.__dict__['_sig_children']:
+                break
+            self.__dict__.pop('_sig_modules', None)   # a sub-module was replaced or added: walk the new tree
+        return (ver, ptr, ident)
 
     def load_state_dict(self, *args, **kwargs):
         self._graphs.clear()                       # captured graphs point at the old packed weights
-        self.__dict__.pop('_sig_tensors', None)
+        self.__dict__.pop('_sig_modules', None)
         return super().load_state_dict(*args, **kwargs)
 
     def _apply(self, fn, *args, **kwargs):         # .to() / .cuda() / .float(): parameters move, graphs are stale
         if getattr(self, '_graphs', None):
             self._graphs.clear()
-        self.__dict__.pop('_sig_tensors', None)
+        self.__dict__.pop('_sig_modules', None)
         return super()._apply(fn, *args, **kwargs)
 
     def invalidate_packed_weights(self):
         self._graphs.clear()
-        self.__dict__.pop('_sig_tensors', None)
+        self.__dict__.pop('_sig_modules', None)
         super().invalidate_packed_weights()
 
     def forward(self, x, w=0, detach_16=True, code_only=False, adain=False):
         if x.is_cuda:
-            with torch.no_grad():
+            ops.L.ensure_device(x.device)   # kernel attributes on the tensor's device, before (never inside) a capture
+            with torch.no_grad(), torch.cuda.device(x.device):
                 graphed = self.use_hip_graphs is True or (self.use_hip_graphs == 'auto' and x.shape[0] <= self.graph_max_batch)
                 if graphed and ops.PROFILE is None and not torch.cuda.is_current_stream_capturing():
                     return self._forward_graphed(x, w, code_only, adain)

@@ -21,7 +21,7 @@ class HipModule(nn.Module):
 
     def _packed(self, key, build, *params):
         """Cache a packed weight until one of its source parameters is modified, replaced or moved."""
-        sig = tuple((p.data_ptr(), p._version, str(p.device)) for p in params if p is not None)
+        sig = tuple((p.data_ptr(), ops.tensor_version(p), str(p.device)) for p in params if p is not None)
         cache = self.__dict__.setdefault('_hip_cache', {})
         ent = cache.get(key)
         if ent is None or ent[0] != sig:
@@ -74,6 +74,7 @@ class HipModule(nn.Module):
 
     def forward(self, x):
         if x.is_cuda:
-            with torch.no_grad():
+            ops.L.ensure_device(x.device)   # kernel attributes on the tensor's device, outside any capture
+            with torch.no_grad(), torch.cuda.device(x.device):
                 return ops.to_nchw(self.forward_nhwc(ops.to_nhwc(x.float())))
         return self.forward_host(x)

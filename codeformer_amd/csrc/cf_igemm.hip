@@ -178,9 +178,8 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Arg
     b = mt / a.tiles_per_img;
     int r = mt - b * a.tiles_per_img;
     if (TAPS == 4) {
-      const int src_tiles = a.tiles_per_img >> 2;
-      const int cls = r / src_tiles;
-      r -= cls * src_tiles;
+      const int cls = r & 3;  // class-minor: the four parity classes of a source tile run side by side on one XCD and share its halo patch in L2 (cf_split.hip)
+      r >>= 2;
       sub_y = cls >> 1;
       sub_x = cls & 1;
     }

@@ -123,8 +123,37 @@ def load():
     if _cuda:
         dev = torch.cuda.current_device()
         if dev not in _devices:   # per-device kernel attributes (dynamic LDS above 64 KB), once per device and process
-            check(lib.cf_device_init(), 'cf_device_init')
-            _devices.add(dev)
+            _init_device(lib, dev)
+    return lib
+
+
+def _init_device(lib, dev):
+    if torch.cuda.is_current_stream_capturing():
+        # hipFuncSetAttribute must not be issued inside a stream capture: the arch modules call ensure_device() before they capture;
+        # a user capture that is the FIRST use of a device has to do the same
+        raise NativeLibraryError(f'cf_device_init has not run on cuda:{dev} yet and the current stream is capturing: call '
+                                 'codeformer_amd.lib.ensure_device(device) (or run one forward) before the capture')
+    if lib.cf_device_init() != 0:
+        raise NativeLibraryError(f'cf_device_init failed on cuda:{dev} ({torch.cuda.get_device_name(dev)}): '
+                                 f'{lib.cf_last_error().decode("utf-8", "replace")}')
+    _devices.add(dev)
+
+
+def ensure_device(device):
+    """Run cf_device_init() for `device` (torch.device / str / index) under that device's context.  The arch modules call this with the
+    INPUT tensor's device at the top of every forward, so the per-device kernel attributes are set on the device the kernels will run
+    on (not on whatever device happens to be current) and never inside a stream capture."""
+    global _cuda
+    lib = _lib if _lib is not None else _open()
+    if _cuda is None:
+        _cuda = torch.cuda.is_available()
+    if not _cuda:
+        return lib
+    d = torch.device(device) if not isinstance(device, int) else torch.device('cuda', device)
+    idx = torch.cuda.current_device() if d.index is None else d.index
+    if idx not in _devices:
+        with torch.cuda.device(idx):
+            _init_device(lib, idx)
     return lib
 
 

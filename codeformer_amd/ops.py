@@ -210,15 +210,22 @@ def _act_cells(device, batch):
     return t
 
 
+def tensor_version(t):
+    """Version counter of a tensor, or None for inference tensors (torch.inference_mode), which do not track one -- reading
+    `._version` there raises.  Callers skip their version-keyed caches for None."""
+    return None if t.is_inference() else t._version
+
+
 def act_scale(x, x2=None, growth=4.0):
     """(B, 2) float32 table (s_b, 1 / s_b): power-of-two scale that puts growth * max|x_b| into [2^13, 2^14) -- from the statistics
     partials the producing conv wrote (no pass over x; the bound is loose by a few bits, which is harmless) or, for tensors without
     them, from x itself; one launch (cf_act_scale_fused).  x2: the second half of a concatenated input -- the table then covers both.
     Cached on the tensor under (growth, tensor version): one table serves every conv that reads the tensor, and an in-place write
     (out= reuse, a user-held buffer) or another growth factor gets a fresh table; pairs are not cached."""
-    if x2 is None:
+    ver = tensor_version(x)   # None under torch.inference_mode(): no version to key the cache on, every call computes its table
+    if x2 is None and ver is not None:
         cached = getattr(x, '_cf_act', None)
-        if cached is not None and cached[0] == (float(growth), x._version):
+        if cached is not None and cached[0] == (float(growth), ver):
             return cached[1]
     lib = L.load()
     B = x.shape[0]
@@ -237,7 +244,8 @@ def act_scale(x, x2=None, growth=4.0):
             L.check(lib.cf_act_scale_from_stats(L.ptr(st.part, dtype=torch.float64), B, st.part.numel() // (2 * B), float(growth), L.ptr(scratch), L.ptr(act), L.stream_ptr()), 'cf_act_scale_from_stats')
         else:
             L.check(lib.cf_act_scale_from_tensor(L.ptr(_f32(x)), B, x.numel() // B, float(growth), L.ptr(scratch), L.ptr(act), L.stream_ptr()), 'cf_act_scale_from_tensor')
-        x._cf_act = ((float(growth), x._version), act)
+        if ver is not None:
+            x._cf_act = ((float(growth), ver), act)
         return act
     if st is not None:
         nper = st.part.numel() // (2 * B)
@@ -249,8 +257,8 @@ def act_scale(x, x2=None, growth=4.0):
             raise ValueError('act_scale: expected a dense tensor with a multiple of 4 elements per image')
         L.check(lib.cf_act_scale_fused(None, 0, None, 0, L.ptr(_f32(x)), x.numel() // B, B, float(growth), cells, L.ptr(act), L.stream_ptr()),
                 'cf_act_scale_fused')
-    if x2 is None:
-        x._cf_act = ((float(growth), x._version), act)
+    if x2 is None and ver is not None:
+        x._cf_act = ((float(growth), ver), act)
     return act
 
 

@@ -130,3 +130,22 @@ def range_variant(sd, kind, seed=4321, calib=None):
                     out[k] = v + 0.3 * torch.randn(v.shape, generator=g)
         return out
     raise ValueError(kind)
+
+
+def sweep32_inputs(golden_dir):
+    """The 32 faces of the round-5 logit sweep (tests/golden/logit_sweep32.npz), rebuilt from fixtures that are already committed:
+    the reference's three real crops (uint8 inputs stored in tests/golden/real_*.npz) under eight EXACT transforms each (flips, a
+    quarter turn, a cyclic shift, negation, channel reversal, halving and flip + negation: bit-exact on every device) plus eight
+    seeded uniform-noise faces.  Natural-image statistics with 24 different token layouts, without new image fixtures.
+    Returns a (32, 3, 512, 512) float32 CPU tensor."""
+    import os
+
+    import numpy as np
+    faces = []
+    for name in ('real_0143.npz', 'real_0342.npz', 'real_Solvay_conference_1927_0018.npz'):
+        img = np.load(os.path.join(golden_dir, name))['img']                      # uint8 HWC BGR, as cv2.imread returns it
+        t = torch.from_numpy(np.ascontiguousarray(img[:, :, ::-1].transpose(2, 0, 1))).float() / 255.   # img2tensor(img / 255., bgr2rgb=True)
+        t = (t - 0.5) / 0.5
+        faces += [t.flip(2), t.flip(1), t.rot90(1, (1, 2)), t.roll((37, 101), (1, 2)), -t, t.flip(0), t * 0.5, -t.flip(2)]
+    faces = [f.contiguous() for f in faces] + list(seeded_input(8, seed=777))
+    return torch.stack(faces)

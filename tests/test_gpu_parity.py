@@ -257,6 +257,42 @@ def test_hip_graph_replay_is_bitwise_eager(chk):
     assert float((net(y, w=0.5, adain=True)[0] - eager_y[0] - 1.0).abs().max()) < 1e-5
 
 
+def test_forward_under_inference_mode_and_replaced_parameters(chk):
+    """Advisor items of round 4: (a) torch.inference_mode() -- inference tensors carry no version counter, the range-scale cache must
+    not read one; bits equal to the no_grad call, eager and graphed.  (b) A REPLACED Parameter object (`m.bias = nn.Parameter(...)`: not
+    an in-place update, not load_state_dict) must reach a default-on graph replay.  (c) `last_indices` of a replay is a fresh tensor."""
+    import torch
+    from oracle.synth import seeded_input
+    net = chk.build_net().cuda()
+    x = seeded_input(2).cuda()
+    for graphs in (False, 'auto'):
+        net.use_hip_graphs = graphs
+        ref = [t.clone() for t in net(x, w=0.5, adain=True)]
+        with torch.inference_mode():
+            got = net(x, w=0.5, adain=True)
+            got2 = net(x.clone(), w=0.5, adain=True)     # an inference-tensor input as well
+        assert all(torch.equal(a, b) for a, b in zip(got, ref)) and all(torch.equal(a, b) for a, b in zip(got2, ref))
+    net.use_hip_graphs = 'auto'
+    a = net(x, w=0.5, adain=True)[0].clone()
+    idx_a = net.last_indices
+    y = seeded_input(2, seed=5).cuda()
+    net(y, w=0.5, adain=True)
+    assert net.last_indices is not idx_a and idx_a.data_ptr() != net.last_indices.data_ptr()
+    net.use_hip_graphs = False
+    net(x, w=0.5, adain=True)
+    assert torch.equal(net.last_indices, idx_a)           # the earlier call's indices were not overwritten by the later replay
+    net.use_hip_graphs = 'auto'
+    old = net.generator.blocks[24].bias
+    net.generator.blocks[24].bias = torch.nn.Parameter(old.detach() + 0.5, requires_grad=False)   # a new object, version 0
+    b = net(x, w=0.5, adain=True)[0]
+    assert float((b - a - 0.5).abs().max()) < 1e-5
+    from codeformer_amd.archs.vqgan_arch import _Conv3x3
+    net.generator.blocks[24] = _Conv3x3(64, 3).cuda().requires_grad_(False)                      # a replaced sub-module
+    c = net(x, w=0.5, adain=True)[0]
+    net.use_hip_graphs = False
+    assert torch.equal(c, net(x, w=0.5, adain=True)[0])
+
+
 def test_code_only_and_vqautoencoder_module_api(chk):
     """Other callers of the boundary: code_only=True (training stage II) and VQAutoEncoder.forward (scripts/inference_vqgan.py)."""
     import torch

@@ -19,6 +19,8 @@ pytestmark = pytest.mark.gpu
 
 REAL = ('real_0143.npz', 'real_0342.npz', 'real_Solvay_conference_1927_0018.npz')
 # precision modes of CodeFormer.precision and their pixel gates against the fp32 reference: (max |d|, mean |d|)
+# (bf16: 1.65x / 1.32x the cost of bf16 operands for ANY implementation with these weights -- the CPU oracle with the same 58 convolutions'
+# operands rounded to bf16 differs from the fp32 reference by 0.1094 / 0.01064: tools/bf16_gate_derivation.py, profiles/r05_bf16_gate_derivation.txt)
 GATES = {'fp32': (1e-3, 1e-4), 'f16x2': (1e-3, 1e-4), 'fp16': (0.04, 0.003), 'bf16': (0.18, 0.014)}
 
 
@@ -71,6 +73,28 @@ def test_real_aligned_faces_match_the_reference(net, name, precision):
     assert dl <= 1e-4 and dp <= 1e-3
     _check_u8(ops.tensor_to_img_u8(out)[0].cpu().numpy(), g['out_u8'])
     net.precision = 'fp32'
+
+
+@pytest.mark.parametrize('precision', ['f16x2', 'fp32'])
+def test_encoder_logit_margin(chk, precision):
+    """The gate behind Winograd F(4x4,3x3) in the ENCODER (CodeFormer.winograd_f43_encoder, on by default since round 5): over every
+    golden with reference logits -- seeded face, three real crops, masked face (inpainting net), four range variants (full logits) and the
+    32-face sweep (tests/golden/logit_sweep32.npz, the reference's top-8 codes per token) -- and every token whose reference top-2 gap is
+    >= 1e-5:   (reference gap) / (2 x max |our logit - reference logit|)  >=  5,   no index differs, and no code outside the reference's
+    top-8 comes anywhere near the winner.  Measured on MI355X: 7.0 ('f16x2') / 7.3 ('fp32') with the switch on, 9.9 / 8.7 with it off."""
+    spec = importlib.util.spec_from_file_location('logit_margin', os.path.join(ROOT, 'tools', 'logit_margin.py'))
+    lm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lm)
+    default_on = chk.build_net().winograd_f43_encoder
+    r = lm.measure(lm.Nets(chk), chk, precision, default_on)
+    rows = {k: v for k, v in r.items() if not k.startswith('_')}
+    for k, v in rows.items():
+        print(f'{k:40s} [{precision}, encoder F(4,3) {default_on}] min margin {v[0]:9.2f}  max logit error {v[1]:.2e}  near ties {v[2]}  indices differing {v[3]}')
+    assert len(rows) == 10
+    assert all(v[3] == 0 for v in rows.values())                       # every index on every safe token
+    assert all(v[1] <= 1e-4 for v in rows.values())                    # the north-star logit tolerance
+    assert min(v[0] for v in rows.values()) >= 5.0, min(v[0] for v in rows.values())
+    assert r['_sweep32_outside_top8_distance'] >= 1e-2                 # (top-8 is enough: the ninth code is ~1e-1 below the winner)
 
 
 def test_real_masked_face_inpainting_matches_the_reference(chk):

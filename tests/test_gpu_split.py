@@ -67,6 +67,12 @@ def test_split_conv_is_bitwise_repeatable_and_batch_invariant(sc):
         assert torch.equal(y, y2) and torch.equal(y._cf_stats.part, y2._cf_stats.part)
         y1 = ops.conv2d(xx[1:2].contiguous(), pw, emit_stats=True)
         assert torch.equal(y[1:2], y1) and torch.equal(y._cf_stats.part.view(3, -1)[1:2], y1._cf_stats.part.view(1, -1))
+    # a single 16-channel slab (pipeline shorter than its depth) through the eight-wave kernel, against the exact Winograd kernel
+    xx = torch.randn(2, 32, 32, 16, generator=g).cuda()
+    w16 = (torch.randn(128, 16, 3, 3, generator=g) * 0.1).cuda()
+    yw = ops.conv2d(xx, ops.pack_weight(w16, b, bf16=ops.WSPLIT))
+    yf = ops.conv2d(xx, ops.pack_weight(w16, b, bf16=ops.WINOGRAD))
+    assert float((yw - yf).abs().max()) <= 1e-5
 
 
 def test_split_conv_refusals_and_overflow_is_loud(sc):

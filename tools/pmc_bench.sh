@@ -1,14 +1,20 @@
 #!/bin/bash
 # PMC passes over one bench step (each counter set in its own run, --kernel-trace only): per-kernel averages -> JSON.
+# Usage: bash tools/pmc_bench.sh <tag> [precision]   precision f16x2 (default) -> gpurun_out/pmc_bench_<tag>.json,
+#        fp32 / bf16 -> gpurun_out/pmc_bench_<tag>_<precision>.json (copy to profiles/<tag>_pmc_bench[_<precision>].json: bench.py quotes
+#        `traffic` of the exact_fp32 / config3_rank legs from those)
 tag=${1:-r01}
+prec=${2:-f16x2}
+suffix=""; [ "$prec" != "f16x2" ] && suffix="_$prec"
+wflag=""; [ "$prec" = "bf16" ] && wflag="--w 0.7"
 mkdir -p gpurun_out; export TMPDIR=/tmp
 i=0
 for set in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
-  i=$((i+1)); rm -rf /tmp/pb$i
-  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pb$i -o p -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-exact-leg --no-config3-leg --no-parity-gate > gpurun_out/pmcbench_${tag}_run$i.log 2>&1
+  i=$((i+1)); rm -rf /tmp/pb$i; [ $i = 1 ] && rm -rf /tmp/pb[0-9]*
+  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pb$i -o p -- python bench.py --steps 1 --warmup 1 --precision $prec $wflag --no-cpu-baseline --no-roofline --no-exact-leg --no-config3-leg --no-parity-gate > gpurun_out/pmcbench_${tag}${suffix}_run$i.log 2>&1
   echo "set $i rc=$?"
 done
-python - "$tag" <<'PY'
+python - "$tag$suffix" "$prec $wflag" <<'PY'
 import csv, glob, json, sys, collections
 tag = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -32,7 +38,7 @@ for k, d in agg.items():
 import ctypes, os
 lib = ctypes.CDLL(os.path.join('codeformer_amd', 'libcodeformer_hip.so'))
 lib.cf_build_id.restype = ctypes.c_char_p
-out['_meta'] = {'cf_build_id': lib.cf_build_id().decode(), 'command': 'bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-exact-leg --no-config3-leg --no-parity-gate'}
+out['_meta'] = {'cf_build_id': lib.cf_build_id().decode(), 'command': f'bench.py --steps 1 --warmup 1 --precision {sys.argv[2].strip()} --no-cpu-baseline --no-roofline --no-exact-leg --no-config3-leg --no-parity-gate'}
 json.dump(out, open(f'gpurun_out/pmc_bench_{tag}.json', 'w'), indent=1, sort_keys=True)
 for k, d in out.items():
     if k == '_meta':

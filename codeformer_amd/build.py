@@ -54,18 +54,56 @@ def needs_build():
     return built_id() != source_hash()
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
+def _compile_one(args):
+    hipcc, src, obj, flags = args
+    if os.path.exists(obj):
+        return obj, ''
+    tmp = obj + f'.{os.getpid()}.tmp'
+    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c'] + flags + ['-o', tmp, src], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f'hipcc failed on {os.path.basename(src)}:\n' + r.stdout + r.stderr)
+    os.replace(tmp, obj)
+    return obj, r.stderr
+
+
+def build(force=False, verbose=False, out=None, defines=(), extra_sources=()):
+    """Compile every source of SOURCES for gfx950 (one hipcc process per file, in parallel; objects are cached by content hash under
+    $CF_OBJ_CACHE or /tmp/cf_objcache, so an edit recompiles one file) and link libcodeformer_hip.so in-tree.
+    out / defines / extra_sources: experiment variants (tools/*): another output path, extra -D flags, extra .hip files."""
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
+    target = out or LIB
+    if out is None and not defines and not extra_sources and not force and not needs_build():
         return LIB
-    cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', f'-DCF_BUILD_ID="{source_hash()}"',
-           '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC, '-o', LIB + '.tmp'] + [os.path.join(CSRC, s) for s in SOURCES]
+    hipcc = _hipcc()
+    cache = os.environ.get('CF_OBJ_CACHE', '/tmp/cf_objcache')
+    os.makedirs(cache, exist_ok=True)
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')) + [os.path.join(ROOT, 'include', 'codeformer_hip.h')]
+    hh = hashlib.sha256()
+    for f in headers:
+        with open(f, 'rb') as fh:
+            hh.update(fh.read())
+    build_id = source_hash()
+    jobs = []
+    for src in [os.path.join(CSRC, s) for s in SOURCES] + [os.path.abspath(s) for s in extra_sources]:
+        flags = ['-I' + os.path.join(ROOT, 'include'), '-I' + CSRC] + [f'-D{d}' for d in defines]
+        if os.path.basename(src) == 'cf_misc.hip':
+            flags.append(f'-DCF_BUILD_ID="{build_id}"')    # (only this file reads it: the others stay cached across unrelated edits)
+        h = hashlib.sha256(hh.digest())
+        with open(src, 'rb') as fh:
+            h.update(fh.read())
+        h.update(' '.join(flags).encode())
+        jobs.append((hipcc, src, os.path.join(cache, f'{os.path.basename(src)}.{h.hexdigest()[:20]}.o'), flags))
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+        objs = [o for o, _ in ex.map(_compile_one, jobs)]
+    cmd = [hipcc, '--offload-arch=gfx950', '-fPIC', '-shared', '-o', target + '.tmp'] + objs
     if verbose:
         print(' '.join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError('hipcc failed:\n' + r.stdout + r.stderr)
-    os.replace(LIB + '.tmp', LIB)
-    return LIB
+        raise RuntimeError('hipcc link failed:\n' + r.stdout + r.stderr)
+    os.replace(target + '.tmp', target)
+    return target
 
 
 if __name__ == '__main__':

@@ -25,7 +25,7 @@ extern "C" const char* cf_build_id(void) { return g_build_id + 12; }
 extern "C" const char* cf_last_error(void) { return g_err; }
 // Table of the kernels that need the dynamic-LDS attribute (cf_common.h): filled by static initialisers while the library loads, constant
 // afterwards.  Zero-initialised storage, so the order of the initialisers across translation units does not matter.
-constexpr int CF_LDS_TABLE = 256;
+constexpr int CF_LDS_TABLE = 512;
 static const void* g_lds_kernel[CF_LDS_TABLE];
 static int g_lds_bytes[CF_LDS_TABLE];
 static int g_lds_count;

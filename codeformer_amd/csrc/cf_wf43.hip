@@ -69,6 +69,16 @@
 #define F4_ABLATE 0
 #endif
 
+#ifndef F4_K32_PAIR   // 32-channel-slab form, A/B record of round 5: 1 = a wave owns 9 positions x 2 channel blocks (an A fragment read from LDS feeds
+#define F4_K32_PAIR 0  // two MFMA triples: half the A-fragment LDS reads, 295 KB less per slab), 0 = 18 positions x 1 channel block (round 4, shipped).
+#endif                 // Bitwise the same results; measured flat on every shape (0.768 vs 0.772 ms on 128 -> 128 @ 256x256 x 16: profiles/r05_f43_pair_ab.txt)
+#ifndef F4_WIDE_DEFAULT   // form of the 16-wave workgroup when CF_F43_WIDE is not set (f4_wide_mode below)
+#define F4_WIDE_DEFAULT 1
+#endif
+#ifndef F4_OVL_PRIO   // A/B: s_setprio level of waves 0..3 inside their MFMA stage of the overlapped form (0: none)
+#define F4_OVL_PRIO 0
+#endif
+
 #ifndef F4_TIMING   // experiment builds only (tools/f43_timing.py): s_memtime stamps of one workgroup in the middle of the grid
 #define F4_TIMING 0
 #endif
@@ -107,6 +117,7 @@ static_assert(F4_M_FLOATS <= 2 * F4_PATCH_FLOATS + F4_V_FLOATS, "epilogue stagin
 static_assert(F4_LDS_FLOATS * 4 <= 81920, "LDS budget of two workgroups per CU");
 constexpr int F4_LDS_FLOATS_16 = 2 * F4_M_FLOATS;   // 16-wave form: its epilogue pass stages 36 x 8 tiles x 128 channels = 147,456 bytes (the slab loop needs the 80,896 above)
 static_assert(F4_LDS_FLOATS_16 >= F4_LDS_FLOATS && F4_LDS_FLOATS_16 * 4 <= 163840, "LDS budget of the 16-wave form");
+static_assert(F4_LDS_FLOATS_16 >= 2 * F4_PATCH_FLOATS + 2 * F4_V_FLOATS + 2 * F4_TAB, "the overlapped form's two V buffers fit under the epilogue staging");
 constexpr int F4_LDS_FLOATS_32 = 2 * F4_SLOTS * 32 + 36 * F4_NT * 32 + 2 * F4_TAB;   // 16 waves, 32-channel slabs: 159,744 bytes
 static_assert(F4_LDS_FLOATS_32 >= F4_LDS_FLOATS_16 && F4_LDS_FLOATS_32 * 4 <= 163840, "LDS budget of the 32-channel-slab form");
 
@@ -165,9 +176,13 @@ __device__ __forceinline__ unsigned f4_vu(unsigned lq, unsigned p, unsigned t) {
 // F32 = IEEE-fp32 operands on v_mfma_f32_16x16x4_f32 (precision 'fp32': BASELINE config 2 to the letter) instead of hi + lo halves: the SAME
 // data movement -- a lane's A and B fragments are 16 (32) bytes either way: four (eight) fp32 values k = 4 j + (lane >> 4) instead of
 // [4 hi halves | 4 lo halves] -- with four (eight) fp32 MFMAs per position instead of three f16 ones; no weight / activation scale.
-template <int PRO, int EPI, int NW, int KS, bool F32>
+// OVL (round 5; NW = 16, KS = 16 only): ONE barrier interval per slab with V double-buffered -- every wave multiplies slab s FIRST, then waves
+// 0..3 transform slab s + 1 into the other V buffer while the younger waves (which lose the arbitration for the vector-memory path and
+// finish their weight stream last) are still multiplying: see "The overlapped 16-wave form" at the slab loop.
+template <int PRO, int EPI, int NW, int KS, bool F32, bool OVL = false>
 __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
   static_assert(KS == 16 || (KS == 32 && NW == 16), "32-channel slabs need the LDS of the 16-wave form");
+  static_assert(!OVL || (NW == 16 && KS == 16), "the overlapped form: 16 waves on 16-channel slabs (two V buffers of 36 KB beside two patch buffers)");
   constexpr int F4_THREADS = NW * 64;
   constexpr int F4_BN = NW * 8;                  // output channels per workgroup
   constexpr int TWV = KS / 4;                    // transform waves: 256 (tile, channel pair, xi half) items per 16 channels
@@ -180,7 +195,8 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
   constexpr int PSK = F4_NT * KS;                // floats between positions of V
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const V = smem + 2 * PATCHF;
-  float* const tab = V + 36 * PSK;  // [scale: F4_TAB][shift: F4_TAB]
+  constexpr int VBUF = 36 * PSK;                   // floats per V buffer (OVL: two, slab parity)
+  float* const tab = V + (OVL ? 2 : 1) * VBUF;     // [scale: F4_TAB][shift: F4_TAB]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -205,6 +221,7 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tlast = __builtin_amdgcn_s_memtime();
   const unsigned long long tstart = tlast;
+  const unsigned long long rstart = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz: cycles / realtime = the shader clock this launch ran at
 #endif
 
   constexpr bool affine = PRO == CF_PRO_AFFINE || PRO == CF_PRO_AFFINE_SWISH;
@@ -342,6 +359,7 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
   // weight fragments are requested there: the first pass's column sums are dead, the live set is at its smallest).
   auto transform = [&](int chunk, auto mid) __attribute__((always_inline)) {
     const char* const pb = reinterpret_cast<const char*>(smem + (chunk & 1) * PATCHF);
+    float* const V = smem + 2 * PATCHF + (OVL ? (chunk & 1) * VBUF : 0);   // (shadows the kernel's V: this slab's buffer)
     unsigned ln = (unsigned)lane;
     asm volatile("" : "+v"(ln));  // opaque per slab (see above)
     // 16-channel slabs: wave = (xi half, tile half), lane = (tile, 8 channel pairs); 32-channel slabs: wave = (xi half, tile row), lane = (tile column, 16 pairs)
@@ -475,7 +493,7 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
       unsigned ln = (unsigned)lane;
       asm volatile("" : "+v"(ln));
       const unsigned t15 = ln & 15u;
-      a_base = V + (18 * m_g) * PSK + t15 * CF_BK + (((ln >> 4) ^ (unsigned)f4_vs((int)(t15 >> 2))) << 2);
+      a_base = V + (OVL ? (chunk & 1) * VBUF : 0) + (18 * m_g) * PSK + t15 * CF_BK + (((ln >> 4) ^ (unsigned)f4_vs((int)(t15 >> 2))) << 2);
       lane16 = ln * 16u;
     }
     auto read_A = [&](int i) __attribute__((always_inline)) { va[i % NA] = *reinterpret_cast<const f32x4*>(a_base + i * PSK); };
@@ -526,9 +544,14 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
   // one A register set, B ring of three positions (what 128 registers hold beside 72 accumulators), positions 0..2 requested in the T interval
   typedef _Float16 f4_f16x8 __attribute__((ext_vector_type(8)));
   f32x4 xb[3][2], xa[1][2];
+  // Unit i of a wave (F4_K32_PAIR): position p_g + (i >> 1) of its group of nine, channel block 2 (wave & 3) + (i & 1); accumulator i.
+  constexpr bool PAIR = F4_K32_PAIR && KS == 32;
+  const int p_g = PAIR ? 9 * (wave >> 2) : 18 * m_g;                     // first position of this wave
+  const int p_nb = PAIR ? 2 * (wave & 3) : m_nb;                        // first (only) 16-channel block
+  const unsigned w_s32 = (unsigned)p_g * w_pos + (unsigned)(n0 / 16 + p_nb) * (unsigned)(64 * KS);
   auto load_B32 = [&](int chunk, int i) __attribute__((always_inline)) {
 #if !(F4_ABLATE & 16)
-    const unsigned so = w_s0 + (unsigned)i * w_pos + (unsigned)chunk * w_chunk;
+    const unsigned so = w_s32 + (PAIR ? (unsigned)(i >> 1) * w_pos + (unsigned)(i & 1) * (unsigned)(64 * KS) : (unsigned)i * w_pos) + (unsigned)chunk * w_chunk;
     xb[i % 3][0] = f4_ld128(rs_w, lane16, so);
     xb[i % 3][1] = f4_ld128(rs_w, lane16 + 16u, so);
 #endif
@@ -540,13 +563,13 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
       asm volatile("" : "+v"(ln));
       const unsigned t15 = ln & 15u, lq = ln >> 4;
 #pragma unroll
-      for (unsigned pp = 0; pp < 4; ++pp) ao[pp] = ((unsigned)(18 * m_g) * (unsigned)PSK + t15 * 32u + f4_vu(lq, pp, t15) * 2u) * 4u;   // bytes from V
+      for (unsigned pp = 0; pp < 4; ++pp) ao[pp] = ((unsigned)p_g * (unsigned)PSK + t15 * 32u + f4_vu(lq, pp, t15) * 2u) * 4u;   // bytes from V
       lane16 = ln * 32u;
     }
     const char* const vb = reinterpret_cast<const char*>(V);
-    auto read_A = [&](int i) __attribute__((always_inline)) {
-      const f4_f32x2 p0 = *reinterpret_cast<const f4_f32x2*>(vb + ao[0] + i * (PSK * 4)), p1 = *reinterpret_cast<const f4_f32x2*>(vb + ao[1] + i * (PSK * 4));
-      const f4_f32x2 p2 = *reinterpret_cast<const f4_f32x2*>(vb + ao[2] + i * (PSK * 4)), p3 = *reinterpret_cast<const f4_f32x2*>(vb + ao[3] + i * (PSK * 4));
+    auto read_A = [&](int pos) __attribute__((always_inline)) {
+      const f4_f32x2 p0 = *reinterpret_cast<const f4_f32x2*>(vb + ao[0] + pos * (PSK * 4)), p1 = *reinterpret_cast<const f4_f32x2*>(vb + ao[1] + pos * (PSK * 4));
+      const f4_f32x2 p2 = *reinterpret_cast<const f4_f32x2*>(vb + ao[2] + pos * (PSK * 4)), p3 = *reinterpret_cast<const f4_f32x2*>(vb + ao[3] + pos * (PSK * 4));
       xa[0][0] = f32x4{p0[0], p0[1], p1[0], p1[1]};
       xa[0][1] = f32x4{p2[0], p2[1], p3[0], p3[1]};
     };
@@ -575,7 +598,12 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
         mf(xa[0][0], xb[i % 3][1], acc[i]);
         mf(xa[0][0], xb[i % 3][0], acc[i]);
       }
-      if (i + 1 < 18) read_A(i + 1);   // (one register set: the next fragment is read once this position's MFMAs are issued -- 128 registers)
+      // (one register set: the next fragment is read once this position's MFMAs are issued -- 128 registers; PAIR: after its second channel block)
+      if (PAIR) {
+        if ((i & 1) && i + 1 < 18) read_A((i + 1) >> 1);
+      } else if (i + 1 < 18) {
+        read_A(i + 1);
+      }
       if (i + 3 < 18) load_B32(chunk, i + 3);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -665,6 +693,114 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
         mma_stage32(s);
         __builtin_amdgcn_sched_barrier(0);
         if (s + 2 < n) load_A_range(s + 2, h0, h1);
+        __builtin_amdgcn_sched_barrier(0);
+        F4_T(3);
+        __syncthreads();
+        F4_T(4);
+      }
+    }
+  } else if constexpr (OVL) {
+    // ---- The overlapped 16-wave form.  The two-interval loop below leaves the vector-memory path idle while the patch is transformed
+    // (T, 25 % of a patch's cycles) and the matrix / LDS side idle while the weight fragments stream (M: 295 KB per 16-channel slab
+    // at ~57 B/clk; the OLD waves win the arbitration and finish their 18 positions in a third of the interval, then wait at the
+    // barrier -- profiles/r04_f43_k32_stage_timing.txt).  Here an interval is  M(s) | transform(s + 1)  for waves 0..3 and
+    // store(patch s + 2) | M(s)  for waves 4..15: V(s + 1) goes to the other V buffer, patch(s + 2) into the buffer transform(s) freed
+    // one interval ago.  Round 4 measured the opposite order (transform first: its waves then stream alone, latency-bound) as no gain.
+    // Arithmetic and summation order are those of the two-interval <., ., 16, 16> form: results are bitwise equal.
+    if (wave < 4) {
+      __syncthreads();  // (the GroupNorm rows are in LDS)
+      __syncthreads();  // patch(0) visible
+      transform(0, [&]() __attribute__((always_inline)) {
+        set_lane16();
+        load_B(0, 0, nb4);
+        load_B(0, 1, nb4);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      load_B(0, 2, nb4);
+      load_B(0, 3, nb4);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();  // V(0) and patch(1) visible
+      F4_T(0);
+      int s = 0;
+      for (; s + 1 < n; ++s) {
+#if F4_OVL_PRIO
+        __builtin_amdgcn_s_setprio(F4_OVL_PRIO);
+#endif
+        mma_stage(s, na4, []() __attribute__((always_inline)) {});
+#if F4_OVL_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        F4_T(3);
+        transform(s + 1, [&]() __attribute__((always_inline)) {
+          set_lane16();
+          load_B(s + 1, 0, nb4);
+          load_B(s + 1, 1, nb4);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        load_B(s + 1, 2, nb4);
+        load_B(s + 1, 3, nb4);
+        __builtin_amdgcn_sched_barrier(0);
+        F4_T(1);
+        __syncthreads();  // V(s + 1) and patch(s + 2) visible; V(s) and patch(s + 1) are free
+        F4_T(4);
+      }
+      mma_stage(s, na4, []() __attribute__((always_inline)) {});
+      __builtin_amdgcn_sched_barrier(0);
+      F4_T(3);
+      __syncthreads();
+      F4_T(4);
+    } else {
+      constexpr std::integral_constant<int, 0> h0{};
+      constexpr std::integral_constant<int, F4_APT> h2{};
+      static_assert(!HALVES, "two gather items per thread");
+      load_A_range(0, h0, h2);
+      __syncthreads();  // (the GroupNorm rows are in LDS)
+#if !(F4_ABLATE & 4)
+      store_patch(0);
+#endif
+      if (n > 1) load_A_range(1, h0, h2);
+      __syncthreads();  // patch(0) visible
+#if !(F4_ABLATE & 4)
+      if (n > 1) store_patch(1);
+#endif
+      if (n > 2) load_A_range(2, h0, h2);
+      __builtin_amdgcn_sched_barrier(0);
+      set_lane16();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) load_B(0, i, nb4);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();  // V(0) and patch(1) visible
+      F4_T(0);
+      int s = 0;
+      for (; s + 3 < n; ++s) {   // (its own loop: the gather request must not sit under a condition, see the two-interval loop)
+#if !(F4_ABLATE & 4)
+        store_patch(s + 2);   // requested one interval ago
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        F4_T(1);
+        mma_stage(s, na_gather, [&]() __attribute__((always_inline)) { load_A_range(s + 3, h0, h2); });
+        __builtin_amdgcn_sched_barrier(0);
+        set_lane16();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_B(s + 1, i, nb4);
+        __builtin_amdgcn_sched_barrier(0);
+        F4_T(3);
+        __syncthreads();
+        F4_T(4);
+      }
+      for (; s < n; ++s) {   // the last three slabs: nothing left to request; the fragment prefetch of a slab past the end re-reads the last one (unused)
+#if !(F4_ABLATE & 4)
+        if (s + 2 < n) store_patch(s + 2);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        F4_T(1);
+        mma_stage(s, na_gather, []() __attribute__((always_inline)) {});
+        __builtin_amdgcn_sched_barrier(0);
+        set_lane16();
+        const int sn = s + 1 < n ? s + 1 : s;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_B(sn, i, nb4);
         __builtin_amdgcn_sched_barrier(0);
         F4_T(3);
         __syncthreads();
@@ -807,7 +943,8 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
     F4_T(6);
 #pragma unroll
     for (int i = 0; i < 18; ++i) {
-      float* mp = Mst + ((18 * m_g + i) * 8 + 2 * (lane >> 4)) * F4_BN + m_nb * 16 + (lane & 15);
+      float* mp = PAIR ? Mst + ((p_g + (i >> 1)) * 8 + 2 * (lane >> 4)) * F4_BN + (p_nb + (i & 1)) * 16 + (lane & 15)
+                       : Mst + ((18 * m_g + i) * 8 + 2 * (lane >> 4)) * F4_BN + m_nb * 16 + (lane & 15);
       mp[0] = acc[i][2 * th];
       mp[F4_BN] = acc[i][2 * th + 1];
     }
@@ -923,6 +1060,7 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
     for (int k = 0; k < 8; ++k) f4_timing_buf[wave * 16 + k] = tacc[k];
     f4_timing_buf[wave * 16 + 8] = tlast - tstart;
     f4_timing_buf[wave * 16 + 9] = (unsigned long long)n;
+    f4_timing_buf[wave * 16 + 10] = __builtin_amdgcn_s_memrealtime() - rstart;
   }
 #endif
 }
@@ -1001,14 +1139,20 @@ __global__ void pack_weight_wf43_kernel(const float* __restrict__ w, int cout, i
 
 }  // namespace
 
-// A/B switch (debug): CF_F43_K32=0 keeps the 16-wave form on 16-channel slabs (the one-interval loop) for every shape; packing and launch agree
-static bool f4_k32_enabled() {
+// Form of the 16-wave (128-output-channel) workgroup; packing and launch agree through this one function:
+//   1  32-channel slabs, two barrier intervals per slab (rounds 4: v_mfma_f32_16x16x32_f16)            CF_F43_WIDE=k32
+//   2  16-channel slabs, ONE interval per slab with the transform under the weight stream (round 5)     CF_F43_WIDE=ovl
+//   0  16-channel slabs, two intervals (A/B only; also what cin % 32 != 0 runs in mode 1)                CF_F43_WIDE=k16 (or CF_F43_K32=0)
+static int f4_wide_mode() {
   static const int v = [] {
+    const char* w = getenv("CF_F43_WIDE");
+    if (w) return w[0] == 'o' ? 2 : (w[0] == 'k' && w[1] == '1') ? 0 : 1;
     const char* e = getenv("CF_F43_K32");
-    return e ? atoi(e) : 1;
+    return e && atoi(e) == 0 ? 0 : F4_WIDE_DEFAULT;
   }();
-  return v != 0;
+  return v;
 }
+static bool f4_k32_enabled() { return f4_wide_mode() == 1; }
 
 extern "C" int cf_pack_conv_weight_winograd43_f16x2(const float* w, int cout, int cin, int cout_pad, int cin_pad, float scale, void* packed,
                                                     cf_stream_t stream) {
@@ -1091,6 +1235,7 @@ int cf_wf43_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query) 
   a.nparts = a.tiles_per_img;
   const bool wide = d->cout % 128 == 0;                      // 16 waves x 128 channels where the layer has them ...
   const bool k32 = wide && (d->c0 + d->c1) % 32 == 0 && f4_k32_enabled();   // ... on 32-channel slabs where cin allows: the rule the pack functions lay the weight out by
+  const bool ovl = wide && f4_wide_mode() == 2;                             // ... or on 16-channel slabs with the transform under the weight stream
   CF_REQUIRE(!k32 || d->c0 % 32 == 0, "cf_conv2d(winograd 2): with cout %% 128 == 0 and cin %% 32 == 0 the concat boundary must be a multiple of 32 (c0 = %d)", d->c0);
   a.ntn = d->cout / (wide ? 128 : 64);
   if (parts_query) {
@@ -1105,7 +1250,9 @@ int cf_wf43_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query) 
     CF_LDS_ATTR((wf43_kernel<P, E, 8, 16, O>), F4_LDS_FLOATS * sizeof(float) + (F4_TIMING ? 32768 : 0));                      \
     CF_LDS_ATTR((wf43_kernel<P, E, 16, 16, O>), F4_LDS_FLOATS_16 * sizeof(float));                                            \
     CF_LDS_ATTR((wf43_kernel<P, E, 16, 32, O>), F4_LDS_FLOATS_32 * sizeof(float));                                            \
+    CF_LDS_ATTR((wf43_kernel<P, E, 16, 16, O, true>), F4_LDS_FLOATS_16 * sizeof(float));                                      \
     if (k32) hipLaunchKernelGGL((wf43_kernel<P, E, 16, 32, O>), grid, block, lds, stream, a);                                 \
+    else if (ovl) hipLaunchKernelGGL((wf43_kernel<P, E, 16, 16, O, true>), grid, block, lds, stream, a);                      \
     else if (wide) hipLaunchKernelGGL((wf43_kernel<P, E, 16, 16, O>), grid, block, lds, stream, a);                           \
     else hipLaunchKernelGGL((wf43_kernel<P, E, 8, 16, O>), grid, block, lds, stream, a);                                      \
   } while (0)

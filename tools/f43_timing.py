@@ -25,6 +25,8 @@ buf = (ctypes.c_ulonglong * 256)()
 assert raw.cf_debug_f4_timing(buf) == 0
 names = ['fill', 'T work', 'T barrier', 'M work', 'M barrier', 'epi load+stage', 'epi barriers', 'epi compute+store']
 n = int(buf[9])
+if int(buf[10]):
+    print(f'shader clock of the stamped workgroup: {int(buf[8]) / (int(buf[10]) * 10e-9) / 1e9:.3f} GHz ({int(buf[8])} cycles in {int(buf[10]) * 10e-3:.1f} us)')
 print(f'{cin}->{cout} @ {H}x{H} x {B}: {n} slabs; shader cycles summed over the patch (per slab in brackets for the slab stages)')
 print('wave  ' + '  '.join(f'{s:>17s}' for s in names) + '   total')
 for w in range(16 if cout % 128 == 0 and not os.environ.get("CF_F43_NARROW") else 8):

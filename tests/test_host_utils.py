@@ -183,3 +183,57 @@ def test_entry_scripts_compile():
     assert len(files) > 10
     for f in files:
         compile(open(f).read(), f, 'exec')
+
+
+def test_param_signature_follows_replaced_parameters_and_modules():
+    """The graph-replay key of CodeFormer (advisor item of round 4): a REPLACED Parameter object (version 0 again, possibly the same
+    size) and a replaced / added sub-module must change the signature; in-place versioned updates and load_state_dict too; calling it
+    twice without a change must not."""
+    import torch
+    import codeformer_amd.archs  # noqa: F401
+    from codeformer_amd.utils.registry import ARCH_REGISTRY
+    net = ARCH_REGISTRY.get('CodeFormer')(dim_embd=512, codebook_size=1024, n_head=8, n_layers=9, connect_list=['32', '64', '128', '256']).eval()
+    s0 = net._param_signature()
+    assert net._param_signature() == s0
+    old = net.generator.blocks[24].bias
+    net.generator.blocks[24].bias = torch.nn.Parameter(old.detach().clone(), requires_grad=False)     # a new object with equal content
+    s1 = net._param_signature()
+    assert s1 != s0
+    with torch.no_grad():
+        net.generator.blocks[24].bias.add_(1.0)                                                          # versioned in-place update
+    s2 = net._param_signature()
+    assert s2 != s1
+    from codeformer_amd.archs.vqgan_arch import _Conv3x3
+    net.generator.blocks[24] = _Conv3x3(64, 3)                                                           # a replaced sub-module
+    s3 = net._param_signature()
+    assert s3 != s2 and net._param_signature() == s3
+    net.extra = torch.nn.Linear(4, 4)                                                                    # an added sub-module
+    assert net._param_signature() != s3
+    import copy
+    import pickle
+    copy.deepcopy(net.ft_layers[0])                                                                      # module attributes stay copyable / picklable
+    pickle.dumps(net.idx_pred_layer)
+
+
+def test_version_reads_are_safe_under_inference_mode():
+    """ops.tensor_version: inference tensors carry no version counter (reading `._version` raises); version-keyed caches skip them."""
+    import torch
+    from codeformer_amd import ops
+    t = torch.zeros(3)
+    assert ops.tensor_version(t) == t._version
+    with torch.inference_mode():
+        u = torch.zeros(3)
+        assert ops.tensor_version(u) is None
+    assert ops.tensor_version(u) is None and u.is_inference()
+
+
+def test_bf16_gate_is_a_stated_multiple_of_the_intrinsic_cost(golden_dir):
+    """Where the bf16 pixel gate (0.18 / 0.014) comes from: the CPU oracle with bf16-rounded operands in the convolutions the 'bf16' mode
+    puts on bf16 MFMA, against the reference's fp32 output at w = 0.7 -- the cost of bf16 operands for any implementation.  The gate
+    must stay between 1.2x and 2x that cost (tools/bf16_gate_derivation.py; profiles/r05_bf16_gate_derivation.txt has the numbers)."""
+    import re
+    txt = open(os.path.join(ROOT, 'profiles', 'r05_bf16_gate_derivation.txt')).read()
+    mx, mean = (float(v) for v in re.search(r'vs the same golden: max ([0-9.]+) mean ([0-9.]+)', txt).groups())
+    assert 1.2 * mx <= 0.18 <= 2.0 * mx and 1.2 * mean <= 0.014 <= 2.0 * mean, (mx, mean)
+    src = open(os.path.join(ROOT, 'tests', 'test_gpu_real_images.py')).read()
+    assert "'bf16': (0.18, 0.014)" in src

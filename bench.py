@@ -103,8 +103,8 @@ def recorded_traffic(prefixes=('wsplit_kernel',), precision='f16x2'):
 
 
 def wf43_names(f32):
-    """Instantiation names of wf43_kernel<PRO, EPI, NW, KS, F32> for one operand type (the template argument is the LAST one: no common prefix)."""
-    return tuple(f'wf43_kernel<{p}, {e}, {nw}, {ks}, {f32}>' for p in range(4) for e in range(3) for nw, ks in ((8, 16), (16, 16), (16, 32)))
+    """Name prefixes of the instantiations wf43_kernel<PRO, EPI, NW, KS, F32, OVL> of one operand type (F32 is the fifth argument: no common prefix)."""
+    return tuple(f'wf43_kernel<{p}, {e}, {nw}, {ks}, {f32},' for p in range(4) for e in range(3) for nw, ks in ((8, 16), (16, 16), (16, 32)))
 
 
 def roofline_leg(net, x, w):

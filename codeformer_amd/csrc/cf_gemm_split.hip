@@ -300,6 +300,74 @@ __global__ __launch_bounds__(256) void gemm_split_tile_kernel(const GsArgs g) {
   }
 }
 
+// ---- the same GEMM for FEW tokens (one to four faces; round 5): the K chunks of a 32 x 32 output tile are shared by the four waves of ONE
+// workgroup -- split_k == CF_SPLITK_IN_WORKGROUP (-1).  The cross-workgroup split above costs a launch of 128 workgroups two dependent
+// global phases (park + ticket, then the last arriver's ordered re-read: 16 us for 256 x 512 x 512); here wave w accumulates virtual
+// chunks w, w + 4, ... from zero (a whole chunk's sixteen A / sixteen B fragments requested at once: ONE L2 round trip per chunk), parks
+// each chunk sum in LDS, and after one barrier the 256 threads add the chunk sums IN CHUNK ORDER from zero and run the epilogue
+// expression of the kernels above.  Per output element that is their arithmetic exactly (k steps in order inside a chunk, lo*hi, hi*lo,
+// hi*hi per step; out = ((0 + P0) + P1) + ...), so all three kernels agree BITWISE and the host may choose by the number of tiles in
+// flight -- i.e. by the batch -- without touching batch invariance.  No workspace, no counters.
+constexpr int GS_SMALL_MAXV = 8;   // K <= 1024: chunk sums of a tile in LDS = V x 4 KB
+__global__ __launch_bounds__(256) void gemm_split_small_kernel(const GsArgs g) {
+  __shared__ __attribute__((aligned(16))) float part[GS_SMALL_MAXV][16][64];   // [chunk][accumulator register][lane]: 32 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int ntn = g.N >> 5;
+  const int nt = blockIdx.x % ntn, mt = blockIdx.x / ntn;
+  const int m0 = mt * 32, n0 = nt * 32;
+  const int V = g.K >> 7;
+  const float* const arow = g.a + (size_t)(m0 + l31) * g.K + half * 8;
+  const size_t kstride = (size_t)(g.N >> 5) * 512;  // floats between consecutive k steps of the packed weights
+  const float* const wl = g.w + (size_t)nt * 512 + lane * 4;
+  for (int c = wave; c < V; c += 4) {
+    f32x4 ra[8][2], rb[8][2];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int ks = c * 8 + s;
+      ra[s][0] = *reinterpret_cast<const f32x4*>(arow + ks * 16);
+      ra[s][1] = *reinterpret_cast<const f32x4*>(arow + ks * 16 + 4);
+      rb[s][0] = *reinterpret_cast<const f32x4*>(wl + (size_t)ks * kstride);
+      rb[s][1] = *reinterpret_cast<const f32x4*>(wl + (size_t)ks * kstride + 256);
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      f32x4 ah, al;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const f32x4 v = ra[s][e >> 1];
+        float hh, ll;
+        cf_split_pair(v[(e & 1) * 2], v[(e & 1) * 2 + 1], hh, ll);
+        ah[e] = hh;
+        al[e] = ll;
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gs_f16x8, al), __builtin_bit_cast(gs_f16x8, rb[s][0]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gs_f16x8, ah), __builtin_bit_cast(gs_f16x8, rb[s][1]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gs_f16x8, ah), __builtin_bit_cast(gs_f16x8, rb[s][0]), acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[c][r][lane] = acc[r];
+  }
+  __syncthreads();
+  // thread t finishes accumulator registers (t >> 6) + 4 j of lane t & 63: column n0 + (lane & 31), rows cf_acc_row(r, lane)
+  const int n = n0 + l31;
+  const float bias = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = wave + 4 * j;
+    float tot = 0.f;
+    for (int c = 0; c < V; ++c) tot += part[c][r][lane];
+    const size_t o = (size_t)(m0 + cf_acc_row(r, lane)) * g.N + n;
+    float v = tot * g.acc_scale + bias;
+    if (g.epilogue == CF_EPI_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (g.epilogue == CF_EPI_RESIDUAL) v += g.res[o];
+    g.out[o] = v;
+  }
+}
+
 // W' = scale * W as hi = f16(W'), lo = f16(W' - hi) in MFMA-operand order [K/16][N/32][hi, lo][lane 64][4 words]:
 // a lane's 16 bytes are the 8 halves of W'[n = tile*32 + (lane&31)][k = kstep*16 + (lane>>5)*8 + 0..7]
 __global__ void pack_linear_f16x2_kernel(const float* __restrict__ w, int N, int K, float scale, unsigned* __restrict__ packed, long total) {
@@ -358,8 +426,29 @@ int cf_gemm_split_launch(const cf_conv_desc* d, hipStream_t stream) {
   CF_REQUIRE(d->epilogue == CF_EPI_NONE || d->epilogue == CF_EPI_GELU || d->epilogue == CF_EPI_RESIDUAL,
              "cf_conv2d(1x1, f16x2): epilogues are none / GELU / residual");
   CF_REQUIRE(d->acc_scale > 0.f, "cf_conv2d(1x1, f16x2): acc_scale must be the inverse of the pack-time weight scale (got %g)", (double)d->acc_scale);
-  const int nsplit = d->split_k >= 1 ? d->split_k : 1;
   const int V = d->c0 / 128;
+  if (d->split_k == CF_SPLITK_IN_WORKGROUP) {   // few tokens: the chunks of a 32 x 32 tile shared by the waves of one workgroup (same bits)
+    CF_REQUIRE(V >= 1 && V <= GS_SMALL_MAXV && d->cout % 32 == 0 && ((long)d->batch * d->hout * d->wout) % 32 == 0,
+               "cf_conv2d(1x1, f16x2, in-workgroup split): K %d must be a multiple of 128 up to %d, M and N multiples of 32", d->c0, GS_SMALL_MAXV * 128);
+    GsArgs g;
+    g.a = d->in0;
+    g.w = d->weight;
+    g.bias = d->bias;
+    g.res = d->res;
+    g.out = d->out;
+    g.M = (int)((long)d->batch * d->hout * d->wout);
+    g.N = d->cout;
+    g.K = d->c0;
+    g.epilogue = d->epilogue;
+    g.acc_scale = d->acc_scale;
+    g.ws = nullptr;
+    g.counters = nullptr;
+    g.nsplit = 1;
+    hipLaunchKernelGGL(gemm_split_small_kernel, dim3((unsigned)((g.M / 32) * (g.N / 32))), dim3(256), 0, stream, g);
+    CF_CHECK_LAUNCH("cf_conv2d(1x1, f16x2, in-workgroup split)");
+    return CF_OK;
+  }
+  const int nsplit = d->split_k >= 1 ? d->split_k : 1;
   CF_REQUIRE(V % nsplit == 0, "cf_conv2d(1x1, f16x2): split_k %d must divide K/128 = %d", nsplit, V);
   CF_REQUIRE(nsplit == 1 || (d->workspace && d->counters), "cf_conv2d(1x1, f16x2): split_k > 1 needs workspace and counters");
   GsArgs g;

@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 20
+#define CF_ABI_VERSION 21
+#define CF_SPLITK_IN_WORKGROUP (-1) /* cf_conv_desc.split_k: see there (ABI v21) */
 
 typedef void* cf_stream_t; /* hipStream_t */
 
@@ -174,7 +175,10 @@ typedef struct cf_conv_desc {
    * `workspace`, the workgroup drawing the last ticket on counters[tile] adds them in split order (bitwise reproducible, independent of
    * arrival order) and runs the epilogue.  0 = off.  Supported: taps == 1 (64x64 tiles; also selects them with split_k == 1),
    * winograd, CF_OPERAND_F16X2.  workspace: cf_conv2d_workspace_bytes(d) bytes; counters: one zero-initialised uint32 per output
-   * tile (cf_conv2d_tiles(d)), left at zero by every launch. */
+   * tile (cf_conv2d_tiles(d)), left at zero by every launch.
+   * ABI v21: CF_SPLITK_IN_WORKGROUP (-1), taps == 1 with CF_OPERAND_F16X2 only (token GEMMs of one to a few faces): the K chunks of a
+   * 32 x 32 output tile are shared by the four waves of ONE workgroup and added in chunk order through LDS -- the same bits as every
+   * other split count, no workspace / counters (K <= 1024, M % 32 == 0, N % 32 == 0). */
   int32_t split_k;
   float* workspace;
   uint32_t* counters;

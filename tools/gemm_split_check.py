@@ -46,8 +46,10 @@ def case(M, K, N, epilogue=ops.EPI_NONE, bias=True, seed=0, timing=False, wscale
     same = True
     x4 = xc.view(M // 256, 16, 16, K)
     r4 = None if kw['res'] is None else kw['res'].view(M // 256, 16, 16, N)
-    for ns in (1, 2, 4, 8):
-        if (K // 128) % ns == 0:
+    for ns in (-1, 1, 2, 4, 8):    # (-1: the chunks shared by the waves of one workgroup, ABI v21)
+        if ns == -1 and K > 1024:
+            continue
+        if ns == -1 or (K // 128) % ns == 0:
             y = ops.conv2d(x4, pw_s, epilogue=epilogue, res=r4, split_k=ns).view(M, N)
             same = same and bool(torch.equal(y, ys))
     msg = f'M{M} K{K} N{N} epi{epilogue}: split max {es:.2e} | fp32 max {ef:.2e} (ref max {float(ref.abs().max()):.2f}) | split counts bitwise equal: {same}'
@@ -55,6 +57,11 @@ def case(M, K, N, epilogue=ops.EPI_NONE, bias=True, seed=0, timing=False, wscale
         ts_, tf_ = t_ms(lambda: ops.linear(xc, pw_s, **kw)), t_ms(lambda: ops.linear(xc, pw_f, **kw))
         fl = 2.0 * M * N * K
         msg += f' | split {ts_ * 1e3:.1f} us ({fl / ts_ / 1e9:.0f} TF-equiv) fp32 {tf_ * 1e3:.1f} us ({fl / tf_ / 1e9:.0f}) x{tf_ / ts_:.2f}'
+        per = {}
+        for ns in (-1, 1, 2, 4):
+            if (ns == -1 and K <= 1024) or (ns > 0 and (K // 128) % ns == 0):
+                per[ns] = t_ms(lambda: ops.conv2d(x4, pw_s, epilogue=epilogue, res=r4, split_k=ns)) * 1e3
+        msg += ' | us by split_k: ' + ' '.join(f'{k}:{v:.1f}' for k, v in per.items())
     print(msg, flush=True)
     return es, ef, float(ref.abs().max()), same
 

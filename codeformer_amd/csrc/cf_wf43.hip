@@ -3,8 +3,9 @@
 //   <PRO, EPI, 16, 32>  128 output channels per sixteen-wave workgroup on 32-channel slabs (see "The 16-wave form" at the end)
 //   <PRO, EPI, 16, 16>  the same on 16-channel slabs (cin % 32 != 0)
 //
-// Serves 3x3 stride-1 convolutions of GENERATOR and fusion (CFT) blocks (vqgan_arch.py:141-164,296-323, codeformer_arch.py:136-157) --
-// never the encoder, which decides the code indices and stays on F(2x2,3x3).
+// Serves 3x3 stride-1 convolutions of generator and fusion (CFT) blocks (vqgan_arch.py:141-164,296-323, codeformer_arch.py:136-157) and,
+// since round 5, the encoder's covered layers (vqgan_arch.py:243-262) -- the encoder decides the code indices, so that use sits behind a
+// measured logit-margin gate (tests/test_gpu_real_images.py::test_encoder_logit_margin).
 //
 //   Y = A^T [ (G g G^T) (.) (B^T d B) ] A      d: 6x6 input tile, g: 3x3 kernel, Y: 4x4 outputs
 // with the interpolation points (0, +-1/2, +-2, inf) -- the set with the smallest mean error among those tools/winograd_f43_numerics.py

@@ -164,8 +164,8 @@ typedef struct cf_conv_desc {
                              NHWC, zero padding, hout % 16 == 0, wout % 16 == 0, cout == cout_pad, cout % 64 == 0, cin % 16 == 0,
                              cin <= 256, an image of any of its tensors below 2^31 bytes; prologues / epilogues / statistics / act_scale as winograd 1, no split_k.  Its error
                              against fp64 is ~5x that of F(2x2,3x3) (the conditioning of the larger transform), far inside the
-                             1e-3 pixel gate but too close for layers that decide code indices: the host uses it for generator /
-                             CFT convolutions only (vqgan_arch.py:296-323, codeformer_arch.py:136-157), never in the encoder.
+                             1e-3 pixel gate; the host uses it for generator / CFT convolutions (vqgan_arch.py:296-323,
+                             codeformer_arch.py:136-157) and -- behind a measured logit-margin gate, round 5 -- for the encoder's covered layers.
                              ABI v20: also with CF_OPERAND_F32 (`weight` from cf_pack_conv_weight_winograd43; acc_scale / act_scale
                              unused, act_scale must be null): the same kernel with IEEE-fp32 operands on v_mfma_f32_16x16x4_f32 */
   float acc_scale;        /* CF_OPERAND_F16X2 only (direct or winograd): the accumulator is multiplied by this before the bias is added -- the exact

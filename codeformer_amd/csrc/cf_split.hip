@@ -111,6 +111,7 @@ struct SplitArgs {
   double* stats_out;
   int stats_cpg, nparts;
   int tiles_x, tiles_per_img, ntn;
+  int s2_skip;  // stride-2 form: 1 = skip the (tap, parity) steps whose weight block is zero by construction (C % 32 == 0)
 };
 
 template <int TAPS, int NI, int WM>
@@ -423,10 +424,26 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 && TAPS != 1 && !(S2 &
   constexpr int CONV_TAP = TAPS == 9 ? 4 : 2;
   if constexpr (TAPS != 1)
   for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+    // Stride-2 form (round 5): the slab holds 32 channels of ONE parity (p, q) of the space-to-depth view (C % 32 == 0); tap (ty, tx) of
+    // parity (p, q) is the 3x3 weight (2 ty + p, 2 tx + q), which does not exist for ty & p or tx & q: 7 of the 16 (tap, parity) blocks are
+    // zeros by construction.  Their steps keep the pipeline's shape (weight prefetch, ring rotation, barrier) and skip the fragment reads
+    // and the MFMAs: an exact zero is not added (x * 0 contributes nothing for finite x; a non-finite x still reaches the output through
+    // the tap of its parity that exists).
+    [[maybe_unused]] bool par_p = false, par_q = false;
+    if constexpr (S2) {
+      if (a.s2_skip) {
+        const int c = chunk * SP_KC;
+        par_p = c >= a.c0;
+        par_q = (par_p ? c - a.c0 : c) >= (a.c0 >> 1);
+      }
+    }
+    auto is_zero = [&](int tap) __attribute__((always_inline)) { return S2 && (((tap >> 1) && par_p) || ((tap & 1) && par_q)); };
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap, ++step) {
       const int slot1 = slot == 2 ? 0 : slot + 1;
       const int slot2 = slot1 == 2 ? 0 : slot1 + 1;
+      const bool zero_cur = is_zero(tap);                                // (wave-uniform)
+      const bool zero_next = tap != TAPS - 1 ? is_zero(tap + 1) : false;   // (the next slab's first tap always exists)
 #if !(SP_ABLATE & 2)
       load_B(step + 2 < nsteps ? step + 2 : nsteps - 1);  // clamped: the tail prefetches are harmless re-reads
 #endif
@@ -434,13 +451,13 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 && TAPS != 1 && !(S2 &
       if (tap == 0) load_A(ra, chunk + 1 < a.nchunks ? chunk + 1 : chunk);
 #endif
 #if !(SP_ABLATE & 8)
-      read_frags(fy, tap, slot, 1);
+      if (!zero_cur) read_frags(fy, tap, slot, 1);
 #endif
       constexpr int NMF = MI * NI * 3;  // MFMAs per half step
-      const bool weave = SP_WEAVE && NMF >= 2 * (MI + NI) + C::BPT && tap != CONV_TAP && tap != 0;
+      const bool weave = SP_WEAVE && !S2 && NMF >= 2 * (MI + NI) + C::BPT && tap != CONV_TAP && tap != 0;   // (the stride-2 form branches around its MFMA blocks: no weave)
       if (!weave) __builtin_amdgcn_sched_barrier(0);  // pin the fetches above the MFMA block (hipcc would sink them next to their use)
 #if !(SP_ABLATE & 32)
-      mma(fx);
+      if (!zero_cur) mma(fx);
 #endif
 #if !(SP_ABLATE & (64 | 128))
       if (tap == CONV_TAP) convert(ra);
@@ -463,10 +480,10 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 && TAPS != 1 && !(S2 &
       }
       __builtin_amdgcn_sched_barrier(0);
 #if !(SP_ABLATE & 8)
-      if (tap != TAPS - 1) read_frags(fx, tap + 1, slot1, 0);
+      if (tap != TAPS - 1 && !zero_next) read_frags(fx, tap + 1, slot1, 0);
 #endif
 #if !(SP_ABLATE & 32)
-      mma(fy);
+      if (!zero_cur) mma(fy);
 #endif
       if (!weave) __builtin_amdgcn_sched_barrier(0);
 #if !(SP_ABLATE & 4)
@@ -806,6 +823,11 @@ int cf_split_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query)
   a.tiles_per_img = (d->upsample ? 4 : 1) * a.tiles_x * (gh / TH);
   a.nparts = a.tiles_per_img * SP_WM;
   a.ntn = 0;
+  static const int s2_skip_on = [] {   // A/B only: CF_S2_SKIP=0 multiplies the zero blocks as rounds 3-4 did
+    const char* e = getenv("CF_S2_SKIP");
+    return e ? atoi(e) : 1;
+  }();
+  a.s2_skip = s2 && s2_skip_on && d->c0 % 32 == 0;
   if (parts_query) {
     *parts_query = a.nparts;
     return CF_OK;

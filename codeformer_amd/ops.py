@@ -67,7 +67,7 @@ WSPLIT = 6     # ... Winograd F(2x2,3x3) with split-half operands in the 16 tran
 GSPLIT = 7     # ... a Linear / 1x1 weight for the split-half token GEMM (cf_gemm_split.hip)
 WF16 = 8       # ... Winograd F(2x2,3x3) with SINGLE IEEE-half operands (eight-wave kernel of cf_wsplit.hip; precision 'fp16')
 WBF16 = 9      # ... the same with single bf16 operands (precision 'bf16')
-SPLIT_F43 = 10  # ... REQUEST: SPLIT, with Winograd F(4x4,3x3) where its kernel applies (generator / CFT layers only: ~5x the error of F(2,3))
+SPLIT_F43 = 10  # ... REQUEST: SPLIT, with Winograd F(4x4,3x3) where its kernel applies (~5x the error of F(2,3): generator / CFT layers, and the encoder behind its margin gate)
 WF43 = 11      # ... Winograd F(4x4,3x3) with split-half operands (cf_wf43.hip; cf_conv_desc.winograd = 2)
 WINOGRAD_F43 = 12   # ... REQUEST: WINOGRAD (exact fp32), with Winograd F(4x4,3x3) on fp32 operands where its kernel applies (generator / CFT only)
 WF43F = 13     # ... Winograd F(4x4,3x3) with IEEE-fp32 operands (cf_wf43.hip on v_mfma_f32_16x16x4_f32; winograd = 2, operand fp32)

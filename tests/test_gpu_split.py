@@ -356,6 +356,28 @@ def test_winograd_f43_forms_against_fp64(sc):
         assert torch.equal(y[1:2], y1) and torch.equal(y._cf_stats.part.view(3, -1)[1:2], y1._cf_stats.part.view(1, -1))
 
 
+def test_process_level_ab_forms_are_bitwise_equal(sc):
+    """Forms that a process-level switch selects (read once per process by the library): the overlapped 16-wave F(4,3) form (CF_F43_WIDE=ovl)
+    against the two-interval form on the same 16-channel slabs (=k16), split-half and fp32 operands, and the stride-2 form with / without its
+    zero (tap, parity) blocks (CF_S2_SKIP=1 / 0): digests of outputs + GroupNorm partials from sub-processes must agree."""
+    import re
+    import subprocess
+    import sys
+
+    def digests(script, env, *args):
+        e = dict(os.environ, **env)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', script), *args], capture_output=True, text=True, env=e, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = re.findall(r'digest .*', r.stdout)
+        assert len(d) >= 4 and all('False' not in x for x in d), r.stdout
+        return d
+
+    for extra in ((), ('fp32',)):
+        assert digests('f43_ovl_ab.py', {'CF_F43_WIDE': 'ovl', 'F43_AB_DIGESTS_ONLY': '1'}, *extra) == \
+            digests('f43_ovl_ab.py', {'CF_F43_WIDE': 'k16', 'F43_AB_DIGESTS_ONLY': '1'}, *extra)
+    assert digests('s2_skip_ab.py', {'CF_S2_SKIP': '1'}) == digests('s2_skip_ab.py', {'CF_S2_SKIP': '0'})
+
+
 def test_winograd_f43_fp32_operands_against_fp64(sc):
     """The same kernel with IEEE-fp32 operands (CF_OPERAND_F32 + winograd = 2, ABI v20: precision 'fp32' of the generator / fusion layers):
     the same cases and batch invariance, bound 4e-5 * max(|ref| / 4, 1) (measured 1.1-2.8e-5); no weight / activation scale is involved

@@ -1,5 +1,7 @@
+"""Stride-2 form of the split-half kernel: digests of outputs + GroupNorm partials on a few shapes (incl. one whose slabs mix parities: no skipping
+there).  CF_S2_SKIP=1 / 0 (read once per process by the library) must give the same digests.  GPU box only."""
 import hashlib, os, sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from codeformer_amd import ops
 g = torch.Generator(device='cuda').manual_seed(3)
 for C, H in ((64, 64), (128, 32), (256, 32), (48, 32)):

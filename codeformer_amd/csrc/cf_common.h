@@ -79,7 +79,11 @@ __device__ __forceinline__ void cf_split_pair(float x0, float x1, float& hi, flo
   hi = __builtin_bit_cast(float, h);
   float l;
   asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi), "v"(x0));
-  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(x1));
+  // `s_nop 1` INSIDE the string: hipcc pads nothing after inline asm, and a VGPR just written by a VALU instruction needs two wait states before
+  // an MFMA may read it as an operand (cdna_hip_programming.md 5.7 item 2).  Where `lo` goes straight into an MFMA (the token GEMMs, the
+  // four-wave Winograd kernel) the matrix instruction otherwise reads the stale register on some waves of some launches: found in round 5 on a
+  // build whose schedule put the MFMA directly behind this statement (wrong, non-repeatable lo products: errors of 2e-4).
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 1" : "+v"(l) : "v"(hi), "v"(x1));
   lo = l;
 }
 

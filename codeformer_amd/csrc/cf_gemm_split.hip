@@ -300,71 +300,110 @@ __global__ __launch_bounds__(256) void gemm_split_tile_kernel(const GsArgs g) {
   }
 }
 
-// ---- the same GEMM for FEW tokens (one to four faces; round 5): the K chunks of a 32 x 32 output tile are shared by the four waves of ONE
-// workgroup -- split_k == CF_SPLITK_IN_WORKGROUP (-1).  The cross-workgroup split above costs a launch of 128 workgroups two dependent
-// global phases (park + ticket, then the last arriver's ordered re-read: 16 us for 256 x 512 x 512); here wave w accumulates virtual
-// chunks w, w + 4, ... from zero (a whole chunk's sixteen A / sixteen B fragments requested at once: ONE L2 round trip per chunk), parks
-// each chunk sum in LDS, and after one barrier the 256 threads add the chunk sums IN CHUNK ORDER from zero and run the epilogue
-// expression of the kernels above.  Per output element that is their arithmetic exactly (k steps in order inside a chunk, lo*hi, hi*lo,
-// hi*hi per step; out = ((0 + P0) + P1) + ...), so all three kernels agree BITWISE and the host may choose by the number of tiles in
-// flight -- i.e. by the batch -- without touching batch invariance.  No workspace, no counters.
-constexpr int GS_SMALL_MAXV = 8;   // K <= 1024: chunk sums of a tile in LDS = V x 4 KB
-__global__ __launch_bounds__(256) void gemm_split_small_kernel(const GsArgs g) {
-  __shared__ __attribute__((aligned(16))) float part[GS_SMALL_MAXV][16][64];   // [chunk][accumulator register][lane]: 32 KB
+// ---- the same GEMM with the K chunks of an output tile shared by the four waves of ONE workgroup (round 5): split_k == CF_SPLITK_IN_WORKGROUP (-1).
+// The cross-workgroup split above costs a launch two dependent global phases (park + ticket, then the last arriver's ordered re-read: 16 us
+// for 256 x 512 x 512), and the token-tile kernel walks its sixteen 32-wide stages one L2 round trip after the other (27 us for 4096 x 512
+// x 512 at one wave per SIMD).  Here wave w accumulates virtual chunks w, w + 4, ... of a (32 MI) x (32 NI) tile from zero -- the operand
+// fragments of a whole chunk (MI = NI = 1) or of half a chunk (2 x 2) requested at once: one or two L2 round trips per chunk --, parks each
+// chunk sum in LDS, and after one barrier the 256 threads add the chunk sums IN CHUNK ORDER from zero and run the epilogue expression of the
+// kernels above.  Per output element that is their arithmetic exactly (k steps in order inside a chunk, lo*hi, hi*lo, hi*hi per step; out =
+// ((0 + P0) + P1) + ...), so all the kernels of this file agree BITWISE and the host may choose by the number of tiles in flight -- i.e.
+// by the batch -- without touching batch invariance.  No workspace, no counters.
+//   <1, 1>: 32 x 32 tiles -- the shipped instantiation, for launches of at most 2^20 outputs (one to four faces; at eight the N = 512 layers).
+#ifndef GS_CHUNK_PIN
+#define GS_CHUNK_PIN 1
+#endif
+constexpr int GS_CHUNK_MAXV = 8;   // K <= 1024: chunk sums of a tile in LDS = V x MI x NI x 4 KB
+template <int MI, int NI>
+__global__ __launch_bounds__(256, MI * NI == 1 ? 1 : 2) void gemm_split_chunk_kernel(const GsArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float gs_part[];   // [chunk][mi][ni][accumulator register][lane]
+  constexpr int HS = MI * NI == 1 ? 8 : 4;                          // k steps whose operands are in flight together
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
-  const int ntn = g.N >> 5;
+  const int ntn = g.N / (32 * NI);
   const int nt = blockIdx.x % ntn, mt = blockIdx.x / ntn;
-  const int m0 = mt * 32, n0 = nt * 32;
+  const int m0 = mt * (32 * MI), n0 = nt * (32 * NI);
   const int V = g.K >> 7;
   const float* const arow = g.a + (size_t)(m0 + l31) * g.K + half * 8;
   const size_t kstride = (size_t)(g.N >> 5) * 512;  // floats between consecutive k steps of the packed weights
-  const float* const wl = g.w + (size_t)nt * 512 + lane * 4;
+  const float* const wl = g.w + (size_t)(n0 >> 5) * 512 + lane * 4;
   for (int c = wave; c < V; c += 4) {
-    f32x4 ra[8][2], rb[8][2];
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const int ks = c * 8 + s;
-      ra[s][0] = *reinterpret_cast<const f32x4*>(arow + ks * 16);
-      ra[s][1] = *reinterpret_cast<const f32x4*>(arow + ks * 16 + 4);
-      rb[s][0] = *reinterpret_cast<const f32x4*>(wl + (size_t)ks * kstride);
-      rb[s][1] = *reinterpret_cast<const f32x4*>(wl + (size_t)ks * kstride + 256);
-    }
-    f32x16 acc;
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      f32x4 ah, al;
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const f32x4 v = ra[s][e >> 1];
-        float hh, ll;
-        cf_split_pair(v[(e & 1) * 2], v[(e & 1) * 2 + 1], hh, ll);
-        ah[e] = hh;
-        al[e] = ll;
+    for (int h = 0; h < 8 / HS; ++h) {
+      f32x4 ra[HS][MI][2], rb[HS][NI][2];
+#pragma unroll
+      for (int s = 0; s < HS; ++s) {
+        const int ks = c * 8 + h * HS + s;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          ra[s][mi][0] = *reinterpret_cast<const f32x4*>(arow + (size_t)(32 * mi) * g.K + ks * 16);
+          ra[s][mi][1] = *reinterpret_cast<const f32x4*>(arow + (size_t)(32 * mi) * g.K + ks * 16 + 4);
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          rb[s][ni][0] = *reinterpret_cast<const f32x4*>(wl + (size_t)ks * kstride + ni * 512);
+          rb[s][ni][1] = *reinterpret_cast<const f32x4*>(wl + (size_t)ks * kstride + ni * 512 + 256);
+        }
       }
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gs_f16x8, al), __builtin_bit_cast(gs_f16x8, rb[s][0]), acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gs_f16x8, ah), __builtin_bit_cast(gs_f16x8, rb[s][1]), acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gs_f16x8, ah), __builtin_bit_cast(gs_f16x8, rb[s][0]), acc, 0, 0, 0);
+#if GS_CHUNK_PIN
+      __builtin_amdgcn_sched_barrier(0);   // every request of the group above the first MFMA (hipcc otherwise sinks each load next to its use)
+#endif
+#pragma unroll
+      for (int s = 0; s < HS; ++s) {
+        f32x4 ah[MI], al[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const f32x4 v = ra[s][mi][e >> 1];
+            float hh, ll;
+            cf_split_pair(v[(e & 1) * 2], v[(e & 1) * 2 + 1], hh, ll);
+            ah[mi][e] = hh;
+            al[mi][e] = ll;
+          }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gs_f16x8, al[mi]), __builtin_bit_cast(gs_f16x8, rb[s][ni][0]), acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gs_f16x8, ah[mi]), __builtin_bit_cast(gs_f16x8, rb[s][ni][1]), acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gs_f16x8, ah[mi]), __builtin_bit_cast(gs_f16x8, rb[s][ni][0]), acc[mi][ni], 0, 0, 0);
+          }
+      }
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) part[c][r][lane] = acc[r];
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gs_part[(((c * MI + mi) * NI + ni) * 16 + r) * 64 + lane] = acc[mi][ni][r];
   }
   __syncthreads();
-  // thread t finishes accumulator registers (t >> 6) + 4 j of lane t & 63: column n0 + (lane & 31), rows cf_acc_row(r, lane)
-  const int n = n0 + l31;
-  const float bias = g.bias ? g.bias[n] : 0.f;
+  // thread t finishes accumulator registers (t >> 6) + 4 j of lane t & 63 of every tile: column n0 + 32 ni + (lane & 31), rows cf_acc_row(r, lane)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int r = wave + 4 * j;
-    float tot = 0.f;
-    for (int c = 0; c < V; ++c) tot += part[c][r][lane];
-    const size_t o = (size_t)(m0 + cf_acc_row(r, lane)) * g.N + n;
-    float v = tot * g.acc_scale + bias;
-    if (g.epilogue == CF_EPI_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-    if (g.epilogue == CF_EPI_RESIDUAL) v += g.res[o];
-    g.out[o] = v;
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = n0 + ni * 32 + l31;
+    const float bias = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = wave + 4 * j;
+        float tot = 0.f;
+        for (int c = 0; c < V; ++c) tot += gs_part[(((c * MI + mi) * NI + ni) * 16 + r) * 64 + lane];
+        const size_t o = (size_t)(m0 + mi * 32 + cf_acc_row(r, lane)) * g.N + n;
+        float v = tot * g.acc_scale + bias;
+        if (g.epilogue == CF_EPI_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        if (g.epilogue == CF_EPI_RESIDUAL) v += g.res[o];
+        g.out[o] = v;
+      }
   }
 }
 
@@ -427,16 +466,17 @@ int cf_gemm_split_launch(const cf_conv_desc* d, hipStream_t stream) {
              "cf_conv2d(1x1, f16x2): epilogues are none / GELU / residual");
   CF_REQUIRE(d->acc_scale > 0.f, "cf_conv2d(1x1, f16x2): acc_scale must be the inverse of the pack-time weight scale (got %g)", (double)d->acc_scale);
   const int V = d->c0 / 128;
-  if (d->split_k == CF_SPLITK_IN_WORKGROUP) {   // few tokens: the chunks of a 32 x 32 tile shared by the waves of one workgroup (same bits)
-    CF_REQUIRE(V >= 1 && V <= GS_SMALL_MAXV && d->cout % 32 == 0 && ((long)d->batch * d->hout * d->wout) % 32 == 0,
-               "cf_conv2d(1x1, f16x2, in-workgroup split): K %d must be a multiple of 128 up to %d, M and N multiples of 32", d->c0, GS_SMALL_MAXV * 128);
+  if (d->split_k == CF_SPLITK_IN_WORKGROUP) {   // the chunks of a tile shared by the waves of one workgroup (same bits)
+    const long m = (long)d->batch * d->hout * d->wout;
+    CF_REQUIRE(V >= 1 && V <= GS_CHUNK_MAXV && d->cout % 32 == 0 && m % 32 == 0,
+               "cf_conv2d(1x1, f16x2, in-workgroup split): K %d must be a multiple of 128 up to %d, M and N multiples of 32", d->c0, GS_CHUNK_MAXV * 128);
     GsArgs g;
     g.a = d->in0;
     g.w = d->weight;
     g.bias = d->bias;
     g.res = d->res;
     g.out = d->out;
-    g.M = (int)((long)d->batch * d->hout * d->wout);
+    g.M = (int)m;
     g.N = d->cout;
     g.K = d->c0;
     g.epilogue = d->epilogue;
@@ -444,7 +484,10 @@ int cf_gemm_split_launch(const cf_conv_desc* d, hipStream_t stream) {
     g.ws = nullptr;
     g.counters = nullptr;
     g.nsplit = 1;
-    hipLaunchKernelGGL(gemm_split_small_kernel, dim3((unsigned)((g.M / 32) * (g.N / 32))), dim3(256), 0, stream, g);
+    // (a 64 x 64-tile instantiation <2, 2> of the same kernel -- operands of half a chunk in flight -- was measured from 2048 rows up: 17.3 vs 15.2 us
+    //  at 2048 x 512 x 512, 23.4 vs the token-tile kernel's 23.5 us at 4096 rows: no gain, not instantiated; the host sends large launches to the tile kernel)
+    CF_LDS_ATTR((gemm_split_chunk_kernel<1, 1>), GS_CHUNK_MAXV * 4096);
+    hipLaunchKernelGGL((gemm_split_chunk_kernel<1, 1>), dim3((unsigned)((g.M / 32) * (g.N / 32))), dim3(256), (size_t)V * 4096, stream, g);
     CF_CHECK_LAUNCH("cf_conv2d(1x1, f16x2, in-workgroup split)");
     return CF_OK;
   }

@@ -186,7 +186,7 @@ HALF_LIMIT = 65504.0 / 4.0    # largest |activation| a Winograd-domain IEEE-half
 
 def switches():
     """The module-level A/B switches a captured forward depends on (part of the graph-replay key of the arch modules)."""
-    return (SPLIT_WINOGRAD, F43_LAYERS, F43_WIDE_MIN_PIXELS, F43_WIDE_MIN_PIXELS_FP32, WINOGRAD_16BIT, RANGE_SCALE, ACT_FUSED, SPLITK_MAX, GEMM_IN_WG_MAX_ROWS)
+    return (SPLIT_WINOGRAD, F43_LAYERS, F43_WIDE_MIN_PIXELS, F43_WIDE_MIN_PIXELS_FP32, WINOGRAD_16BIT, RANGE_SCALE, ACT_FUSED, SPLITK_MAX, GEMM_IN_WG_MAX_OUTPUTS)
 
 
 def needs_act_scale(pw):
@@ -412,10 +412,12 @@ def _nhwc_ld(t, what):
 # not change the result (see cf_common.h).  CODEFORMER_HIP_SPLITK = largest split count (0: layers keep the large-tile kernel).
 SPLITK_MAX = int(os.environ.get('CODEFORMER_HIP_SPLITK', '8'))
 SPLITK_IN_WORKGROUP = -1    # CF_SPLITK_IN_WORKGROUP of the header (ABI v21): split-half token GEMMs of one to a few faces
-# Token GEMMs (split-half operands) of at most this many rows take the in-workgroup split: one to four faces (256 tokens each).  Measured in
-# the network (tools/latency.py, graph replay, one box): one face 6.71 -> 6.35 ms, two 8.34 -> 7.93, four 11.66 -> 11.38 -- the 46 launches
-# lose the park / ticket / ordered re-read of the cross-workgroup split; from eight faces up the tiled kernel runs (4096 rows: 47 vs 28 us).
-GEMM_IN_WG_MAX_ROWS = int(os.environ.get('CODEFORMER_HIP_GEMM_IN_WG_ROWS', '1024'))
+# Token GEMMs (split-half operands) of at most this many OUTPUTS (rows x columns) take the in-workgroup split: one to four faces (256 tokens
+# each) for every layer, eight faces for the 512-column layers.  Measured per launch inside a captured graph (tools/gemm_chunk_probe.py):
+# 256 x 512 x 512: 5.6 us against 15.0 (cross-workgroup split), 1024 x 512 x 1024: 13.9 / 17.2, 2048 x 1024 x 512: 22.3 / 30.2 -- and 4096 x 512 x
+# 1024: 34.1 against 26.7 for the token-tile kernel, which keeps the large launches.  In the network (tools/latency.py, graph replay, one
+# box): one face 6.71 -> 6.35 ms, two 8.34 -> 7.93, four 11.66 -> 11.38.
+GEMM_IN_WG_MAX_OUTPUTS = int(os.environ.get('CODEFORMER_HIP_GEMM_IN_WG_OUTPUTS', str(1 << 20)))
 _COUNTERS = {}
 
 
@@ -430,7 +432,7 @@ def splitk_for(pw, ho, wo, cin, batch=1):
             return 0
         tiles = batch * (ho // 8) * (wo // 16) * (pw.cout_pad // 64)
     elif pw.taps == 1 and (ho * wo) % 64 == 0 and pw.cout_pad % 64 == 0:
-        if int(pw.bf16) == OPERAND_F16X2 and not pw.conv1 and batch * ho * wo <= GEMM_IN_WG_MAX_ROWS and cin <= 1024:
+        if int(pw.bf16) == OPERAND_F16X2 and not pw.conv1 and batch * ho * wo * pw.cout_pad <= GEMM_IN_WG_MAX_OUTPUTS and cin <= 1024:
             return SPLITK_IN_WORKGROUP   # few tokens: the chunks of a 32x32 tile shared by the waves of one workgroup (cf_gemm_split.hip: same bits)
         tiles = batch * (ho * wo // 64) * (pw.cout_pad // 64)
     else:

@@ -91,11 +91,14 @@ def test_kernel_selection_host_rules():
     assert [ops.splitk_for(lin, 16, 16, 512, b) for b in (1, 2, 4, 8, 16)] == [4, 2, 1, 1, 1]
     assert [ops.splitk_for(lin1024, 16, 16, 1024, b) for b in (1, 2, 4, 16)] == [4, 2, 1, 1]
     assert ops.splitk_for(lin, 64, 64, 512, 1) == 0 and ops.splitk_for(lin, 16, 16, 320, 1) == 0
-    # split-half token GEMMs of one to four faces (<= 1024 rows, K <= 1024): the in-workgroup split (ABI v21: same bits, no workspace)
+    # split-half token GEMMs of at most 2^20 outputs and K <= 1024 -- one to four faces, eight for the 512-column layers: the in-workgroup
+    # split (ABI v21: same bits, no workspace)
     glin = ops.PackedWeight(None, None, 512, 512, 1, 512, 512, bf16=ops.OPERAND_F16X2)
-    glin1024 = ops.PackedWeight(None, None, 512, 1024, 1, 512, 1024, bf16=ops.OPERAND_F16X2)
-    assert [ops.splitk_for(glin, 16, 16, 512, b) for b in (1, 2, 4, 8, 16)] == [ops.SPLITK_IN_WORKGROUP] * 3 + [1, 1]
-    assert [ops.splitk_for(glin1024, 16, 16, 1024, b) for b in (1, 4, 8)] == [ops.SPLITK_IN_WORKGROUP, ops.SPLITK_IN_WORKGROUP, 1]
+    glin1024 = ops.PackedWeight(None, None, 512, 1024, 1, 512, 1024, bf16=ops.OPERAND_F16X2)          # 1024 -> 512 (MLP-down)
+    gup = ops.PackedWeight(None, None, 1024, 512, 1, 1024, 512, bf16=ops.OPERAND_F16X2)               # 512 -> 1024 (q|k, MLP-up)
+    assert [ops.splitk_for(glin, 16, 16, 512, b) for b in (1, 2, 4, 8, 16)] == [ops.SPLITK_IN_WORKGROUP] * 4 + [1]
+    assert [ops.splitk_for(glin1024, 16, 16, 1024, b) for b in (1, 4, 8, 16)] == [ops.SPLITK_IN_WORKGROUP] * 3 + [1]
+    assert [ops.splitk_for(gup, 16, 16, 512, b) for b in (1, 4, 8)] == [ops.SPLITK_IN_WORKGROUP, ops.SPLITK_IN_WORKGROUP, 1]
     assert ops.splitk_for(ops.PackedWeight(None, None, 512, 2048, 1, 512, 2048, bf16=ops.OPERAND_F16X2), 16, 16, 2048, 1) == 4
     # Winograd latents: at most 256 workgroups; 16 faces -> one workgroup per tile
     wino = ops.PackedWeight(None, None, 512, 512, 9, 512, 512, bf16=ops.OPERAND_F16X2, wino=True)

@@ -87,6 +87,17 @@ __device__ __forceinline__ void cf_split_pair(float x0, float x1, float& hi, flo
   lo = l;
 }
 
+// Output stores of the big epilogues: non-temporal when the launch's output tensor is larger than anything the caches keep for the
+// next launch (CF_NT_STORE_BYTES; round 5: the first conv 0.42 -> 0.34 ms, the 64-channel 512x512 F(4,3) layers -1..3 %, 128-channel
+// 128x128 -5 %: no write-allocate traffic through L2).  A host decision per launch (tensor bytes), never a change of the stored bits;
+// one-face calls stay below the threshold, where the next kernel still finds its input in the Infinity Cache.
+constexpr long CF_NT_STORE_BYTES = 100L << 20;
+bool cf_nt_store(long out_bytes);   // cf_misc.hip: out_bytes >= the threshold (CF_NT_STORE_MB in the environment overrides it; 0 = never)
+__device__ __forceinline__ void cf_store16(float* p, f32x4 v, bool nt) {
+  if (nt) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+  else *reinterpret_cast<f32x4*>(p) = v;
+}
+
 // Row of accumulator register r (0..15) of a 32x32 MFMA tile held by `lane`; the column is lane&31.
 __device__ __forceinline__ int cf_acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 

@@ -70,6 +70,7 @@ struct ConvArgsExt : ConvArgs {
   int ld0, ld1, ldo;  // channel strides of in0 / in1 / out (and res, res2)
   int pad_mode;       // CF_PAD_ZERO / CF_PAD_REFLECT (3x3) / CF_PAD_EDGE (folded upsample)
   int pad_lo;         // stride 2: rows / columns of padding on the top / left (0 = CodeFormer Downsample, 1 = symmetric)
+  int nt_out;         // non-temporal output stores (the first conv; cf_common.h: cf_store16)
 };
 // border handling of the gather for the EXT instantiations: coordinate remap instead of zero fill
 __device__ __forceinline__ int cf_border(int i, int n, int mode) {
@@ -949,47 +950,66 @@ __global__ __launch_bounds__(256) void conv3x3_few_cout_kernel(const ConvArgsExt
   }
   const int py = tid >> 4, px = tid & 15;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-    const int c = chunk * CF_BK + k4 * 4;
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (a.prologue == CF_PRO_AFFINE || a.prologue == CF_PRO_AFFINE_SWISH) {
-      sc = *reinterpret_cast<const f32x4*>(a.pro_scale + (size_t)b * a.cin + c);
-      sh = *reinterpret_cast<const f32x4*>(a.pro_shift + (size_t)b * a.cin + c);
+  const bool affine = a.prologue == CF_PRO_AFFINE || a.prologue == CF_PRO_AFFINE_SWISH;
+  // Two 16-channel slabs per gather (round 5).  The slab of a pixel is 64 bytes -- half a 128-byte line -- and with one slab per pass the
+  // other half was requested a whole tap loop later, when the line had left the L2 (counters: 2.2x the tensor's bytes from HBM); and the
+  // loads sat under the per-item validity branch, so each was waited for before the next was issued.  Now both halves of a line are
+  // requested together, unconditionally from clamped addresses (out-of-image items are zeroed at the store), the second slab waits in
+  // registers while the first is multiplied: the LDS footprint -- what sets the six resident workgroups per CU -- is unchanged, and so is
+  // the accumulation order (slab, tap, channel): bitwise the same output.
+  for (int chunk = 0; chunk < a.nchunks; chunk += 2) {
+    const bool two = chunk + 1 < a.nchunks;
+    f32x4 raw[2][APT], sc[2], sh[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = (two || u == 0 ? chunk + u : chunk) * CF_BK + k4 * 4;
+      sc[u] = f32x4{1.f, 1.f, 1.f, 1.f};
+      sh[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (affine) {
+        sc[u] = *reinterpret_cast<const f32x4*>(a.pro_scale + (size_t)b * a.cin + c);
+        sh[u] = *reinterpret_cast<const f32x4*>(a.pro_shift + (size_t)b * a.cin + c);
+      }
+#pragma unroll
+      for (int j = 0; j < APT; ++j) {
+        const size_t pj = pix[j] < 0 ? (size_t)b * a.hin * a.win : (size_t)pix[j];   // (clamped: any pixel of this image)
+        raw[u][j] = *reinterpret_cast<const f32x4*>(a.in0 + pj * a.c0 + c);
+      }
     }
 #pragma unroll
-    for (int j = 0; j < APT; ++j) {
-      const int p = (tid >> 2) + 64 * j;
-      if (p < NPIX) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (pix[j] >= 0) {
-          v = *reinterpret_cast<const f32x4*>(a.in0 + (size_t)pix[j] * a.c0 + c);
+    for (int u = 0; u < 2; ++u) {
+      if (u == 1 && !two) break;
+#pragma unroll
+      for (int j = 0; j < APT; ++j) {
+        const int p = (tid >> 2) + 64 * j;
+        if (p < NPIX) {
+          f32x4 v = raw[u][j];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            float y = v[e] * sc[e] + sh[e];
+            float y = v[e] * sc[u][e] + sh[u][e];
             if (a.prologue == CF_PRO_AFFINE_SWISH) y = swishf(y);
             if (a.prologue == CF_PRO_LEAKY) y = v[e] > 0.f ? v[e] : 0.2f * v[e];
-            v[e] = y;
+            v[e] = pix[j] >= 0 ? y : 0.f;
           }
+          *reinterpret_cast<f32x4*>(As + p * CF_LDK + k4 * 4) = v;
         }
-        *reinterpret_cast<f32x4*>(As + p * CF_LDK + k4 * 4) = v;
       }
-    }
-    __syncthreads();
+      __syncthreads();
 #pragma unroll 1  // one tap's 64 weights fit the scalar registers; unrolling all nine spills them
-    for (int tap = 0; tap < 9; ++tap) {
-      const float* ap = As + ((py + tap / 3) * HWD + px + tap % 3) * CF_LDK;
-      const float* wp = a.weight + (size_t)(tap * a.nchunks + chunk) * a.cout_pad * CF_BK;  // [cout_pad][16], wave-uniform
+      for (int tap = 0; tap < 9; ++tap) {
+        const float* ap = As + ((py + tap / 3) * HWD + px + tap % 3) * CF_LDK;
+        const float* wp = a.weight + (size_t)(tap * a.nchunks + chunk + u) * a.cout_pad * CF_BK;  // [cout_pad][16], wave-uniform
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + q * 4);
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(ap + q * 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+          for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int co = 0; co < NCO; ++co)  // (NCO = 4: rows >= cout of the packed weight are zero padding, no branch needed)
-            acc[co] = fmaf(av[e], wp[co * CF_BK + q * 4 + e], acc[co]);
+            for (int co = 0; co < NCO; ++co)  // (NCO = 4: rows >= cout of the packed weight are zero padding, no branch needed)
+              acc[co] = fmaf(av[e], wp[co * CF_BK + q * 4 + e], acc[co]);
+        }
       }
+      __syncthreads();
     }
-    __syncthreads();
   }
   const int oy = y0 + py, ox = x0 + px;
 #pragma unroll
@@ -1008,6 +1028,9 @@ __global__ __launch_bounds__(256) void conv3x3_few_cout_kernel(const ConvArgsExt
 // the thread keeps the 27 float4 weight rows of ITS channel quad in registers for all sixteen pixels it computes: the LDS-resident
 // weights cost one ds_read_b128 per tap and pixel, 3456 LDS wave-instructions per tile = 0.31 of the kernel's 0.39 ms per 16 faces.
 // The FMA chain (channel-major, then taps) and with it every bit of the output is unchanged.
+#ifndef FC_ABLATE   // timing-only ablations of the first conv: 1 no output store, 2 one tap instead of 27
+#define FC_ABLATE 0
+#endif
 template <int C0>
 __global__ __launch_bounds__(256) void conv3x3_few_cin_kernel(const ConvArgsExt a) {
   __shared__ float s_in[4][18 * 18];
@@ -1042,6 +1065,7 @@ __global__ __launch_bounds__(256) void conv3x3_few_cin_kernel(const ConvArgsExt 
   f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
   if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + n);
   float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool nt_out = a.nt_out != 0;   // (cf_common.h: cf_store16)
 #pragma unroll 4
   for (int round = 0; round < 16; ++round) {
     const int p = round * 16 + slot, py = p >> 4, px = p & 15;
@@ -1051,6 +1075,9 @@ __global__ __launch_bounds__(256) void conv3x3_few_cin_kernel(const ConvArgsExt 
       for (int c = 0; c < C0; ++c) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
+#if FC_ABLATE & 2
+          if (tap || c) continue;
+#endif
           const float v = s_in[c][(py + tap / 3) * 18 + px + tap % 3];
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[e] = fmaf(v, wreg[c * 9 + tap][e], acc[e]);
@@ -1067,7 +1094,9 @@ __global__ __launch_bounds__(256) void conv3x3_few_cin_kernel(const ConvArgsExt 
         }
       }
     }
-    *reinterpret_cast<f32x4*>(a.out + (((size_t)b * a.hout + (y0 + py)) * a.wout + (x0 + px)) * a.cout + n) = acc;
+#if !(FC_ABLATE & 1)
+    cf_store16(a.out + (((size_t)b * a.hout + (y0 + py)) * a.wout + (x0 + px)) * a.cout + n, acc, nt_out);
+#endif
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       ssum[e] += acc[e];
@@ -1435,6 +1464,7 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
   a.ldo = ldo;
   a.pad_mode = d->pad_mode;
   a.pad_lo = d->pad_lo;
+  a.nt_out = cf_nt_store((long)d->batch * d->hout * d->wout * d->cout * 4);
 
   const int cp = d->cout_pad;
   // Small-M layers (16x16 / 32x32 latents): at batch 16 a 128x128 tiling yields only 128-256 workgroups for 256 CUs;

@@ -2,6 +2,8 @@
 // nearest-code argmin, layout converters, the u8<->tensor boundary, and the two bundled StyleGAN2 ops.
 #include <stdarg.h>
 
+#include <cstdlib>
+
 #include "cf_common.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -46,6 +48,14 @@ extern "C" int cf_device_init(void) {
     }
   }
   return CF_OK;
+}
+bool cf_nt_store(long out_bytes) {
+  static const long threshold = [] {
+    const char* e = getenv("CF_NT_STORE_MB");
+    const long mb = e ? atol(e) : -1;
+    return mb < 0 ? CF_NT_STORE_BYTES : (mb == 0 ? (1L << 62) : mb << 20);
+  }();
+  return out_bytes >= threshold;
 }
 extern "C" int cf_device_cu_count(void) {
   int dev = 0, n = 0;

@@ -111,6 +111,7 @@ struct SplitArgs {
   double* stats_out;
   int stats_cpg, nparts;
   int tiles_x, tiles_per_img, ntn;
+  int nt_out;   // non-temporal output stores (cf_common.h: cf_store16)
   int s2_skip;  // stride-2 form: 1 = skip the (tap, parity) steps whose weight block is zero by construction (C % 32 == 0)
 };
 
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 && TAPS != 1 && !(S2 &
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = r0[mi][p][e] + a.sft_w * (r0[mi][p][e] * r1[mi][p][e] + v[e]);
         }
-        *reinterpret_cast<f32x4*>(a.out + offs[mi][p]) = v;
+        cf_store16(a.out + offs[mi][p], v, a.nt_out != 0);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           ssum[e] += v[e];
@@ -828,6 +829,7 @@ int cf_split_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query)
     return e ? atoi(e) : 1;
   }();
   a.s2_skip = s2 && s2_skip_on && d->c0 % 32 == 0;
+  a.nt_out = cf_nt_store((long)d->batch * d->hout * d->wout * d->cout * 4);
   if (parts_query) {
     *parts_query = a.nparts;
     return CF_OK;

@@ -139,8 +139,10 @@ __device__ __forceinline__ f32x4 f4_ld128(__amdgpu_buffer_rsrc_t r, unsigned vof
 __device__ __forceinline__ f4_f32x2 f4_ld64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(f4_f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
 }
-__device__ __forceinline__ void f4_st64(f4_f32x2 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(f4_u32x2, v), r, (int)voff, (int)soff, 0);
+__device__ __forceinline__ void f4_st64(f4_f32x2 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, bool nt) {
+  // (the cache-policy bits are an immediate: two instructions under a wave-uniform condition; aux 2 = nt, cf_common.h: cf_store16)
+  if (nt) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(f4_u32x2, v), r, (int)voff, (int)soff, 2);
+  else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(f4_u32x2, v), r, (int)voff, (int)soff, 0);
 }
 
 struct F4Args {
@@ -163,6 +165,7 @@ struct F4Args {
   double* stats_out;
   int stats_cpg, nparts;
   int tiles_x, tiles_per_img, ntn;
+  int nt_out;   // non-temporal output stores (cf_common.h: cf_store16)
 };
 
 // quad swizzle of V: tile row ty -> 0, 2, 3, 1
@@ -1004,7 +1007,7 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
         f4_f32x2 v = o[aa][c] * acc_s + bias2;
         if (EPI == CF_EPI_RESIDUAL) v += r0[aa][c];
         else if (EPI == CF_EPI_SFT) v = r0[aa][c] + a.sft_w * (r0[aa][c] * r1[aa][c] + v);
-        f4_st64(v, rs_out, voff0, soff0 + aa * e_rowc + c * e_px);
+        f4_st64(v, rs_out, voff0, soff0 + aa * e_rowc + c * e_px, a.nt_out != 0);
         rs += v;
         rq += v * v;
       }
@@ -1239,6 +1242,7 @@ int cf_wf43_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query) 
   const bool ovl = wide && f4_wide_mode() == 2;                             // ... or on 16-channel slabs with the transform under the weight stream
   CF_REQUIRE(!k32 || d->c0 % 32 == 0, "cf_conv2d(winograd 2): with cout %% 128 == 0 and cin %% 32 == 0 the concat boundary must be a multiple of 32 (c0 = %d)", d->c0);
   a.ntn = d->cout / (wide ? 128 : 64);
+  a.nt_out = cf_nt_store((long)d->batch * d->hout * d->wout * d->cout * 4);
   if (parts_query) {
     *parts_query = a.nparts;
     return CF_OK;

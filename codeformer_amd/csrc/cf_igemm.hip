@@ -1031,7 +1031,7 @@ __global__ __launch_bounds__(256) void conv3x3_few_cout_kernel(const ConvArgsExt
 #ifndef FC_ABLATE   // timing-only ablations of the first conv: 1 no output store, 2 one tap instead of 27
 #define FC_ABLATE 0
 #endif
-template <int C0>
+template <int C0, bool NT = false>   // NT: non-temporal output stores (cf_common.h: cf_store16; a compile-time choice here -- sixteen stores per thread)
 __global__ __launch_bounds__(256) void conv3x3_few_cin_kernel(const ConvArgsExt a) {
   __shared__ float s_in[4][18 * 18];
   __shared__ __attribute__((aligned(16))) float s_w[36][64];  // [tap * 4 + c][n]
@@ -1065,7 +1065,6 @@ __global__ __launch_bounds__(256) void conv3x3_few_cin_kernel(const ConvArgsExt 
   f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
   if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + n);
   float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
-  const bool nt_out = a.nt_out != 0;   // (cf_common.h: cf_store16)
 #pragma unroll 4
   for (int round = 0; round < 16; ++round) {
     const int p = round * 16 + slot, py = p >> 4, px = p & 15;
@@ -1095,7 +1094,7 @@ __global__ __launch_bounds__(256) void conv3x3_few_cin_kernel(const ConvArgsExt 
       }
     }
 #if !(FC_ABLATE & 1)
-    cf_store16(a.out + (((size_t)b * a.hout + (y0 + py)) * a.wout + (x0 + px)) * a.cout + n, acc, nt_out);
+    cf_store16(a.out + (((size_t)b * a.hout + (y0 + py)) * a.wout + (x0 + px)) * a.cout + n, acc, NT);
 #endif
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -1526,7 +1525,8 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
         *pq = a.nparts;
         return CF_OK;
       }
-      if (d->c0 == 3) hipLaunchKernelGGL(conv3x3_few_cin_kernel<3>, dim3(a.tiles_per_img * d->batch), dim3(256), 0, stream, a);
+      if (d->c0 == 3 && a.nt_out) hipLaunchKernelGGL((conv3x3_few_cin_kernel<3, true>), dim3(a.tiles_per_img * d->batch), dim3(256), 0, stream, a);
+      else if (d->c0 == 3) hipLaunchKernelGGL(conv3x3_few_cin_kernel<3>, dim3(a.tiles_per_img * d->batch), dim3(256), 0, stream, a);
       else hipLaunchKernelGGL(conv3x3_few_cin_kernel<0>, dim3(a.tiles_per_img * d->batch), dim3(256), 0, stream, a);
       CF_CHECK_LAUNCH("cf_conv2d");
       return CF_OK;

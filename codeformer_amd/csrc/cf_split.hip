@@ -611,12 +611,20 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 && TAPS != 1 && !(S2 &
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = r0[mi][p][e] + a.sft_w * (r0[mi][p][e] * r1[mi][p][e] + v[e]);
         }
-        cf_store16(a.out + offs[mi][p], v, a.nt_out != 0);
+        t[p] = v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           ssum[e] += v[e];
           ssq[e] += v[e] * v[e];
         }
+      }
+      // (one wave-uniform choice of the stores' cache policy per 32-row block, not per store: cf_common.h cf_store16, cf_wf43.hip)
+      if (a.nt_out) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) __builtin_nontemporal_store(t[p], reinterpret_cast<f32x4*>(a.out + offs[mi][p]));
+      } else {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) *reinterpret_cast<f32x4*>(a.out + offs[mi][p]) = t[p];
       }
       __builtin_amdgcn_wave_barrier();  // the staging rows are rewritten by the next 32-row block
     }

@@ -136,13 +136,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t f4_rsrc(const void* p, unsigne
 __device__ __forceinline__ f32x4 f4_ld128(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
+#ifndef F4_RES_AUX   // A/B: cache-policy bits of the epilogue's residual / SFT operand loads (2 = nt: read once)
+#define F4_RES_AUX 0
+#endif
 __device__ __forceinline__ f4_f32x2 f4_ld64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  return __builtin_bit_cast(f4_f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+  return __builtin_bit_cast(f4_f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, F4_RES_AUX));
 }
-__device__ __forceinline__ void f4_st64(f4_f32x2 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, bool nt) {
-  // (the cache-policy bits are an immediate: two instructions under a wave-uniform condition; aux 2 = nt, cf_common.h: cf_store16)
-  if (nt) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(f4_u32x2, v), r, (int)voff, (int)soff, 2);
-  else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(f4_u32x2, v), r, (int)voff, (int)soff, 0);
+__device__ __forceinline__ void f4_st64(f4_f32x2 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(f4_u32x2, v), r, (int)voff, (int)soff, 0);
 }
 
 struct F4Args {
@@ -1007,7 +1008,7 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
         f4_f32x2 v = o[aa][c] * acc_s + bias2;
         if (EPI == CF_EPI_RESIDUAL) v += r0[aa][c];
         else if (EPI == CF_EPI_SFT) v = r0[aa][c] + a.sft_w * (r0[aa][c] * r1[aa][c] + v);
-        f4_st64(v, rs_out, voff0, soff0 + aa * e_rowc + c * e_px, a.nt_out != 0);
+        o[aa][c] = v;   // (stored below: the eight stores of a pass sit behind ONE wave-uniform choice of their cache policy)
         rs += v;
         rq += v * v;
       }
@@ -1015,6 +1016,21 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
       dsq += (double)rq[0];
       dsum1 += (double)rs[1];
       dsq1 += (double)rq[1];
+    }
+    // Output stores, non-temporal for outputs no cache keeps (cf_common.h: cf_store16).  The policy bits are an immediate of the store, so
+    // there are two copies of the block behind one branch per pass -- a branch per store made hipcc wait for every load in flight at each of
+    // them (whole step 444 -> 403 faces/s on one box before this form).
+    if (a.nt_out) {
+#pragma unroll
+      for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(f4_u32x2, o[aa][c]), rs_out, (int)voff0, (int)(soff0 + aa * e_rowc + c * e_px), 2);
+    } else {
+#pragma unroll
+      for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) f4_st64(o[aa][c], rs_out, voff0, soff0 + aa * e_rowc + c * e_px);
     }
     if (a.stats_out) {
       // GroupNorm statistics of the values this wave wrote in this pass (one tile x 64 channels): fp64, fixed shuffle order; the two

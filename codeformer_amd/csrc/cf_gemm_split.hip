@@ -407,6 +407,144 @@ __global__ __launch_bounds__(256, MI * NI == 1 ? 1 : 2) void gemm_split_chunk_ke
   }
 }
 
+// ---- the token-tile GEMM with IEEE-fp32 operands (round 6; precision 'fp32': the Transformer's Linear layers of BASELINE config 2 to the letter)
+// The fp32 split-K instantiation of cf_igemm.hip (64 x 64 tiles, wave tile 32 x 32, both operands through 3-deep LDS rings, one barrier per
+// 16-wide slab = per 8 MFMAs of a wave) runs 4096 x 512 x 512 in 46 us -- latency between barriers, not matrix work (13.7 us at the fp32 MFMA
+// peak).  Here the structure of gemm_split_tile_kernel: 128 tokens x 64 columns per workgroup, a wave owns 64 tokens x 32 columns (two MFMA
+// tiles), the token tile of a 32-wide stage staged once through LDS in operand order (conflict-free ds_read_b128, double-buffered, one
+// barrier per stage = per 32 MFMAs of a wave), weight fragments straight from L2 in the fp32 packing of cf_pack_conv_weight
+// ([K/16][N][16]: a lane's 16 bytes are W[n][16 slab + 8 kg + 4 (lane >> 5) .. + 3]), three stages ahead in registers.
+// Per output element the arithmetic is that of the split-K instantiation with one workgroup per tile -- virtual chunks of 128 K values
+// accumulated from zero on v_mfma_f32_32x32x2_f32 in slab order, k group 0 then 1, j = 0..3 (cf_mma_slab's operand convention), chunk sums
+// added in chunk order, the same epilogue expression -- so the two agree BITWISE and the host may choose by the batch (this one: M % 128 == 0,
+// one workgroup per tile) without touching batch invariance.
+__global__ __launch_bounds__(256) void gemm_f32_tile_kernel(const GsArgs g) {
+  __shared__ __attribute__((aligned(16))) float As[2][2][128][16];  // [buffer][16-wide slab of the stage][row][16 words]: 32 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int ntn = g.N / 64;
+  const int nt = blockIdx.x % ntn, mt = blockIdx.x / ntn;
+  const int m0 = mt * 128, n0 = nt * 64 + wn * 32;
+  const int nst = g.K >> 5;  // stages of 32 K values
+
+  // staging: item j of this thread is float4 #q of row (tid >> 3) + 32 j of the tile's stage (k = 4 q .. 4 q + 3)
+  const float* const asrc = g.a + (size_t)(m0 + (tid >> 3)) * g.K + (tid & 7) * 4;
+  f32x4 rg[4][4];
+  auto load_stage = [&](int st, auto buf) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(buf)::value;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rg[BUF][j] = *reinterpret_cast<const f32x4*>(asrc + (size_t)(32 * j) * g.K + st * 32);
+  };
+  auto store_stage = [&](int lbuf, auto buf) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(buf)::value;
+    const int q = tid & 7, ks = q >> 2, ch = q & 3;   // 16-byte chunk ch of slab ks: k group ch >> 1, lane half ch & 1
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = (tid >> 3) + 32 * j;
+      *reinterpret_cast<f32x4*>(&As[lbuf][ks][row][(ch ^ ((row >> 2) & 3)) << 2]) = rg[BUF][j];
+    }
+  };
+  // weights: [K/16][N_pad][16] floats (g.acc_scale carries nothing here; N_pad == N is checked by the launch)
+  const float* const wl = g.w + (size_t)(n0 + l31) * 16 + half * 4;
+  const size_t kstride = (size_t)g.N * 16;  // floats between consecutive 16-wide slabs
+  f32x4 rb[4][2][2];  // [ring slot][slab of the stage][k group]
+  auto load_B = [&](int st, auto buf) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(buf)::value;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const float* p = wl + (size_t)(st * 2 + s) * kstride;
+      rb[BUF][s][0] = *reinterpret_cast<const f32x4*>(p);
+      rb[BUF][s][1] = *reinterpret_cast<const f32x4*>(p + 8);
+    }
+  };
+  f32x16 acc[2], tot[2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mi][r] = tot[mi][r] = 0.f;
+  auto compute = [&](int lbuf, auto buf) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(buf)::value;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      f32x4 a0[2], a1[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int row = wm * 64 + mi * 32 + l31;
+        const int swz = (row >> 2) & 3;
+        a0[mi] = *reinterpret_cast<const f32x4*>(&As[lbuf][s][row][(half ^ swz) << 2]);
+        a1[mi] = *reinterpret_cast<const f32x4*>(&As[lbuf][s][row][((2 + half) ^ swz) << 2]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[mi][j], rb[BUF][s][0][j], acc[mi], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[mi][j], rb[BUF][s][1][j], acc[mi], 0, 0, 0);
+    }
+  };
+  using R0 = std::integral_constant<int, 0>;
+  using R1 = std::integral_constant<int, 1>;
+  using R2 = std::integral_constant<int, 2>;
+  using R3 = std::integral_constant<int, 3>;
+  auto stage = [&](int st, auto cur, auto nxt, auto far, auto do_load, auto do_store) __attribute__((always_inline)) {
+    if constexpr (decltype(do_load)::value) {
+      load_stage(st + 3, far);
+      load_B(st + 3, far);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // (keep the prefetch ahead of the MFMAs)
+    compute(st & 1, cur);
+    if ((st & 3) == 3) {  // a virtual chunk of 128 K values is complete: fold it into the running sum, restart from zero
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        tot[mi] += acc[mi];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+      }
+    }
+    if constexpr (decltype(do_store)::value) store_stage((st + 1) & 1, nxt);
+    __syncthreads();
+  };
+  constexpr std::true_type Y{};
+  constexpr std::false_type NO{};
+  load_stage(0, R0{});
+  load_B(0, R0{});
+  load_stage(1, R1{});
+  load_B(1, R1{});
+  load_stage(2, R2{});
+  load_B(2, R2{});
+  store_stage(0, R0{});
+  __syncthreads();
+  int st = 0;
+  for (; st + 4 < nst; st += 4) {  // (K % 128 == 0: four stages per virtual chunk)
+    stage(st, R0{}, R1{}, R3{}, Y, Y);
+    stage(st + 1, R1{}, R2{}, R0{}, Y, Y);
+    stage(st + 2, R2{}, R3{}, R1{}, Y, Y);
+    stage(st + 3, R3{}, R0{}, R2{}, Y, Y);
+  }
+  stage(st, R0{}, R1{}, R3{}, Y, Y);   // the last chunk: one stage left to request, three to stage
+  stage(st + 1, R1{}, R2{}, R0{}, NO, Y);
+  stage(st + 2, R2{}, R3{}, R1{}, NO, Y);
+  stage(st + 3, R3{}, R0{}, R2{}, NO, NO);
+
+  // ---- epilogue: the expression of cf_igemm.hip's vector epilogue per element (+ bias, then GELU / + residual); lane holds column n of rows
+  //      cf_acc_row(r, lane) of each of its tiles.  A wave's 32 lanes of a half store 128 contiguous bytes per row. ----
+  const int n = n0 + l31;
+  const float bias = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const size_t o = (size_t)(m0 + wm * 64 + mi * 32 + cf_acc_row(r, lane)) * g.N + n;
+      float v = tot[mi][r] + bias;
+      if (g.epilogue == CF_EPI_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+      if (g.epilogue == CF_EPI_RESIDUAL) v += g.res[o];
+      g.out[o] = v;
+    }
+}
+
 // W' = scale * W as hi = f16(W'), lo = f16(W' - hi) in MFMA-operand order [K/16][N/32][hi, lo][lane 64][4 words]:
 // a lane's 16 bytes are the 8 halves of W'[n = tile*32 + (lane&31)][k = kstep*16 + (lane>>5)*8 + 0..7]
 __global__ void pack_linear_f16x2_kernel(const float* __restrict__ w, int N, int K, float scale, unsigned* __restrict__ packed, long total) {
@@ -523,5 +661,40 @@ int cf_gemm_split_launch(const cf_conv_desc* d, hipStream_t stream) {
   }
   hipLaunchKernelGGL(gemm_split_kernel, dim3((unsigned)(tiles * nsplit)), dim3(256), 0, stream, g);
   CF_CHECK_LAUNCH("cf_conv2d(1x1, f16x2)");
+  return CF_OK;
+}
+
+// Called by cf_conv2d (cf_igemm.hip) for fp32 1x1 / Linear descriptors with split_k == 1 (one workgroup per output tile: large token
+// matrices).  Returns CF_OK after launching, or 1 when the shape is not this kernel's (the caller then runs its split-K instantiation:
+// the same bits).  CF_GEMM_F32_TILE=0 in the environment keeps every launch there (A/B).
+int cf_gemm_f32_tile_try(const cf_conv_desc* d, hipStream_t stream) {
+  static const bool on = !(getenv("CF_GEMM_F32_TILE") && atoi(getenv("CF_GEMM_F32_TILE")) == 0);
+  const long m = (long)d->batch * d->hout * d->wout;
+  const int k = d->c0;
+  if (!on || d->taps != 1 || d->bf16_mfma != CF_OPERAND_F32 || d->split_k != 1 || d->c1 != 0 || d->stride != 1 || d->in_nchw || d->out_nchw ||
+      d->prologue != CF_PRO_NONE || d->stats_out || d->stats_cpg || m % 128 || k % 128 || d->cout % 64 || d->cout_pad != d->cout ||
+      (d->ld_in0 != 0 && d->ld_in0 != d->c0) || (d->ld_out != 0 && d->ld_out != d->cout) || d->pad_mode != CF_PAD_ZERO ||
+      !(d->epilogue == CF_EPI_NONE || d->epilogue == CF_EPI_GELU || d->epilogue == CF_EPI_RESIDUAL))
+    return 1;
+  // 512 -> 512 (v / out projections) stays on the 64 x 64 instantiation: 29.4 us against 33.6 here at 4096 tokens (its 512 workgroups
+  // against 256 one-wave-per-SIMD ones); every other Linear shape of the Transformer gains (profiles/r06_gemm_f32_tile_probe.txt:
+  // 256 -> 512 19.0 -> 16.4 us, 512 -> 1024 52.7 -> 45.8, 1024 -> 512 54.7 -> 51.0).  A per-shape choice between bitwise-equal kernels.
+  if (k == 512 && d->cout == 512) return 1;
+  GsArgs g;
+  g.a = d->in0;
+  g.w = d->weight;
+  g.bias = d->bias;
+  g.res = d->res;
+  g.out = d->out;
+  g.M = (int)m;
+  g.N = d->cout;
+  g.K = k;
+  g.epilogue = d->epilogue;
+  g.acc_scale = 1.f;
+  g.ws = nullptr;
+  g.counters = nullptr;
+  g.nsplit = 1;
+  hipLaunchKernelGGL(gemm_f32_tile_kernel, dim3((unsigned)((g.M / 128) * (g.N / 64))), dim3(256), 0, stream, g);
+  CF_CHECK_LAUNCH("cf_conv2d(1x1, fp32 token tiles)");
   return CF_OK;
 }

@@ -1332,6 +1332,7 @@ int cf_winograd_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_que
 int cf_wf43_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query);      // cf_wf43.hip
 int cf_gemm_split_launch(const cf_conv_desc* d, hipStream_t stream);                     // cf_gemm_split.hip
 int cf_gemm_split_geometry(const cf_conv_desc* d, int* tiles, long* bytes_per_part);
+int cf_gemm_f32_tile_try(const cf_conv_desc* d, hipStream_t stream);                     // cf_gemm_split.hip: fp32 token tiles (CF_OK: launched, 1: not its shape)
 int cf_split_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query);     // cf_split.hip
 
 static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
@@ -1559,6 +1560,10 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
       CF_REQUIRE(cp % 64 == 0 && a.nchunks % CF_SK_SLABS == 0 && V >= 1 && V % d->split_k == 0,
                  "cf_conv2d: split_k %d needs cout_pad %% 64 == 0, K %% 128 == 0 and split_k dividing K/128 = %d", d->split_k, V);
       CF_REQUIRE(pq || d->split_k == 1 || (d->workspace && d->counters), "cf_conv2d: split_k > 1 needs workspace and counters");
+      if (!pq && d->split_k == 1) {   // one workgroup per tile on a large token matrix: the 128-token tile kernel (bitwise the same result)
+        const int rc = cf_gemm_f32_tile_try(d, stream);
+        if (rc != 1) return rc;
+      }
       return launch_sk<2, 2, 1, 1>(a, d->workspace, d->counters, d->split_k, stream, pq);
     }
     if (narrow) return launch<1, 1, 2, 2, 2, 1, false>(a, stream, pq);

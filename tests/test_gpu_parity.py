@@ -158,11 +158,14 @@ def test_inpainting_config(chk):
 
 
 # ---- size-independent properties at BASELINE config-2 sizes (the CPU oracle is too slow there) -------------------------
-def test_full_size_batch16_is_bitwise_batch_invariant(chk):
-    """Config 2 shape (16 faces): every face of the batch equals the same face restored alone / in a 2-rank shard."""
+@pytest.mark.parametrize('precision', ['f16x2', 'fp32'])
+def test_full_size_batch16_is_bitwise_batch_invariant(chk, precision):
+    """Config 2 shape (16 faces): every face of the batch equals the same face restored alone / in a 2-rank shard -- in the product's default
+    mode and in the IEEE-fp32 mode bench.py's headline runs (whose token GEMMs take another kernel at sixteen faces than at one)."""
     import torch
     from oracle.synth import seeded_input
     net = chk.build_net().cuda()
+    net.precision = precision
     x = seeded_input(16).cuda()
     full = net(x, w=0.5, adain=True)
     for i in (0, 7, 15):

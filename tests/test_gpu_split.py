@@ -162,6 +162,33 @@ def test_splitk_gemm_bits_do_not_depend_on_the_split_count(sc):
     assert ops.splitk_for(pw, 16, 16, 512, 1) == 4 and ops.splitk_for(pw, 16, 16, 512, 16) == 1 and ops.splitk_for(pw, 64, 64, 512, 1) == 0
 
 
+def test_fp32_token_tile_gemm_is_bitwise_the_splitk_gemm(sc):
+    """Round 6: fp32 Linear launches with one workgroup per tile on at least 128 tokens run gemm_f32_tile_kernel (cf_gemm_split.hip); its
+    bits must be those of the 64x64 split-K instantiation (any split count), whole and per image of the batch -- the host picks by batch."""
+    import torch
+    from codeformer_amd import ops
+    g = torch.Generator().manual_seed(11)
+    for (B, K, N, epi) in ((16, 512, 512, ops.EPI_RESIDUAL), (16, 512, 1024, ops.EPI_GELU), (8, 1024, 512, ops.EPI_NONE), (16, 256, 512, ops.EPI_NONE), (2, 512, 1024, ops.EPI_NONE)):
+        x = torch.randn(B, 16, 16, K, generator=g).cuda()
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+        b = torch.randn(N, generator=g).cuda()
+        res = torch.randn(B, 16, 16, N, generator=g).cuda() if epi == ops.EPI_RESIDUAL else None
+        pw = ops.pack_weight(w, b)
+        y1 = ops.conv2d(x, pw, epilogue=epi, res=res, split_k=1)                 # the tile kernel (M % 128 == 0)
+        for ns in (2, 4):
+            if (K // 128) % ns == 0:
+                assert torch.equal(y1, ops.conv2d(x, pw, epilogue=epi, res=res, split_k=ns)), (B, K, N, ns)
+        one = ops.conv2d(x[:1].contiguous(), pw, epilogue=epi, res=None if res is None else res[:1].contiguous())   # (host's choice for one face: a split)
+        assert torch.equal(one, y1[:1])
+        assert torch.equal(y1, ops.conv2d(x, pw, epilogue=epi, res=res))      # the host's own choice at this batch
+        ref = x.double().view(-1, K) @ w.double().t() + b.double()
+        if epi == ops.EPI_RESIDUAL:
+            ref = ref + res.double().view(-1, N)
+        elif epi == ops.EPI_GELU:
+            ref = torch.nn.functional.gelu(ref)
+        assert float((y1.double().view(-1, N) - ref).abs().max()) <= 2e-5 + 1e-5 * float(ref.abs().max())
+
+
 def test_splitk_winograd_bits_do_not_depend_on_the_split_count(sc):
     """The Winograd kernel on images of at most 32x32 pixels: virtual chunks of 128 channels are taken to the output domain and added
     in a fixed order -- 1, 2 or 4 workgroups per patch give the same bits; errors vs fp64 as the unsplit kernel's."""

@@ -1,11 +1,11 @@
 #!/bin/bash
 # PMC passes over one bench step (each counter set in its own run, --kernel-trace only): per-kernel averages -> JSON.
-# Usage: bash tools/pmc_bench.sh <tag> [precision]   precision f16x2 (default) -> gpurun_out/pmc_bench_<tag>.json,
-#        fp32 / bf16 -> gpurun_out/pmc_bench_<tag>_<precision>.json (copy to profiles/<tag>_pmc_bench[_<precision>].json: bench.py quotes
-#        `traffic` of the exact_fp32 / config3_rank legs from those)
+# Usage: bash tools/pmc_bench.sh <tag> [precision]   precision fp32 (default, bench.py's headline) / f16x2 / bf16
+#        -> gpurun_out/pmc_bench_<tag>_<precision>.json (copy to profiles/<tag>_pmc_bench_<precision>.json: bench.py quotes
+#        `traffic_recorded` of the leg with that precision from it, when the build id matches)
 tag=${1:-r01}
-prec=${2:-f16x2}
-suffix=""; [ "$prec" != "f16x2" ] && suffix="_$prec"
+prec=${2:-fp32}
+suffix="_$prec"
 wflag=""; [ "$prec" = "bf16" ] && wflag="--w 0.7"
 mkdir -p gpurun_out; export TMPDIR=/tmp
 i=0

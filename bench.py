@@ -230,12 +230,12 @@ def parity_gate(net, sd_cpu, weights, w):
 def config3_gate(net, weights):
     """Gate of the bf16 / w = 0.7 leg (tests/test_gpu_real_images.py:test_config3_fidelity_weight_through_the_network, tools/gpu_check.py:g_bf16):
     the seeded face at w = 0.7 with net.precision = 'bf16' against the REFERENCE's committed outputs -- code indices exact, logits 1e-4
-    (encoder and Transformer do not run on bf16), pixels within the stated bf16 gate (max 0.18, mean 0.014 on outputs of std ~0.5).
-    Where 0.18 / 0.014 come from (tools/bf16_gate_derivation.py, profiles/r05_bf16_gate_derivation.txt): the CPU oracle with the operands
-    of the same 58 convolutions rounded to bf16 (fp32 accumulation, fp32 tensors) differs from the reference's fp32 output on this face by
-    max 0.1094 / mean 0.01064 -- the cost of bf16 operands for ANY implementation with these weights.  The gate is 1.65x / 1.32x that
-    intrinsic cost; the kernels measure 1.00x / 1.07x (0.109 / 0.0114: they round Winograd-domain operands, the emulation direct ones), so
-    the thin-looking margin to 0.014 is a margin above a floor, not above zero."""
+    (encoder and Transformer do not run on bf16), pixels within the stated bf16 gate (max 0.196, mean 0.0152 on outputs of std ~0.5).
+    Where the gate comes from (tools/bf16_gate_derivation.py, profiles/r06_bf16_gate_derivation.txt): the CPU oracle with the operands of the
+    same 58 convolutions rounded to bf16 AND the 46 generator / fusion activations of more than 1024 pixels stored as bf16 (rounded once where
+    they are written, fp32 accumulation) differs from the reference's fp32 output on this face by max 0.1307 / mean 0.01215 -- the cost of
+    that arithmetic for ANY implementation with these weights (operands alone, the mode of rounds 2-5: 0.1094 / 0.01064).  The gate is 1.5x /
+    1.25x that intrinsic cost."""
     import numpy as np
     from oracle.synth import seeded_input
     g7 = os.path.join(ROOT, 'tests', 'golden', 'restoration_seed0_face0_w0.7.npz')
@@ -246,15 +246,17 @@ def config3_gate(net, weights):
     out, logits, _ = net(seeded_input(1).to(next(net.parameters()).device), w=0.7, adain=True)
     torch.cuda.synchronize()
     d = (out.cpu()[:, :, ::4, ::4] - torch.from_numpy(g['out_sub'])).abs()
+    storage = bool(getattr(net, 'bf16_storage', False))
     res = {'against': 'reference golden (tests/golden/restoration_seed0_face0_w0.7.npz, every 4th pixel; logits / indices of restoration_seed0_face0.npz)',
+           'bf16_storage': storage,
            'max_abs_pixel_diff': float(d.max()), 'mean_abs_pixel_diff': float(d.mean()),
            'max_abs_logit_diff': float((logits.cpu() - torch.from_numpy(g0['logits'])).abs().max()),
            'code_indices_equal': bool(np.array_equal(net.last_indices.cpu().numpy().reshape(-1), g0['idx'].reshape(-1))),
-           'tolerances': 'pixels max 0.18 / mean 0.014 (bf16 operands), logits 1e-4, code indices exact',
-           'gate_derivation': 'CPU oracle with bf16-rounded operands in the same 58 convolutions vs the reference fp32 output: max 0.1094 / mean 0.01064 '
-                              '(intrinsic cost of bf16 operands, profiles/r05_bf16_gate_derivation.txt); gate = 1.65x / 1.32x of it'}
-    res['x_intrinsic_bf16_cost'] = [round(res['max_abs_pixel_diff'] / 0.1094, 3), round(res['mean_abs_pixel_diff'] / 0.01064, 3)]
-    if not (res['max_abs_pixel_diff'] <= 0.18 and res['mean_abs_pixel_diff'] <= 0.014 and res['max_abs_logit_diff'] <= 1e-4 and res['code_indices_equal']):
+           'tolerances': 'pixels max 0.196 / mean 0.0152 (bf16 operands + bf16 storage), logits 1e-4, code indices exact',
+           'gate_derivation': 'CPU oracle with bf16-rounded operands in the same 58 convolutions and bf16 storage of the 46 activations of more than 1024 pixels vs the '
+                              'reference fp32 output: max 0.1307 / mean 0.01215 (intrinsic cost, profiles/r06_bf16_gate_derivation.txt); gate = 1.5x / 1.25x of it'}
+    res['x_intrinsic_bf16_cost'] = [round(res['max_abs_pixel_diff'] / (0.1307 if storage else 0.1094), 3), round(res['mean_abs_pixel_diff'] / (0.01215 if storage else 0.01064), 3)]
+    if not (res['max_abs_pixel_diff'] <= 0.196 and res['mean_abs_pixel_diff'] <= 0.0152 and res['max_abs_logit_diff'] <= 1e-4 and res['code_indices_equal']):
         raise SystemExit(f'bench.py: config-3 (bf16, w=0.7) gate FAILED, leg not timed: {json.dumps(res)}')
     return res
 

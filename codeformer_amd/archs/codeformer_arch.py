@@ -229,6 +229,13 @@ class CodeFormer(VQAutoEncoder):
         #            kernel elsewhere; the encoder runs as in the default mode (split halves, fp32-grade), so logits and code indices are
         #            bitwise those of 'f16x2' (pixel gates in tests/test_gpu_real_images.py).
         self.precision = os.environ.get('CODEFORMER_HIP_PRECISION', 'f16x2')
+        # precision 'bf16' as BASELINE configs 3 / 5 define it: "bf16 storage + fp32 accumulate in generator + CFT" (round 6).  With the
+        # switch on (default) every generator / fusion-block activation of more than 1024 pixels per image -- the 64x64 .. 512x512 levels,
+        # 99.6 % of the decoder's bytes -- lives in HBM as bf16: the producing epilogue rounds once, after its GroupNorm partials were taken
+        # from the fp32 accumulators; consumers widen on load; the four encoder taps the fusion blocks read get a bf16 copy.  Encoder,
+        # Transformer, argmax, the 16x16 / 32x32 latents (AttnBlocks, AdaIN) stay fp32, so logits and code indices are bitwise those of the
+        # default mode.  CODEFORMER_HIP_BF16_STORAGE=0 / False: bf16 OPERANDS on fp32 tensors (rounds 2-5).
+        self.bf16_storage = os.environ.get('CODEFORMER_HIP_BF16_STORAGE', '1') != '0'
         # Exact-fp32 convolutions (precision='fp32', and in every mode the layers the split kernel does not take): evaluate 3x3
         # stride-1 convolutions with Winograd F(2x2,3x3) -- the same function in fp32 with 2.25x fewer multiplies (cf_winograd.hip).
         # Set False (or CODEFORMER_HIP_WINOGRAD=0) for the direct evaluation everywhere.
@@ -364,9 +371,12 @@ class CodeFormer(VQAutoEncoder):
         if w > 0:
             def fuse(t):
                 f = str(t.shape[2])
-                return self.fuse_convs_dict[f].forward_nhwc(enc_feat[f], t, w, bf16=bf16)
+                enc = enc_feat[f]
+                if t.dtype == torch.bfloat16:    # bf16 storage: the fusion block concatenates [enc, dec] -- the tap gets its bf16 copy
+                    enc = ops.to_bf16(enc)
+                return self.fuse_convs_dict[f].forward_nhwc(enc, t, w, bf16=bf16)
             gen_taps = {self.fuse_generator_block[f]: fuse for f in self.connect_list}
-        out = self.generator.forward_nhwc(quant, gen_taps, bf16=bf16)      # (B,3,512,512) NCHW
+        out = self.generator.forward_nhwc(quant, gen_taps, bf16=bf16, storage_bf16=bool(self.bf16_storage) and bf16 == 1)      # (B,3,512,512) NCHW
         self.last_indices = idx.view(B, T)
         return out, logits, lq_feat
 
@@ -405,7 +415,7 @@ class CodeFormer(VQAutoEncoder):
         """Capture-once / replay-many execution of _forward_hip on the current stream.  Outputs are copies, so callers may
         keep them across calls.  A graph is re-captured when any packed weight was rebuilt since its capture."""
         with _GRAPH_LOCK:   # static buffers per shape: two threads replaying one graph would race on them
-            key = (tuple(x.shape), float(w), bool(code_only), bool(adain), self.precision, self.encoder_precision, self.gemm_precision, bool(self.winograd), bool(self.winograd_encoder), bool(self.winograd_f43), bool(self.winograd_f43_encoder), str(x.device), ops.switches())
+            key = (tuple(x.shape), float(w), bool(code_only), bool(adain), self.precision, bool(self.bf16_storage), self.encoder_precision, self.gemm_precision, bool(self.winograd), bool(self.winograd_encoder), bool(self.winograd_f43), bool(self.winograd_f43_encoder), str(x.device), ops.switches())
             ent = self._graphs.get(key)
             sig = self._param_signature()
             if ent is None or ent['epoch'] != PACK_EPOCH[0] or ent['sig'] != sig:

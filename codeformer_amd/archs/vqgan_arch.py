@@ -183,7 +183,10 @@ class ResBlock(HipModule):
         through the split-half convolution kernel (these layers are HBM-bound; the fp32 MFMA GEMM holds them at 2-4 TB/s); the input
         is the un-normalised block input, so it carries a range scale -- one table for both halves of a concatenated input."""
         c_split = None if x2 is None else x.shape[3]
-        if int(code) in (2,) + ops.SPLIT_CODES and ops.RANGE_SCALE and \
+        # bf16 storage (x is a bf16 tensor that carries its producer's statistics): the same streaming kernel -- a bf16 value is its own hi
+        # half, so the product is exact on the activation side; the fp32-MFMA GEMM ran these HBM-bound layers at 0.9 ms (128 -> 64 @512^2 x16)
+        stored = x.dtype == torch.bfloat16 and getattr(x, '_cf_stats', None) is not None and (x2 is None or getattr(x2, '_cf_stats', None) is not None)
+        if (int(code) in (2,) + ops.SPLIT_CODES or stored) and ops.RANGE_SCALE and \
                 ops.split_1x1_ok(self.in_channels, self.out_channels, x.shape[1], x.shape[2], c_split):
             pw = self._packed(('conv_out', 'f16x2'), lambda: ops.pack_weight(self.conv_out.weight, self.conv_out.bias, bf16=ops.SPLIT),
                               self.conv_out.weight, self.conv_out.bias)
@@ -280,15 +283,22 @@ class _GroupNorm(nn.GroupNorm):
         return super().forward(x)
 
 
-def _run_blocks_nhwc(blocks, x, taps=None, first_nchw=False, last_nchw=False, bf16=False):
+def _run_blocks_nhwc(blocks, x, taps=None, first_nchw=False, last_nchw=False, bf16=False, storage_bf16=False):
     """Execute a block list on channels-last activations, folding GroupNorm entries into the following conv.
 
     taps: optional {block index: callable(x)} invoked after that block (encoder feature taps / generator fusions;
     a callable may return a replacement activation).
+    storage_bf16 (generator, operand code 1 only -- precision 'bf16', BASELINE configs 3 / 5): every activation of more than
+    ops.TOKEN_IMAGE_MAX pixels per image lives in HBM as bf16 (cf_conv_desc.io_bf16).  The switch happens in front of the first Upsample
+    whose output is that large: its fp32 input (32x32) is copied to bf16 once (ops.to_bf16) and from there every kernel reads and writes
+    bf16 -- the storage type of a launch is the dtype of its input tensor; the final 64 -> 3 conv writes the fp32 NCHW image.
     """
     pending = None
     n = len(blocks)
     for i, blk in enumerate(blocks):
+        if storage_bf16 and int(bf16) == 1 and isinstance(blk, Upsample) and x.dtype == torch.float32 and \
+                4 * x.shape[1] * x.shape[2] > ops.TOKEN_IMAGE_MAX:
+            x = ops.to_bf16(x)
         if isinstance(blk, _GroupNorm):
             pending = ops.groupnorm_tables([x], blk.weight, blk.bias, blk.eps, blk.num_groups) + (blk,)
         elif isinstance(blk, _Conv3x3):
@@ -396,10 +406,10 @@ class Generator(HipModule):
         with torch.no_grad():
             return self.forward_nhwc(ops.to_nhwc(x.float()))
 
-    def forward_nhwc(self, x, taps=None, bf16=False):
+    def forward_nhwc(self, x, taps=None, bf16=False, storage_bf16=False):
         """x: (B,16,16,C) NHWC latent; returns the (B,3,H,W) NCHW image (written directly by the last conv).
-        bf16=True: every 3x3 conv except the final 64->3 one uses bf16 MFMA operands."""
-        return _run_blocks_nhwc(self.blocks, x, taps, last_nchw=True, bf16=bf16)
+        bf16=True: every 3x3 conv except the final 64->3 one uses bf16 MFMA operands; storage_bf16: see _run_blocks_nhwc."""
+        return _run_blocks_nhwc(self.blocks, x, taps, last_nchw=True, bf16=bf16, storage_bf16=storage_bf16)
 
     def forward_host(self, x):
         for blk in self.blocks:

@@ -98,6 +98,27 @@ __device__ __forceinline__ void cf_store16(float* p, f32x4 v, bool nt) {
   else *reinterpret_cast<f32x4*>(p) = v;
 }
 
+// ---- bf16 STORAGE of activations (cf_conv_desc.io_bf16, ABI v22; precision 'bf16' of the network: BASELINE configs 3 / 5) ------------
+// A tensor element is the upper half of its fp32 value, rounded to nearest even ONCE, in the producing epilogue, after the GroupNorm
+// partials were taken from the fp32 values; consumers widen on load (a shift: exact).  Four channels = 8 bytes, eight = 16.
+typedef unsigned cf_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned cf_u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 cf_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 cf_bf16x4_widen(cf_u32x2 p) {
+  return f32x4{__builtin_bit_cast(float, p[0] << 16), __builtin_bit_cast(float, p[0] & 0xffff0000u), __builtin_bit_cast(float, p[1] << 16),
+               __builtin_bit_cast(float, p[1] & 0xffff0000u)};
+}
+__device__ __forceinline__ cf_u32x2 cf_bf16x4_round(f32x4 v) {   // v_cvt_pk_bf16_f32 (round to nearest even) x 2
+  const cf_bf16x2 a = {(__bf16)v[0], (__bf16)v[1]}, b = {(__bf16)v[2], (__bf16)v[3]};
+  return cf_u32x2{__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)};
+}
+__device__ __forceinline__ f32x4 cf_load4_bf16(const float* base, size_t elem) {   // `base` points at bf16 elements (the descriptor keeps float* fields)
+  return cf_bf16x4_widen(*reinterpret_cast<const cf_u32x2*>(reinterpret_cast<const unsigned short*>(base) + elem));
+}
+__device__ __forceinline__ void cf_store4_bf16(float* base, size_t elem, f32x4 v) {
+  *reinterpret_cast<cf_u32x2*>(reinterpret_cast<unsigned short*>(base) + elem) = cf_bf16x4_round(v);
+}
+
 // Row of accumulator register r (0..15) of a 32x32 MFMA tile held by `lane`; the column is lane&31.
 __device__ __forceinline__ int cf_acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 

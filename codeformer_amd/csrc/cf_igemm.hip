@@ -132,10 +132,14 @@ __device__ __forceinline__ float swishf(float y) { return y * (1.0f / (1.0f + ex
 // fp32 accumulation and fp32 tensors in HBM.
 // SK = true (1x1 / Linear only): `nsplit` workgroups share an output tile, each contracting a contiguous range of K slabs; the partial
 // accumulators meet in a workspace and the last arriver adds them in split order (cf_splitk_combine) before the usual epilogue.
+// BIO = true (round 6, cf_conv_desc.io_bf16): in0, in1, res, sft_scale and out are bf16 tensors (2 bytes per element); the gather widens on
+// load, the vector epilogue rounds once (RNE) after the GroupNorm partials were taken.  Only the instantiations the bf16 mode runs from
+// 64x64 pixels up exist (direct bf16 3x3 with 64 output channels, folded upsample, fp32 1x1 on images); every other one is untouched.
 template <int TAPS, int STRIDE, int WM, int WN, int MI, int NI, bool IN_NCHW, bool BF16 = false, bool EXT = false, bool F16 = false,
-          bool SK = false>
+          bool SK = false, bool BIO = false>
 __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const ArgsOf<EXT, SK> a) {
   using C = Cfg<TAPS, STRIDE, WM, WN, MI, NI>;
+  static_assert(!BIO || (!IN_NCHW && !EXT && !SK && !F16 && STRIDE == 1), "bf16 tensors: dense NHWC stride-1 instantiations only");
   static_assert(!SK || (TAPS == 1 && !EXT && !BF16 && !F16), "split-K: 1x1 / Linear fp32 instantiations");
   constexpr bool LP = BF16 || F16;  // 16-bit MFMA operands
   static_assert(!LP || (TAPS > 1 && STRIDE == 1 && !IN_NCHW), "16-bit operand path: 3x3 stride 1 NHWC only");
@@ -266,11 +270,25 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Arg
 #pragma unroll
       for (int j = 0; j < C::APT; ++j) {
         const int pj = pix[j] < 0 ? 0 : pix[j];
+        if constexpr (BIO) {  // bf16 tensor: this item's KC / 4 channels are 8 (fp32 operands) or 16 (16-bit operands) bytes
+          const unsigned short* sp = reinterpret_cast<const unsigned short*>(src) + (size_t)pj * cs + cc;
+          if constexpr (AV == 2) {
+            const cf_u32x4 q = *reinterpret_cast<const cf_u32x4*>(sp);
+            ra[j * 2] = cf_bf16x4_widen(cf_u32x2{q[0], q[1]});
+            ra[j * 2 + 1] = cf_bf16x4_widen(cf_u32x2{q[2], q[3]});
+          } else {
+            ra[j] = cf_bf16x4_widen(*reinterpret_cast<const cf_u32x2*>(sp));
+          }
 #pragma unroll
-        for (int u = 0; u < AV; ++u) {
-          f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)pj * cs + cc + 4 * u);
-          if (pix[j] < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
-          ra[j * AV + u] = v;
+          for (int u = 0; u < AV; ++u)
+            if (pix[j] < 0) ra[j * AV + u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+#pragma unroll
+          for (int u = 0; u < AV; ++u) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)pj * cs + cc + 4 * u);
+            if (pix[j] < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            ra[j * AV + u] = v;
+          }
         }
       }
     }
@@ -731,9 +749,14 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Arg
 #pragma unroll
       for (int p = 0; p < PASSES; ++p) {
         r0[p] = r1[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (BIO) {
+          if (CF_LIVE(p) && (EPI == CF_EPI_RESIDUAL || EPI == CF_EPI_SFT)) r0[p] = cf_load4_bf16(a.res, offs[p]);
+          if (CF_LIVE(p) && EPI == CF_EPI_SFT) r1[p] = cf_load4_bf16(a.sft_scale, offs[p]);
+        } else {
         if (CF_LIVE(p) && (EPI == CF_EPI_RESIDUAL || EPI == CF_EPI_SFT || EPI == CF_EPI_AXPY || EPI == CF_EPI_AXPY2))
           r0[p] = *reinterpret_cast<const f32x4*>(a.res + offs[p]);
         if (CF_LIVE(p) && (EPI == CF_EPI_SFT || EPI == CF_EPI_AXPY2)) r1[p] = *reinterpret_cast<const f32x4*>(a.sft_scale + offs[p]);
+        }
       }
       __builtin_amdgcn_wave_barrier();
 #else
@@ -792,7 +815,8 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Arg
             }
 #endif
           }
-          *reinterpret_cast<f32x4*>(a.out + o) = v;
+          if constexpr (BIO) cf_store4_bf16(a.out, o, v);   // (rounded here, once; the statistics below see the fp32 values)
+          else *reinterpret_cast<f32x4*>(a.out + o) = v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             ssum[e] += v[e];
@@ -922,7 +946,7 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Arg
 // halo patch + prologue as the MFMA kernel, weights fetched through the scalar cache (wave-uniform addresses), coalesced
 // per-plane NCHW stores.  Accumulation order: slab, tap, channel (a plain fp32 FMA chain).
 // NCO = output channels evaluated per pixel (3 for the RGB head: the zero padding row of the packed weight is not multiplied through)
-template <int NCO>
+template <int NCO, bool BIO = false>   // BIO: the input is a bf16 tensor (cf_conv_desc.io_bf16; the NCHW image stays fp32)
 __global__ __launch_bounds__(256) void conv3x3_few_cout_kernel(const ConvArgsExt a) {
   constexpr int TH = 16, TW = 16, HWD = TW + 2, NPIX = (TH + 2) * HWD, APT = (NPIX * 4 + 255) / 256;
   __shared__ __attribute__((aligned(16))) float As[NPIX * CF_LDK];
@@ -972,7 +996,8 @@ __global__ __launch_bounds__(256) void conv3x3_few_cout_kernel(const ConvArgsExt
 #pragma unroll
       for (int j = 0; j < APT; ++j) {
         const size_t pj = pix[j] < 0 ? (size_t)b * a.hin * a.win : (size_t)pix[j];   // (clamped: any pixel of this image)
-        raw[u][j] = *reinterpret_cast<const f32x4*>(a.in0 + pj * a.c0 + c);
+        if constexpr (BIO) raw[u][j] = cf_load4_bf16(a.in0, pj * a.c0 + c);
+        else raw[u][j] = *reinterpret_cast<const f32x4*>(a.in0 + pj * a.c0 + c);
       }
     }
 #pragma unroll
@@ -1122,7 +1147,7 @@ __global__ __launch_bounds__(256) void conv3x3_few_cin_kernel(const ConvArgsExt 
   }
 }
 
-template <int TAPS, int STRIDE, int WM, int WN, int MI, int NI, bool IN_NCHW, bool BF16 = false, bool EXT = false, bool F16 = false>
+template <int TAPS, int STRIDE, int WM, int WN, int MI, int NI, bool IN_NCHW, bool BF16 = false, bool EXT = false, bool F16 = false, bool BIO = false>
 int launch(const ConvArgsExt& a, hipStream_t stream, int* parts_query) {
   using C = Cfg<TAPS, STRIDE, WM, WN, MI, NI>;
   ArgsOf<EXT> k = a;  // (slices the stride fields off for the CodeFormer instantiations)
@@ -1164,7 +1189,7 @@ int launch(const ConvArgsExt& a, hipStream_t stream, int* parts_query) {
     return CF_OK;
   }
   k.ntn = a.cout_pad / C::BN;
-  constexpr auto kern = igemm_kernel<TAPS, STRIDE, WM, WN, MI, NI, IN_NCHW, BF16, EXT, F16>;
+  constexpr auto kern = igemm_kernel<TAPS, STRIDE, WM, WN, MI, NI, IN_NCHW, BF16, EXT, F16, false, BIO>;
   constexpr size_t lds = C::LDS_FLOATS * sizeof(float);
   CF_LDS_ATTR(kern, lds);  // (cf_device_init sets the dynamic-LDS attribute on each device)
   hipLaunchKernelGGL(kern, dim3(mtiles * k.ntn), dim3(256), lds, stream, k);
@@ -1409,6 +1434,21 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
   CF_REQUIRE(d->cout_pad >= d->cout && d->cout_pad % 32 == 0, "cf_conv2d: cout_pad %d invalid for cout %d", d->cout_pad,
              d->cout);
 
+  if (d->io_bf16) {   // bf16 tensors (ABI v22): exactly the launches the bf16 mode makes from 64x64 pixels up; anything else is refused, never reinterpreted
+    const bool dense = ld0 == d->c0 && ld1 == d->c1 && ldo == d->cout && d->pad_mode == CF_PAD_ZERO && !d->in_nchw && d->stride == 1 && d->split_k < 1;
+    const bool wino_bf16 = d->winograd == 1 && d->bf16_mfma == CF_OPERAND_BF16;
+    const bool direct_bf16 = !d->winograd && d->bf16_mfma == CF_OPERAND_BF16 && d->taps == 9 && !d->out_nchw &&
+                             (d->upsample ? (d->cout_pad % 128 == 0 && (long)d->hout * d->wout > 1024) : d->cout_pad == 64);
+    const bool conv1 = !d->winograd && d->bf16_mfma == CF_OPERAND_F32 && d->taps == 1 && (d->cout_pad % 128 == 0 || d->cout_pad == 64) &&
+                       (long)d->hout * d->wout > 1024;
+    const bool conv1s = !d->winograd && d->bf16_mfma == CF_OPERAND_F16X2 && d->taps == 1 && (long)d->hout * d->wout > CF_TOKEN_IMAGE_MAX;   // streaming 1x1 (cf_split.hip)
+    const bool head = few_cout && d->bf16_mfma == CF_OPERAND_F32 && !d->winograd && d->cout == 3;
+    CF_REQUIRE(d->io_bf16 == 1 && dense && !ext && (head || d->cout % 4 == 0) && (wino_bf16 || direct_bf16 || conv1 || conv1s || head),
+               "cf_conv2d: io_bf16 (bf16 tensors) is built for dense stride-1 launches of the bf16 mode: winograd + CF_OPERAND_BF16, direct CF_OPERAND_BF16 3x3 "
+               "(cout_pad 64) / folded upsample (cout_pad %% 128 == 0), fp32 1x1 on images of more than 1024 pixels, the 3-channel NCHW head "
+               "(taps %d operand %d winograd %d cout_pad %d upsample %d)", d->taps, d->bf16_mfma, d->winograd, d->cout_pad, d->upsample);
+    CF_REQUIRE(d->epilogue == CF_EPI_NONE || d->epilogue == CF_EPI_RESIDUAL || d->epilogue == CF_EPI_SFT, "cf_conv2d: io_bf16 epilogues are none / residual / SFT");
+  }
   if (d->act_scale) {
     CF_REQUIRE(d->prologue == CF_PRO_NONE || d->prologue == CF_PRO_LEAKY,
                "cf_conv2d: act_scale is for un-normalised inputs (prologue none / leaky), got prologue %d", d->prologue);
@@ -1495,6 +1535,7 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
       if (cp % 128 == 0) return launch<4, 1, 2, 2, 2, 2, false, false, false, true>(a, stream, pq);
       return launch<4, 1, 4, 1, 2, 2, false, false, false, true>(a, stream, pq);
     }
+    if (d->bf16_mfma && d->io_bf16) return launch<4, 1, 2, 2, 2, 2, false, true, false, false, true>(a, stream, pq);   // (cout_pad % 128 == 0, > 1024 pixels: checked above)
     if (d->bf16_mfma) {
       if (narrow) return launch<4, 1, 2, 2, 2, 1, false, true>(a, stream, pq);
       if (cp % 128 == 0) return launch<4, 1, 2, 2, 2, 2, false, true>(a, stream, pq);
@@ -1511,6 +1552,7 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
     if (cp % 128 == 0) return launch<9, 1, 2, 2, 2, 2, false, false, false, true>(a, stream, pq);
     return launch<9, 1, 4, 1, 2, 2, false, false, false, true>(a, stream, pq);  // cout_pad == 64
   }
+  if (d->bf16_mfma && d->io_bf16) return launch<9, 1, 4, 1, 2, 2, false, true, false, false, true>(a, stream, pq);   // (cout_pad == 64: checked above)
   if (d->bf16_mfma) {
     if (narrow) return launch<9, 1, 2, 2, 2, 1, false, true>(a, stream, pq);
     if (cp % 128 == 0) return launch<9, 1, 2, 2, 2, 2, false, true>(a, stream, pq);
@@ -1542,7 +1584,8 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
     if (few_cout && !pq) {  // any image size: edge tiles are masked
       a.tiles_x = (d->wout + 15) / 16;
       a.tiles_per_img = a.tiles_x * ((d->hout + 15) / 16);
-      if (d->cout == 3) hipLaunchKernelGGL(conv3x3_few_cout_kernel<3>, dim3(a.tiles_per_img * d->batch), dim3(256), 0, stream, a);
+      if (d->cout == 3 && d->io_bf16) hipLaunchKernelGGL((conv3x3_few_cout_kernel<3, true>), dim3(a.tiles_per_img * d->batch), dim3(256), 0, stream, a);
+      else if (d->cout == 3) hipLaunchKernelGGL(conv3x3_few_cout_kernel<3>, dim3(a.tiles_per_img * d->batch), dim3(256), 0, stream, a);
       else hipLaunchKernelGGL(conv3x3_few_cout_kernel<4>, dim3(a.tiles_per_img * d->batch), dim3(256), 0, stream, a);
       CF_CHECK_LAUNCH("cf_conv2d");
       return CF_OK;
@@ -1565,6 +1608,10 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
         if (rc != 1) return rc;
       }
       return launch_sk<2, 2, 1, 1>(a, d->workspace, d->counters, d->split_k, stream, pq);
+    }
+    if (d->io_bf16) {   // (images of more than 1024 pixels, cout_pad 64 or a multiple of 128: checked above)
+      if (cp % 128 == 0) return launch<1, 1, 2, 2, 2, 2, false, false, false, false, true>(a, stream, pq);
+      return launch<1, 1, 4, 1, 2, 2, false, false, false, false, true>(a, stream, pq);
     }
     if (narrow) return launch<1, 1, 2, 2, 2, 1, false>(a, stream, pq);
     if (cp % 128 == 0) return launch<1, 1, 2, 2, 2, 2, false>(a, stream, pq);

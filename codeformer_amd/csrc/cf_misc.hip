@@ -514,6 +514,26 @@ extern "C" int cf_nhwc_to_nchw(const float* x, int batch, int c, int hw, float* 
   return launch_transpose(x, batch, hw, c, y, stream, "cf_nhwc_to_nchw");
 }
 
+// fp32 -> bf16 copy of an activation (round to nearest even): the fp32 tensors that enter the bf16-storage part of the generator (the
+// 32x32 decoder feature in front of the first bf16 Upsample, the encoder taps the fusion blocks read; cf_conv_desc.io_bf16).  Streaming:
+// eight elements per thread, 32 bytes in / 16 out.
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, long n8) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + i * 8), b = *reinterpret_cast<const f32x4*>(x + i * 8 + 4);
+    const cf_u32x2 pa = cf_bf16x4_round(a), pb = cf_bf16x4_round(b);
+    *reinterpret_cast<cf_u32x4*>(y + i * 8) = cf_u32x4{pa[0], pa[1], pb[0], pb[1]};
+  }
+}
+extern "C" int cf_f32_to_bf16(const float* x, int64_t numel, void* out, cf_stream_t stream) {
+  CF_REQUIRE(x && out && numel > 0 && numel % 8 == 0, "cf_f32_to_bf16: null pointer or element count %ld not a multiple of 8", (long)numel);
+  const long n8 = numel / 8;
+  long blocks = (n8 + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, reinterpret_cast<unsigned short*>(out), n8);
+  CF_CHECK_LAUNCH("cf_f32_to_bf16");
+  return CF_OK;
+}
+
 extern "C" int cf_img_u8_to_tensor(const uint8_t* img, int batch, int h, int w, float* out, cf_stream_t stream) {
   CF_REQUIRE(img && out && batch > 0 && h > 0 && w > 0, "cf_img_u8_to_tensor: bad args");
   const long nquads = (long)batch * ((h * w + 3) / 4);

@@ -142,9 +142,13 @@ __device__ __forceinline__ void split2(float x0, float x1, float& hi, float& lo)
   lo = __builtin_bit_cast(float, l);
 }
 
-template <int TAPS, int NI, int WM, bool S2 = false>
+// BIO (round 6, cf_conv_desc.io_bf16; TAPS == 1 only -- the ResBlock skip convolutions of the bf16-storage mode): in0, in1, res, sft_scale and out
+// are bf16 tensors.  A bf16 value is its own hi half (8 significant bits, exact in an IEEE half behind the range scale) and its lo half is
+// zero; the weights keep hi + lo, so the product is as exact as on fp32 tensors.  16 bytes per gather item instead of 32, 8 per output quad.
+template <int TAPS, int NI, int WM, bool S2 = false, bool BIO = false>
 __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 && TAPS != 1 && !(S2 && SP_S2_OCC2) ? SP_NARROW_OCC : 2) : 1) void split_conv_kernel(const SplitArgs a) {
   static_assert(!S2 || TAPS == 4, "the stride-2 form is a 2x2 convolution");
+  static_assert(!BIO || TAPS == 1, "bf16 tensors: the streaming 1x1 form only");
   using C = SplitCfg<TAPS, NI, WM>;
   constexpr int MI = 2;
   constexpr int NT = C::NT;
@@ -242,6 +246,12 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 && TAPS != 1 && !(S2 &
 #pragma unroll
     for (int j = 0; j < C::APT; ++j) {
       const unsigned pj = pix[j] < 0 ? 0u : (unsigned)pix[j];
+      if constexpr (BIO) {   // eight bf16 channels = 16 bytes, widened here (a shift)
+        const cf_u32x4 q16 = *reinterpret_cast<const cf_u32x4*>(reinterpret_cast<const unsigned short*>(first ? a.in0 : a.in1) + (size_t)(pj * cs + k8 * 8) + (first ? c : c - a.c0));
+        r.v[j][0] = cf_bf16x4_widen(cf_u32x2{q16[0], q16[1]});
+        r.v[j][1] = cf_bf16x4_widen(cf_u32x2{q16[2], q16[3]});
+        continue;
+      }
       const float* q = src + (size_t)(pj * cs + k8 * 8);  // (element offsets fit 32 bits: tensors < 16 GiB)
 #pragma unroll
       for (int u = 0; u < 2; ++u) r.v[j][u] = *reinterpret_cast<const f32x4*>(q + 4 * u);
@@ -583,8 +593,13 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 && TAPS != 1 && !(S2 &
           pixel = ((unsigned)b * a.hout + (y0 + (row >> 4))) * a.wout + (x0 + (row & 15));
         offs[mi][p] = pixel * (unsigned)a.cout + n;
         r0[mi][p] = r1[mi][p] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (EPI == CF_EPI_RESIDUAL || EPI == CF_EPI_SFT) r0[mi][p] = *reinterpret_cast<const f32x4*>(a.res + offs[mi][p]);
-        if (EPI == CF_EPI_SFT) r1[mi][p] = *reinterpret_cast<const f32x4*>(a.sft_scale + offs[mi][p]);
+        if constexpr (BIO) {
+          if (EPI == CF_EPI_RESIDUAL || EPI == CF_EPI_SFT) r0[mi][p] = cf_load4_bf16(a.res, offs[mi][p]);
+          if (EPI == CF_EPI_SFT) r1[mi][p] = cf_load4_bf16(a.sft_scale, offs[mi][p]);
+        } else {
+          if (EPI == CF_EPI_RESIDUAL || EPI == CF_EPI_SFT) r0[mi][p] = *reinterpret_cast<const f32x4*>(a.res + offs[mi][p]);
+          if (EPI == CF_EPI_SFT) r1[mi][p] = *reinterpret_cast<const f32x4*>(a.sft_scale + offs[mi][p]);
+        }
       }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -619,7 +634,10 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 && TAPS != 1 && !(S2 &
         }
       }
       // (one wave-uniform choice of the stores' cache policy per 32-row block, not per store: cf_common.h cf_store16, cf_wf43.hip)
-      if (a.nt_out) {
+      if constexpr (BIO) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) cf_store4_bf16(a.out, offs[mi][p], t[p]);   // (rounded here, once)
+      } else if (a.nt_out) {
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) __builtin_nontemporal_store(t[p], reinterpret_cast<f32x4*>(a.out + offs[mi][p]));
       } else {
@@ -740,11 +758,11 @@ __global__ void pack_weight_f16x2_kernel(const float* __restrict__ w, int cout, 
   packed[i] = out;
 }
 
-template <int TAPS, int NI, bool S2 = false>
+template <int TAPS, int NI, bool S2 = false, bool BIO = false>
 int split_launch(SplitArgs& k, int batch, hipStream_t stream) {
   using C = SplitCfg<TAPS, NI, SP_WM>;
   k.ntn = k.cout_pad / C::BN;
-  constexpr auto kern = split_conv_kernel<TAPS, NI, SP_WM, S2>;
+  constexpr auto kern = split_conv_kernel<TAPS, NI, SP_WM, S2, BIO>;
   constexpr size_t lds = C::LDS_FLOATS * sizeof(float);
   CF_LDS_ATTR(kern, lds);  // (cf_device_init sets the dynamic-LDS attribute on each device)
   hipLaunchKernelGGL(kern, dim3(k.tiles_per_img * batch * k.ntn), dim3(C::NT), lds, stream, k);
@@ -777,6 +795,7 @@ int cf_split_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query)
   CF_REQUIRE((d->taps == 9 || one) && (d->stride == 1 || s2) && !d->in_nchw && !d->out_nchw && !d->winograd,
              "cf_conv2d: f16x2 operands cover 3x3 NHWC convolutions (stride 1 plain or nearest-x2 folded, stride 2) and 1x1 on images");
   CF_REQUIRE(!one || (d->stride == 1 && !d->upsample && !d->stats_out), "cf_conv2d(f16x2): 1x1 convolutions are stride 1, no upsample, no statistics");
+  CF_REQUIRE(!d->io_bf16 || one, "cf_conv2d(f16x2): bf16 tensors (io_bf16) are read by the streaming 1x1 form only");
   if (s2)
     CF_REQUIRE(!d->upsample && d->c1 == 0 && d->c0 % 16 == 0 && d->pad_lo == 0 && d->hin % 2 == 0 && d->win % 2 == 0,
                "cf_conv2d(f16x2): stride 2 needs one dense input with c0 %% 16 == 0 (got %d), even size, padding bottom / right", d->c0);
@@ -852,6 +871,7 @@ int cf_split_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query)
   }();
   const bool wide = d->cout_pad % 128 == 0 && (long)a.tiles_per_img * (d->cout_pad / 128) > narrow_max_wgs;
   if (s2) return wide ? split_launch<4, 2, true>(a, d->batch, stream) : split_launch<4, 1, true>(a, d->batch, stream);
+  if (one && d->io_bf16) return wide ? split_launch<1, 2, false, true>(a, d->batch, stream) : split_launch<1, 1, false, true>(a, d->batch, stream);
   if (one) return wide ? split_launch<1, 2>(a, d->batch, stream) : split_launch<1, 1>(a, d->batch, stream);
   if (d->upsample) return wide ? split_launch<4, 2>(a, d->batch, stream) : split_launch<4, 1>(a, d->batch, stream);
   return wide ? split_launch<9, 2>(a, d->batch, stream) : split_launch<9, 1>(a, d->batch, stream);

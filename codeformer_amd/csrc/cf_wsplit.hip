@@ -26,6 +26,10 @@
 // SINGLE 16-bit operands -- U rounded once at pack time (the hi slot of the same fragment layout), V rounded by the transform, one
 // MFMA per transform-domain product instead of three, half the weight-fragment registers and L2 traffic, no lo conversion.  fp32
 // tensors, transform arithmetic, accumulation and epilogue are unchanged.
+//
+// BIO (round 6, cf_conv_desc.io_bf16; instantiated for OP = CF_OPERAND_BF16 only): the activations -- both concatenated inputs, the
+// residual / SFT operands and the output -- are bf16 tensors in HBM.  The gather requests 8 bytes per item instead of 16 and widens in
+// the patch store (a shift), the epilogue rounds once (RNE) after the GroupNorm partials were taken from the fp32 values.
 #include <type_traits>
 
 #include "cf_common.h"
@@ -84,7 +88,7 @@ struct WsArgs {
 
 // PRO = the prologue (enum cf_prologue) as a template parameter: with a switch inside the slab loop hipcc's wait-count pass merged the
 // branches into s_waitcnt vmcnt(0) before the patch store, i.e. every iteration waited for the weight fragments it had just requested.
-template <int PRO, int OP = CF_OPERAND_F16X2>
+template <int PRO, int OP = CF_OPERAND_F16X2, bool BIO = false>
 __global__ __launch_bounds__(WS_THREADS, 1) void wsplit_kernel(const WsArgs a) {
   constexpr int NI = WS_NI;
   constexpr int NPART = OP == CF_OPERAND_F16X2 ? 2 : 1;  // weight-fragment parts a lane keeps: hi + lo, or the single rounded operand
@@ -143,7 +147,8 @@ __global__ __launch_bounds__(WS_THREADS, 1) void wsplit_kernel(const WsArgs a) {
   const float act_s02 = 0.2f * act_s;  // LeakyReLU slope folded with the scale: fl(y * (0.2 s)) == fl(0.2 y) * s
   const float* const tab_sc = affine ? a.pro_scale + (size_t)b * a.cin : a.weight;  // (any valid address when unused)
   const float* const tab_sh = affine ? a.pro_shift + (size_t)b * a.cin : a.weight;
-  f32x4 rsc, rsh, ra[APT];
+  f32x4 rsc, rsh;
+  std::conditional_t<BIO, cf_u32x2, f32x4> ra[APT];   // (bf16 storage: the raw 8 bytes ride through the pipeline, widened at the store)
   // unconditional loads from clamped addresses; out-of-image items are zeroed at the store (see cf_winograd.hip)
   auto load_A = [&](int chunk) __attribute__((always_inline)) {
     const int c = chunk * CF_BK + k4 * 4;
@@ -156,7 +161,8 @@ __global__ __launch_bounds__(WS_THREADS, 1) void wsplit_kernel(const WsArgs a) {
 #pragma unroll
     for (int j = 0; j < APT; ++j) {
       const int pj = pix[j] < 0 ? 0 : pix[j];
-      ra[j] = *reinterpret_cast<const f32x4*>(src + (size_t)pj * cs + cc);
+      if constexpr (BIO) ra[j] = *reinterpret_cast<const cf_u32x2*>(reinterpret_cast<const unsigned short*>(src) + (size_t)pj * cs + cc);
+      else ra[j] = *reinterpret_cast<const f32x4*>(src + (size_t)pj * cs + cc);
     }
   };
   auto store_patch = [&](float* patch) __attribute__((always_inline)) {
@@ -165,7 +171,9 @@ __global__ __launch_bounds__(WS_THREADS, 1) void wsplit_kernel(const WsArgs a) {
     for (int j = 0; j < APT; ++j) {
       const int p = (tid >> 2) + 128 * j;  // (p >= 180: padding rows of the patch buffer, written as zeros -- no branch)
       const bool valid = pix[j] >= 0;
-      f32x4 v = ra[j];
+      f32x4 v;
+      if constexpr (BIO) v = cf_bf16x4_widen(ra[j]);
+      else v = ra[j];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float y = v[e];
@@ -409,8 +417,13 @@ __global__ __launch_bounds__(WS_THREADS, 1) void wsplit_kernel(const WsArgs a) {
         const unsigned off = e_base + (unsigned)(k * 4 + aa) * e_rowc + pass * 32;
         offs[pass][k * 2 + aa] = off;
         r0[pass][k * 2 + aa] = r1[pass][k * 2 + aa] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (a.epilogue == CF_EPI_RESIDUAL || a.epilogue == CF_EPI_SFT) r0[pass][k * 2 + aa] = *reinterpret_cast<const f32x4*>(a.res + off);
-        if (a.epilogue == CF_EPI_SFT) r1[pass][k * 2 + aa] = *reinterpret_cast<const f32x4*>(a.sft_scale + off);
+        if constexpr (BIO) {
+          if (a.epilogue == CF_EPI_RESIDUAL || a.epilogue == CF_EPI_SFT) r0[pass][k * 2 + aa] = cf_load4_bf16(a.res, off);
+          if (a.epilogue == CF_EPI_SFT) r1[pass][k * 2 + aa] = cf_load4_bf16(a.sft_scale, off);
+        } else {
+          if (a.epilogue == CF_EPI_RESIDUAL || a.epilogue == CF_EPI_SFT) r0[pass][k * 2 + aa] = *reinterpret_cast<const f32x4*>(a.res + off);
+          if (a.epilogue == CF_EPI_SFT) r1[pass][k * 2 + aa] = *reinterpret_cast<const f32x4*>(a.sft_scale + off);
+        }
       }
     }
 #if WS_ABLATE & 16
@@ -437,7 +450,8 @@ __global__ __launch_bounds__(WS_THREADS, 1) void wsplit_kernel(const WsArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = r0[pass][i][e] + a.sft_w * (r0[pass][i][e] * r1[pass][i][e] + v[e]);
       }
-      *reinterpret_cast<f32x4*>(a.out + offs[pass][i]) = v;
+      if constexpr (BIO) cf_store4_bf16(a.out, offs[pass][i], v);   // (rounded here, once; the statistics below see the fp32 values)
+      else *reinterpret_cast<f32x4*>(a.out + offs[pass][i]) = v;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         ssum[e] += v[e];
@@ -526,19 +540,26 @@ int cf_wsplit_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query
   CF_LDS_ATTR((wsplit_kernel<CF_PRO_AFFINE, CF_OPERAND_BF16>), lds);
   CF_LDS_ATTR((wsplit_kernel<CF_PRO_AFFINE_SWISH, CF_OPERAND_BF16>), lds);
   CF_LDS_ATTR((wsplit_kernel<CF_PRO_LEAKY, CF_OPERAND_BF16>), lds);
+  CF_LDS_ATTR((wsplit_kernel<CF_PRO_NONE, CF_OPERAND_BF16, true>), lds);
+  CF_LDS_ATTR((wsplit_kernel<CF_PRO_AFFINE, CF_OPERAND_BF16, true>), lds);
+  CF_LDS_ATTR((wsplit_kernel<CF_PRO_AFFINE_SWISH, CF_OPERAND_BF16, true>), lds);
+  CF_LDS_ATTR((wsplit_kernel<CF_PRO_LEAKY, CF_OPERAND_BF16, true>), lds);
   const dim3 grid(a.tiles_per_img * d->batch * a.ntn), block(WS_THREADS);
-  auto launch_op = [&](auto op) {
+  auto launch_op = [&](auto op, auto bio) {
     constexpr int OP = decltype(op)::value;
+    constexpr bool BIO = decltype(bio)::value;
     switch (d->prologue) {
-      case CF_PRO_AFFINE: hipLaunchKernelGGL((wsplit_kernel<CF_PRO_AFFINE, OP>), grid, block, lds, stream, a); break;
-      case CF_PRO_AFFINE_SWISH: hipLaunchKernelGGL((wsplit_kernel<CF_PRO_AFFINE_SWISH, OP>), grid, block, lds, stream, a); break;
-      case CF_PRO_LEAKY: hipLaunchKernelGGL((wsplit_kernel<CF_PRO_LEAKY, OP>), grid, block, lds, stream, a); break;
-      default: hipLaunchKernelGGL((wsplit_kernel<CF_PRO_NONE, OP>), grid, block, lds, stream, a); break;
+      case CF_PRO_AFFINE: hipLaunchKernelGGL((wsplit_kernel<CF_PRO_AFFINE, OP, BIO>), grid, block, lds, stream, a); break;
+      case CF_PRO_AFFINE_SWISH: hipLaunchKernelGGL((wsplit_kernel<CF_PRO_AFFINE_SWISH, OP, BIO>), grid, block, lds, stream, a); break;
+      case CF_PRO_LEAKY: hipLaunchKernelGGL((wsplit_kernel<CF_PRO_LEAKY, OP, BIO>), grid, block, lds, stream, a); break;
+      default: hipLaunchKernelGGL((wsplit_kernel<CF_PRO_NONE, OP, BIO>), grid, block, lds, stream, a); break;
     }
   };
-  if (d->bf16_mfma == CF_OPERAND_F16) launch_op(std::integral_constant<int, CF_OPERAND_F16>{});
-  else if (d->bf16_mfma == CF_OPERAND_BF16) launch_op(std::integral_constant<int, CF_OPERAND_BF16>{});
-  else launch_op(std::integral_constant<int, CF_OPERAND_F16X2>{});
+  CF_REQUIRE(!d->io_bf16 || d->bf16_mfma == CF_OPERAND_BF16, "cf_conv2d(winograd, 8 waves): bf16 tensors (io_bf16) go with CF_OPERAND_BF16 operands");
+  if (d->bf16_mfma == CF_OPERAND_F16) launch_op(std::integral_constant<int, CF_OPERAND_F16>{}, std::false_type{});
+  else if (d->bf16_mfma == CF_OPERAND_BF16 && d->io_bf16) launch_op(std::integral_constant<int, CF_OPERAND_BF16>{}, std::true_type{});
+  else if (d->bf16_mfma == CF_OPERAND_BF16) launch_op(std::integral_constant<int, CF_OPERAND_BF16>{}, std::false_type{});
+  else launch_op(std::integral_constant<int, CF_OPERAND_F16X2>{}, std::false_type{});
   CF_CHECK_LAUNCH("cf_conv2d(winograd f16x2)");
   return CF_OK;
 }

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('CF_LIB_PATH') or os.path.join(_PKG, 'libcodeformer_hi
 
 c_float_p = ctypes.c_void_p  # device pointers are passed as integers
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 PRO_NONE, PRO_AFFINE, PRO_AFFINE_SWISH, PRO_LEAKY = 0, 1, 2, 3
 EPI_NONE, EPI_RESIDUAL, EPI_SFT, EPI_GELU, EPI_LEAKY, EPI_AXPY, EPI_AXPY2 = 0, 1, 2, 3, 4, 5, 6
 PAD_ZERO, PAD_REFLECT, PAD_EDGE = 0, 1, 2
@@ -42,6 +42,7 @@ class ConvDesc(ctypes.Structure):
         ('acc_scale', ctypes.c_float),
         ('split_k', ctypes.c_int32), ('workspace', ctypes.c_void_p), ('counters', ctypes.c_void_p),
         ('act_scale', ctypes.c_void_p),
+        ('io_bf16', ctypes.c_int32),
     ]
 
 
@@ -88,6 +89,7 @@ SIGNATURES = {
     'cf_img_u8_to_tensor': (_I, [_P, _I, _I, _I, _P, _P]),
     'cf_tensor_to_img_u8': (_I, [_P, _I, _I, _I, _P, _P]),
     'cf_mask_composite': (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    'cf_f32_to_bf16': (_I, [_P, _L, _P, _P]),
     'cf_fused_bias_act': (_I, [_P, _P, _L, _I, _I, _F, _F, _P, _P]),
     'cf_fused_bias_act_ex': (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _F, _F, _I, _P, _P]),
     'cf_upfirdn2d': (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),

@@ -28,6 +28,31 @@ def _f32(t):
     return t
 
 
+def _act_dtype(t, what='activation'):
+    """dtype of a conv activation: float32, or bfloat16 (bf16 STORAGE, cf_conv_desc.io_bf16 -- precision 'bf16' from 64x64 pixels up)."""
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError(f'{what}: expected float32 or bfloat16, got {t.dtype}')
+    return t.dtype
+
+
+def to_bf16(x):
+    """fp32 NHWC activation -> its bf16 copy (round to nearest even, cf_f32_to_bf16): the tensors that ENTER the bf16-storage part of the
+    generator (the decoder feature in front of the first bf16 Upsample, the encoder taps of the fusion blocks).  The GroupNorm partials /
+    range-scale table the producer attached travel with the copy: they were taken from the fp32 values, as the bf16 epilogues take theirs."""
+    if x.dtype == torch.bfloat16:
+        return x
+    _f32(x)
+    if not x.is_contiguous() or x.numel() % 8:
+        raise ValueError('to_bf16: expected a dense tensor with a multiple of 8 elements')
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    L.check(L.load().cf_f32_to_bf16(L.ptr(x), x.numel(), L.ptr(y, dtype=torch.bfloat16), L.stream_ptr()), 'cf_f32_to_bf16')
+    for attr in ('_cf_stats', '_cf_act'):
+        v = getattr(x, attr, None)
+        if v is not None:
+            setattr(y, attr, v)
+    return y
+
+
 class GNStats:
     """fp64 (sum, sumsq) partials of one NHWC tensor: [batch][channels/cpg][parts][2] (see cf_groupnorm_finalize).
     Produced by a conv epilogue (attached to the conv's output tensor as `._cf_stats`) or by the stand-alone pass."""
@@ -471,8 +496,9 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
     upsampled image); pad_lo=1 with stride 2: one padded row / column on every side instead of right / bottom only.
     act: (B, 2) range-scale table of an un-normalised input (act_scale(x)); dropped when the layer's kernel has fp32 operands."""
     lib = L.load()
-    _f32(x)
+    io = _act_dtype(x, 'x')            # float32, or bfloat16 = bf16 storage of every activation of the launch (io_bf16)
     if in_nchw:
+        _f32(x)
         B, c0, H, W = x.shape
         ld0 = 0
         if not x.is_contiguous():
@@ -485,7 +511,9 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
         if x2.shape[:3] != x.shape[:3]:
             raise ValueError('x2 spatial shape mismatch')
         c1 = x2.shape[3]
-        ld1 = _nhwc_ld(_f32(x2), 'x2')
+        if x2.dtype != io:
+            raise TypeError(f'x2 is {x2.dtype}, x is {io}: both halves of a concatenated input share the storage type (ops.to_bf16)')
+        ld1 = _nhwc_ld(x2, 'x2')
     if c0 + c1 != pw.cin and not (c1 == 0 and c0 == pw.cin_pad):
         raise ValueError(f'input channels {c0}+{c1} != weight cin {pw.cin}')
     if bool(upsample) != bool(pw.up2x):
@@ -501,11 +529,12 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
         Ho, Wo = (H * 2, W * 2) if upsample else (H, W)
     shape = (B, pw.cout, Ho, Wo) if out_nchw else (B, Ho, Wo, pw.cout)
     ldo = 0
+    odt = torch.float32 if out_nchw else io      # (the NCHW network output stays fp32)
     if out is None:
-        out = torch.empty(shape, dtype=torch.float32, device=x.device)
+        out = torch.empty(shape, dtype=odt, device=x.device)
     else:
-        if tuple(out.shape) != shape or out.dtype != torch.float32 or out.device != x.device:
-            raise ValueError(f'out: expected float32 {shape} on {x.device}')
+        if tuple(out.shape) != shape or out.dtype != odt or out.device != x.device:
+            raise ValueError(f'out: expected {odt} {shape} on {x.device}')
         if out_nchw:
             if not out.is_contiguous():
                 raise ValueError('out_nchw destination must be contiguous')
@@ -514,19 +543,21 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
     for t in (res, sft_scale):
         if t is not None and tuple(t.shape) != (B, Ho, Wo, pw.cout):
             raise ValueError(f'epilogue operand shape {tuple(t.shape)} != {(B, Ho, Wo, pw.cout)}')
-        if t is not None and _nhwc_ld(_f32(t), 'epilogue operand') != (ldo or pw.cout):
+        if t is not None and t.dtype != io:
+            raise TypeError(f'epilogue operand is {t.dtype}, the launch stores {io}')
+        if t is not None and _nhwc_ld(t, 'epilogue operand') != (ldo or pw.cout):
             raise ValueError('epilogue operands must have the channel stride of the output')
     for t in (scale, shift):
         if t is not None and tuple(t.shape) != (B, c0 + c1):
             raise ValueError(f'prologue table shape {tuple(t.shape)} != {(B, c0 + c1)}')
     d = L.ConvDesc(
-        in0=L.ptr(x, not in_nchw), in1=L.ptr(x2, True), c0=c0, c1=c1, batch=B, hin=H, win=W, hout=Ho, wout=Wo, cout=pw.cout,
+        in0=L.ptr(x, not in_nchw, dtype=io), in1=L.ptr(x2, True, dtype=io), c0=c0, c1=c1, batch=B, hin=H, win=W, hout=Ho, wout=Wo, cout=pw.cout,
         cout_pad=pw.cout_pad, taps=pw.taps, stride=stride, upsample=int(bool(upsample)), in_nchw=int(bool(in_nchw)),
         out_nchw=int(bool(out_nchw)), prologue=prologue, epilogue=epilogue, pro_scale=L.ptr(scale),
-        pro_shift=L.ptr(shift), weight=L.ptr(pw.w, dtype=None), bias=L.ptr(pw.bias), res=L.ptr(res, True),
-        sft_scale=L.ptr(sft_scale, True), sft_w=float(sft_w), out=L.ptr(out, not out_nchw), bf16_mfma=int(pw.bf16),
+        pro_shift=L.ptr(shift), weight=L.ptr(pw.w, dtype=None), bias=L.ptr(pw.bias), res=L.ptr(res, True, dtype=io),
+        sft_scale=L.ptr(sft_scale, True, dtype=io), sft_w=float(sft_w), out=L.ptr(out, not out_nchw, dtype=odt), bf16_mfma=int(pw.bf16),
         ld_in0=ld0, ld_in1=ld1, ld_out=ldo, pad_mode=int(pad_mode), pad_lo=int(pad_lo), winograd=int(pw.wino),
-        acc_scale=1.0 / pw.scale)
+        acc_scale=1.0 / pw.scale, io_bf16=int(io == torch.bfloat16))
     if act is not None and needs_act_scale(pw):
         if tuple(act.shape) != (B, 2) or prologue not in (PRO_NONE, PRO_LEAKY):
             raise ValueError('act: expected a (B, 2) table and a none / leaky prologue')
@@ -560,14 +591,17 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
     cin = c0 + c1
     flops = 2.0 * B * Ho * Wo * pw.cout * cin * (4 if upsample else pw.taps)   # executed MACs (folded taps for up2x); Winograd
     # launches are booked at the direct convolution's 9 taps (the algorithmic work), not at their 4 MFMA multiplies per output
-    nbytes = 4.0 * (x.numel() + (0 if x2 is None else x2.numel()) + pw.cout * cin * pw.taps + out.numel()
-                    + (0 if res is None else res.numel()) + (0 if sft_scale is None else sft_scale.numel()))
+    esz = x.element_size()
+    nbytes = float(esz * (x.numel() + (0 if x2 is None else x2.numel()) + (0 if res is None else res.numel()) + (0 if sft_scale is None else sft_scale.numel()))
+                   + 4 * pw.cout * cin * pw.taps + out.element_size() * out.numel())
     kind = ('conv3x3_s2' if stride == 2 else ('conv_up2x' if upsample else ('conv3x3_wino' if pw.wino else 'conv3x3'))) \
         if pw.taps == 9 else 'gemm1x1'
     if pw.taps == 9 and stride == 1 and ((in_nchw and c0 <= 4) or (out_nchw and pw.cout <= 4)):
         kind = 'conv3x3_io'   # the network's first / last conv: vector-ALU kernels, HBM-bound (conv3x3_few_cin / few_cout)
     if pw.bf16:
         kind += ('', '_bf16', '_f16', '_f16x2')[int(pw.bf16)]
+    if io == torch.bfloat16 and not pw.bf16:
+        kind += '_bf16io'     # fp32 operands on bf16 tensors (the 1x1 skips and the RGB head of the bf16 mode)
     if pw.conv1:
         kind = 'conv1x1_stream_f16x2'   # 1x1 on images through the split-half convolution kernel (HBM-bound), not the token GEMM
     if pw.wino == 2:
@@ -608,7 +642,7 @@ def groupnorm_tables(xs, gamma, beta, eps=GN_EPS, groups=GN_GROUPS):
     g_ptr, b_ptr, sc_ptr, sh_ptr = L.ptr(gamma), L.ptr(beta), L.ptr(scale), L.ptr(shift)
     coff = 0
     for t in xs:
-        _f32(t)
+        _act_dtype(t)
         c = t.shape[3]
         if c % cpg:
             raise ValueError('concat boundary splits a group')
@@ -617,6 +651,7 @@ def groupnorm_tables(xs, gamma, beta, eps=GN_EPS, groups=GN_GROUPS):
             # ~128 KB of input per block, enough blocks to cover 256 CUs several times, at most 256 partials per group
             nblk = max(1, min(256, (hw * c * 4 + (1 << 17) - 1) >> 17))
             part = torch.empty(B * (c // cpg) * nblk * 2, dtype=torch.float64, device=dev)
+            _f32(t)   # (the stand-alone pass reads fp32 tensors; bf16 tensors always carry the partials of their producer)
             L.check(lib.cf_groupnorm_stats(L.ptr(t), B, hw, c, cpg, L.ptr(part, dtype=torch.float64), nblk, L.stream_ptr()), 'cf_groupnorm_stats')
             st = GNStats(part, nblk, cpg)
         L.check(lib.cf_groupnorm_finalize(L.ptr(st.part, dtype=torch.float64), B, st.parts, c, st.cpg, cpg // st.cpg, hw * cpg,

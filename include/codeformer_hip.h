@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 21
+#define CF_ABI_VERSION 22
 #define CF_SPLITK_IN_WORKGROUP (-1) /* cf_conv_desc.split_k: see there (ABI v21) */
 
 typedef void* cf_stream_t; /* hipStream_t */
@@ -190,6 +190,14 @@ typedef struct cf_conv_desc {
    * below 2^-3.  Inputs that went through a GroupNorm prologue need none (their range is bounded by gamma, beta and the group size; the
    * host checks that bound when it packs the layer).  Ignored by the exact fp32 kernels. */
   const float* act_scale;
+  /* ABI v22: bf16 STORAGE of the activations of this launch (BASELINE configs 3 / 5: "bf16 = bf16 storage + fp32 accumulate in generator +
+   * CFT", vqgan_arch.py:276-323, codeformer_arch.py:136-157).  0: fp32 tensors (every launch of rounds 1-5).  1: in0, in1, res, sft_scale
+   * and out hold bf16 elements (2 bytes, dense NHWC; the float* fields are then typed loosely) -- consumers widen on load (exact),
+   * the epilogue rounds to nearest even once, AFTER the GroupNorm partials (stats_out) were taken from the fp32 values; prologue tables,
+   * bias, weights, accumulation and statistics are unchanged.  An NCHW output (the network's last conv) stays fp32.  Supported by the
+   * kernels the bf16 mode runs from 64x64 pixels up: winograd == 1 with CF_OPERAND_BF16 (cout % 128 == 0), the direct CF_OPERAND_BF16
+   * 3x3 (cout_pad 64) and folded upsample (cout_pad % 128 == 0) forms, fp32 1x1 on images (no split_k), the <= 4-channel NCHW head. */
+  int32_t io_bf16;
 } cf_conv_desc;
 
 int cf_conv2d(const cf_conv_desc* d, cf_stream_t stream);
@@ -337,6 +345,10 @@ int cf_tensor_to_img_u8(const float* t, int batch, int h, int w, uint8_t* img, c
 /* inpainting composite (inference_inpainting.py:68-74): x, y, out are [batch][3][h][w]; mask = (x0+x1+x2 == 3);
  * out = (1-mask)*x + mask*y */
 int cf_mask_composite(const float* x, const float* y, int batch, int h, int w, float* out, cf_stream_t stream);
+/* ABI v22: fp32 -> bf16 copy (round to nearest even) of `numel` elements (a multiple of 8): the fp32 activations that enter the
+ * bf16-storage part of the generator (cf_conv_desc.io_bf16) -- the decoder feature in front of the first bf16 Upsample
+ * (vqgan_arch.py:129-138) and the encoder taps the fusion blocks concatenate (codeformer_arch.py:152, :228-230). */
+int cf_f32_to_bf16(const float* x, int64_t numel, void* out, cf_stream_t stream);
 
 /* ---- bundled StyleGAN2 ops of basicsr/ops (unused by the hot path) ---------------
  * cf_fused_bias_act: basicsr/ops/fused_act/src/fused_bias_act_kernel.cu:20-50 forward (act=3, grad=0):

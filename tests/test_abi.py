@@ -33,7 +33,7 @@ def test_header_symbols_are_exported(native):
 
 
 def test_version_and_error_string(native):
-    assert native.cf_version() == lib.ABI_VERSION == 21
+    assert native.cf_version() == lib.ABI_VERSION == 22
     assert isinstance(lib.last_error(), str)
 
 

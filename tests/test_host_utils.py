@@ -237,12 +237,14 @@ def test_version_reads_are_safe_under_inference_mode():
 
 
 def test_bf16_gate_is_a_stated_multiple_of_the_intrinsic_cost(golden_dir):
-    """Where the bf16 pixel gate (0.18 / 0.014) comes from: the CPU oracle with bf16-rounded operands in the convolutions the 'bf16' mode
-    puts on bf16 MFMA, against the reference's fp32 output at w = 0.7 -- the cost of bf16 operands for any implementation.  The gate
-    must stay between 1.2x and 2x that cost (tools/bf16_gate_derivation.py; profiles/r05_bf16_gate_derivation.txt has the numbers)."""
+    """Where the bf16 pixel gate (0.196 / 0.0152) comes from: the CPU oracle with bf16-rounded operands in the convolutions the 'bf16' mode
+    puts on bf16 MFMA AND (round 6) bf16 storage of the generator / fusion activations of more than 1024 pixels, against the reference's fp32
+    output at w = 0.7 -- the cost of that arithmetic for any implementation.  The gate must stay between 1.2x and 2x that cost
+    (tools/bf16_gate_derivation.py; profiles/r06_bf16_gate_derivation.txt has the numbers: the last 'vs the same golden' line is the storage mode)."""
     import re
-    txt = open(os.path.join(ROOT, 'profiles', 'r05_bf16_gate_derivation.txt')).read()
-    mx, mean = (float(v) for v in re.search(r'vs the same golden: max ([0-9.]+) mean ([0-9.]+)', txt).groups())
-    assert 1.2 * mx <= 0.18 <= 2.0 * mx and 1.2 * mean <= 0.014 <= 2.0 * mean, (mx, mean)
+    txt = open(os.path.join(ROOT, 'profiles', 'r06_bf16_gate_derivation.txt')).read()
+    mx, mean = (float(v) for v in re.findall(r'vs the same golden: max ([0-9.]+) mean ([0-9.]+)', txt)[-1])
+    assert 'bf16 storage' in txt
+    assert 1.2 * mx <= 0.196 <= 2.0 * mx and 1.2 * mean <= 0.0152 <= 2.0 * mean, (mx, mean)
     src = open(os.path.join(ROOT, 'tests', 'test_gpu_real_images.py')).read()
-    assert "'bf16': (0.18, 0.014)" in src
+    assert "'bf16': (0.196, 0.0152)" in src

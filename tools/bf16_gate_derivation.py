@@ -9,7 +9,10 @@ rounded to bf16 (round-to-nearest-even), and compared with the reference's commi
 network with these weights; the gate is 1.5x its maximum and 1.25x its mean (an implementation may differ from this emulation in the
 summation order and in rounding folded upsample taps after folding instead of before).
 
-usage: python tools/bf16_gate_derivation.py        (about a minute on 8 cores; writes profiles/r05_bf16_gate_derivation.txt)
+Round 6: the 'bf16' mode also STORES the generator / fusion activations of more than 1024 pixels as bf16 (BASELINE: "bf16 storage + fp32
+accumulate"); the emulation gets the same storage points and the gate is re-derived from it.
+
+usage: python tools/bf16_gate_derivation.py        (a few minutes on 8 cores; writes profiles/r06_bf16_gate_derivation.txt)
 """
 import os
 import sys
@@ -38,7 +41,7 @@ def main():
     g = np.load(os.path.join(ROOT, 'tests', 'golden', 'restoration_seed0_face0_w0.7.npz'))
     ref = torch.from_numpy(g['out_sub'])
     plain = O.conv
-    state = {'on': False, 'n': 0}
+    state = {'on': False, 'n': 0, 'store': False, 'stored': 0}
 
     def conv_bf16(xx, sd_, p, stride=1, padding=1):
         wt = sd_[p + '.weight']
@@ -47,7 +50,34 @@ def main():
             return F.conv2d(xx.bfloat16().float(), wt.bfloat16().float(), sd_.get(p + '.bias'), stride=1, padding=padding)
         return plain(xx, sd_, p, stride=stride, padding=padding)
 
+    def q(t):
+        """bf16 STORAGE of a generator / fusion activation of more than 1024 pixels per image (round 6: cf_conv_desc.io_bf16): rounded to
+        nearest even once, where the producing launch writes it; smaller tensors (16x16, 32x32) stay fp32."""
+        if state['on'] and state['store'] and t.shape[-1] * t.shape[-2] > 1024:
+            state['stored'] += 1
+            return t.bfloat16().float()
+        return t
+
+    def res_block_e(x_in, sd_, p):      # vqgan_arch.py:153-164 with the product's storage points: conv1's output, the 1x1 skip, the block output
+        h = O.swish(O.group_norm(x_in, sd_, p + '.norm1'))
+        h = q(O.conv(h, sd_, p + '.conv1'))
+        h = O.swish(O.group_norm(h, sd_, p + '.norm2'))
+        h = O.conv(h, sd_, p + '.conv2')                      # (the fp32 accumulator: the residual is added before the one rounding)
+        if (p + '.conv_out.weight') in sd_:
+            x_in = q(O.conv(x_in, sd_, p + '.conv_out', padding=0))
+        return q(h + x_in)
+
+    def fuse_e(enc, dec, w, sd_, p):    # codeformer_arch.py:151-157: bf16 copy of the tap, e, the two LeakyReLU inputs, scale; the SFT combine rounds once
+        e = res_block_e(torch.cat([q(enc), dec], dim=1), sd_, p + '.encode_enc')
+        scale = q(O.conv(F.leaky_relu(q(O.conv(e, sd_, p + '.scale.0')), 0.2), sd_, p + '.scale.2'))
+        shift = O.conv(F.leaky_relu(q(O.conv(e, sd_, p + '.shift.0')), 0.2), sd_, p + '.shift.2')
+        return q(dec + w * (dec * scale + shift))
+
+    def upsample_e(xx, sd_, p):         # vqgan_arch.py:134-138: the bf16 copy of the 32x32 input is what the operand rounding gives anyway
+        return q(O.conv(F.interpolate(xx, scale_factor=2.0, mode='nearest'), sd_, p + '.conv'))
+
     gen = O.generator_forward
+    orig = (O.res_block, O.fuse_sft, O.upsample)
 
     def generator_bf16(*a, **k):      # generator + fusion blocks only: encoder and Transformer never run on bf16
         state['on'] = True
@@ -60,19 +90,29 @@ def main():
     out32, logits32, _ = O.codeformer_forward(x, sd, w=0.7, adain_flag=True)
     d32 = (out32[:, :, ::4, ::4] - ref).abs()
     lines.append(f'oracle fp32 vs reference golden (w=0.7, every 4th pixel): max {float(d32.max()):.3e} mean {float(d32.mean()):.3e}')
-    O.conv, O.generator_forward = conv_bf16, generator_bf16
-    try:
-        out16, logits16, _ = O.codeformer_forward(x, sd, w=0.7, adain_flag=True)
-    finally:
-        O.conv, O.generator_forward = plain, gen
-    d = (out16[:, :, ::4, ::4] - ref).abs()
-    mx, mean = float(d.max()), float(d.mean())
-    lines.append(f'oracle with bf16-rounded operands in {state["n"]} 3x3 convolutions of generator + fusion (fp32 accumulate) vs the same golden: '
-                 f'max {mx:.4f} mean {mean:.5f}  (output std {float(ref.std()):.3f}; logits bitwise those of the fp32 oracle: {bool(torch.equal(logits16, logits32))})')
-    lines.append(f'gate = 1.5 x max, 1.25 x mean of that intrinsic cost: max {1.5 * mx:.3f}  mean {1.25 * mean:.4f}')
+    res = {}
+    for store in (False, True):
+        state.update(n=0, stored=0, store=store)
+        O.conv, O.generator_forward = conv_bf16, generator_bf16
+        O.res_block, O.fuse_sft, O.upsample = res_block_e, fuse_e, upsample_e     # (q is the identity while `store` is off)
+        try:
+            out16, logits16, _ = O.codeformer_forward(x, sd, w=0.7, adain_flag=True)
+        finally:
+            O.conv, O.generator_forward = plain, gen
+            O.res_block, O.fuse_sft, O.upsample = orig
+        d = (out16[:, :, ::4, ::4] - ref).abs()
+        mx, mean = float(d.max()), float(d.mean())
+        res[store] = (mx, mean)
+        what = (f'bf16-rounded operands in {state["n"]} 3x3 convolutions of generator + fusion AND bf16 storage of the {state["stored"]} activations of more than 1024 pixels '
+                f'(rounded once where they are written; fp32 accumulate)') if store else \
+            f'bf16-rounded operands in {state["n"]} 3x3 convolutions of generator + fusion (fp32 accumulate, fp32 tensors: the mode of rounds 2-5)'
+        lines.append(f'oracle with {what} vs the same golden: max {mx:.4f} mean {mean:.5f}  (output std {float(ref.std()):.3f}; logits bitwise those of the '
+                     f'fp32 oracle: {bool(torch.equal(logits16, logits32))})')
+    mx, mean = res[True]
+    lines.append(f'gate of the storage mode = 1.5 x max, 1.25 x mean of its intrinsic cost: max {1.5 * mx:.3f}  mean {1.25 * mean:.4f}')
     txt = '\n'.join(lines)
     print(txt)
-    with open(os.path.join(ROOT, 'profiles', 'r05_bf16_gate_derivation.txt'), 'w') as f:
+    with open(os.path.join(ROOT, 'profiles', 'r06_bf16_gate_derivation.txt'), 'w') as f:
         f.write(txt + '\n')
 
 

@@ -161,7 +161,7 @@ def roofline_leg(net, x, w):
         'conv3x3_s2_f16x2': ('split_conv_kernel<4,...> (3x3 stride 2 as a 2x2 convolution of the space-to-depth input, split halves: 16 of which 9 tap blocks are non-zero)', 3.0 * 16.0 / 9.0, F16_MFMA_PEAK_TFLOPS, ('split_conv_kernel<4, 2, 2, true', 'split_conv_kernel<4, 1, 2, true')),
         'gemm1x1': ('igemm_kernel<1,1,...> (1x1 conv / Linear, fp32 MFMA)', 1.0, FP32_MFMA_PEAK_TFLOPS, ('igemm_kernel<1, 1',)),
         'conv1x1_stream_f16x2': ('split_conv_kernel<1,...> (1x1 skip convolutions on images of more than 1024 pixels, split halves: read-once / write-once streaming)', 0.0, HBM_PEAK_GBS, ('split_conv_kernel<1',)),
-        'gemm1x1_f16x2': ('gemm_split_tile_kernel (the parameter-bounded Linear layers of the Transformer on split halves: A and pre-split B fragments straight from L2, 3 f16 MFMAs per product)', 3.0, F16_MFMA_PEAK_TFLOPS, ('gemm_split_tile_kernel', 'gemm_split_kernel')),
+        'gemm1x1_f16x2': ('gemm_split_tile_kernel (the parameter-bounded Linear layers of the Transformer on split halves: A and pre-split B fragments straight from L2, 3 f16 MFMAs per product)', 3.0, F16_MFMA_PEAK_TFLOPS, ('gemm_split_tile_kernel', 'gemm_split_kernel', 'gemm_split_chunk_kernel')),
     }
 
     def entry(kind):

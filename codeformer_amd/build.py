@@ -54,12 +54,40 @@ def needs_build():
     return built_id() != source_hash()
 
 
+FIXED_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c']
+
+
+def _cache_dir():
+    """Object cache: $CF_OBJ_CACHE, else build/objcache inside this checkout (git- and gpurun-ignored), else -- a read-only tree --
+    ~/.cache/codeformer_amd/obj; created with mode 0700 and never a shared world-writable directory: whatever sits in the cache under
+    the right name is linked into the library."""
+    for d in (os.environ.get('CF_OBJ_CACHE'), os.path.join(ROOT, 'build', 'objcache'), os.path.join(os.path.expanduser('~'), '.cache', 'codeformer_amd', 'obj')):
+        if not d:
+            continue
+        try:
+            os.makedirs(d, mode=0o700, exist_ok=True)
+            if os.access(d, os.W_OK):
+                return d
+        except OSError:
+            continue
+    raise RuntimeError('no writable object cache directory (set CF_OBJ_CACHE)')
+
+
+def _toolchain_id(hipcc):
+    """What else decides an object's bytes besides source, headers and -D flags: the compiler (its --version text) and the fixed flags."""
+    try:
+        ver = subprocess.run([hipcc, '--version'], capture_output=True, text=True, timeout=60).stdout
+    except Exception:   # noqa: BLE001
+        ver = 'unknown'
+    return (os.path.realpath(hipcc) + '\n' + ver + '\n' + ' '.join(FIXED_FLAGS)).encode()
+
+
 def _compile_one(args):
     hipcc, src, obj, flags = args
     if os.path.exists(obj):
         return obj, ''
     tmp = obj + f'.{os.getpid()}.tmp'
-    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c'] + flags + ['-o', tmp, src], capture_output=True, text=True)
+    r = subprocess.run([hipcc] + FIXED_FLAGS + flags + ['-o', tmp, src], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'hipcc failed on {os.path.basename(src)}:\n' + r.stdout + r.stderr)
     os.replace(tmp, obj)
@@ -67,8 +95,9 @@ def _compile_one(args):
 
 
 def build(force=False, verbose=False, out=None, defines=(), extra_sources=()):
-    """Compile every source of SOURCES for gfx950 (one hipcc process per file, in parallel; objects are cached by content hash under
-    $CF_OBJ_CACHE or /tmp/cf_objcache, so an edit recompiles one file) and link libcodeformer_hip.so in-tree.
+    """Compile every source of SOURCES for gfx950 (one hipcc process per file, in parallel; objects are cached under $CF_OBJ_CACHE or
+    build/objcache by a hash of source, headers, flags and the compiler's identity, so an edit recompiles one file and a
+    ROCm upgrade all of them) and link libcodeformer_hip.so in-tree.
     out / defines / extra_sources: experiment variants (tools/*): another output path, extra -D flags, extra .hip files."""
     import hashlib
     from concurrent.futures import ThreadPoolExecutor
@@ -76,8 +105,8 @@ def build(force=False, verbose=False, out=None, defines=(), extra_sources=()):
     if out is None and not defines and not extra_sources and not force and not needs_build():
         return LIB
     hipcc = _hipcc()
-    cache = os.environ.get('CF_OBJ_CACHE', '/tmp/cf_objcache')
-    os.makedirs(cache, exist_ok=True)
+    cache = _cache_dir()
+    tool = _toolchain_id(hipcc)
     headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')) + [os.path.join(ROOT, 'include', 'codeformer_hip.h')]
     hh = hashlib.sha256()
     for f in headers:
@@ -90,6 +119,7 @@ def build(force=False, verbose=False, out=None, defines=(), extra_sources=()):
         if os.path.basename(src) == 'cf_misc.hip':
             flags.append(f'-DCF_BUILD_ID="{build_id}"')    # (only this file reads it: the others stay cached across unrelated edits)
         h = hashlib.sha256(hh.digest())
+        h.update(tool)
         with open(src, 'rb') as fh:
             h.update(fh.read())
         h.update(' '.join(flags).encode())

@@ -310,9 +310,6 @@ __global__ __launch_bounds__(256) void gemm_split_tile_kernel(const GsArgs g) {
 // ((0 + P0) + P1) + ...), so all the kernels of this file agree BITWISE and the host may choose by the number of tiles in flight -- i.e.
 // by the batch -- without touching batch invariance.  No workspace, no counters.
 //   <1, 1>: 32 x 32 tiles -- the shipped instantiation, for launches of at most 2^20 outputs (one to four faces; at eight the N = 512 layers).
-#ifndef GS_CHUNK_PIN
-#define GS_CHUNK_PIN 1
-#endif
 constexpr int GS_CHUNK_MAXV = 8;   // K <= 1024: chunk sums of a tile in LDS = V x MI x NI x 4 KB
 template <int MI, int NI>
 __global__ __launch_bounds__(256, MI * NI == 1 ? 1 : 2) void gemm_split_chunk_kernel(const GsArgs g) {
@@ -352,9 +349,7 @@ __global__ __launch_bounds__(256, MI * NI == 1 ? 1 : 2) void gemm_split_chunk_ke
           rb[s][ni][1] = *reinterpret_cast<const f32x4*>(wl + (size_t)ks * kstride + ni * 512 + 256);
         }
       }
-#if GS_CHUNK_PIN
       __builtin_amdgcn_sched_barrier(0);   // every request of the group above the first MFMA (hipcc otherwise sinks each load next to its use)
-#endif
 #pragma unroll
       for (int s = 0; s < HS; ++s) {
         f32x4 ah[MI], al[MI];
@@ -584,8 +579,10 @@ extern "C" int cf_pack_linear_weight_f16x2(const float* w, int n, int k, float s
 // Called by cf_conv2d (cf_igemm.hip) for taps == 1 descriptors with bf16_mfma == CF_OPERAND_F16X2; the common argument checks have run.
 int cf_gemm_split_geometry(const cf_conv_desc* d, int* tiles, long* bytes_per_part) {
   const long m = (long)d->batch * d->hout * d->wout;
-  CF_REQUIRE(d->taps == 1 && m % 64 == 0 && d->cout % 64 == 0 && d->cout_pad == d->cout && (d->c0 + d->c1) % 128 == 0,
-             "cf_conv2d(1x1, f16x2): M %ld and N %d must be multiples of 64, K %d of 128", m, d->cout, d->c0 + d->c1);
+  // (the weight packing fixes N % 64 == 0 for every form; the in-workgroup split -- 32 x 32 tiles -- takes M % 32 == 0, the others M % 64 == 0)
+  const int mq = d->split_k == CF_SPLITK_IN_WORKGROUP ? 32 : 64;
+  CF_REQUIRE(d->taps == 1 && m % mq == 0 && d->cout % 64 == 0 && d->cout_pad == d->cout && (d->c0 + d->c1) % 128 == 0,
+             "cf_conv2d(1x1, f16x2): M %ld must be a multiple of %d, N %d of 64, K %d of 128", m, mq, d->cout, d->c0 + d->c1);
   *tiles = (int)(m / 64) * (d->cout / 64);
   const int V = (d->c0 + d->c1) / 128;
   *bytes_per_part = 64L * 64 * 4 * V / (d->split_k > 0 ? d->split_k : 1);  // V chunk sums of 16 KB per tile in all
@@ -606,8 +603,8 @@ int cf_gemm_split_launch(const cf_conv_desc* d, hipStream_t stream) {
   const int V = d->c0 / 128;
   if (d->split_k == CF_SPLITK_IN_WORKGROUP) {   // the chunks of a tile shared by the waves of one workgroup (same bits)
     const long m = (long)d->batch * d->hout * d->wout;
-    CF_REQUIRE(V >= 1 && V <= GS_CHUNK_MAXV && d->cout % 32 == 0 && m % 32 == 0,
-               "cf_conv2d(1x1, f16x2, in-workgroup split): K %d must be a multiple of 128 up to %d, M and N multiples of 32", d->c0, GS_CHUNK_MAXV * 128);
+    CF_REQUIRE(V >= 1 && V <= GS_CHUNK_MAXV && m % 32 == 0,
+               "cf_conv2d(1x1, f16x2, in-workgroup split): K %d must be a multiple of 128 up to %d, M a multiple of 32 (N %% 64 == 0: the packing)", d->c0, GS_CHUNK_MAXV * 128);
     GsArgs g;
     g.a = d->in0;
     g.w = d->weight;

@@ -19,10 +19,6 @@
 
 #include "cf_common.h"
 
-// CF_ABLATE: timing-only ablation builds (tools/ablate.sh); 0 / undefined in every product build.
-#ifndef CF_ABLATE
-#define CF_ABLATE 0
-#endif
 // tuning knobs explored with tools/ab_variants.sh (defaults = the shipped configuration)
 #ifndef CF_LOADA_TAP
 #define CF_LOADA_TAP 0      // tap at which the next halo patch is prefetched into registers (0..8); 0 = a whole slab of cover (+1 % vs 8)
@@ -486,13 +482,9 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Arg
         constexpr int NA = (CF_LOADA_TAP >= 0) ? C::APT * AV : 0;           // halo-patch fetches riding in one step
         constexpr bool WEAVE = CF_INTERLEAVE && !LP && NM >= MI + NI + C::BPT + NA;
         // ---- first half: fetch slab s+2 (and, once per slab, the next halo patch), read frags(s, k 8..15), MFMA on frags(s, k 0..7)
-#if CF_ABLATE != 4
         load_B(step + 2 < nsteps ? step + 2 : nsteps - 1, rb);  // clamped: the tail prefetches are harmless re-reads
-#endif
         if (tap == CF_LOADA_TAP) load_A(chunk + 1 < a.nchunks ? chunk + 1 : chunk, ra);
-#if CF_ABLATE != 5
         read_frags(ay, by, tap_off(tap), slot, 1);
-#endif
         if (!WEAVE) __builtin_amdgcn_sched_barrier(0);  // pin the fetches above the MFMA block (hipcc would sink them)
         mma16(ax, bx);
         if (WEAVE) {
@@ -514,15 +506,11 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Arg
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- second half: read frags(s+1, k 0..7), MFMA on frags(s, k 8..15), LDS write of slab s+2
-#if CF_ABLATE != 5
         if (tap != TAPS - 1) read_frags(ax, bx, tap_off(tap + 1), slot1, 0);
-#endif
         if (!WEAVE) __builtin_amdgcn_sched_barrier(0);
         mma16(ay, by);
         if (!WEAVE) __builtin_amdgcn_sched_barrier(0);
-#if CF_ABLATE != 4
         store_B(slot2, rb);
-#endif
         if (WEAVE) {
 #pragma unroll
           for (int i = 0; i < (tap != TAPS - 1 ? MI + NI : 0); ++i) {
@@ -539,9 +527,7 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Arg
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-#if CF_ABLATE != 3
         __syncthreads();
-#endif
         if (tap == TAPS - 1 && chunk + 1 < a.nchunks) {
           store_A(0, ra, chunk + 1);
           __syncthreads();
@@ -907,19 +893,6 @@ __global__ __launch_bounds__(256, CF_WAVES_PER_SIMD) void igemm_kernel(const Arg
       }
     }
   };
-#if CF_ABLATE == 1
-  {  // no epilogue: keep the accumulators live, write one value
-    float t = 0.f;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) t += acc[mi][ni][r];
-    if (t == 12345.678f) a.out[0] = t;
-    return;
-  }
-#endif
   if constexpr (EXT) {  // host guarantees NHWC output with cout % 4 == 0
     switch (a.epilogue) {
       case CF_EPI_RESIDUAL: epilogue_vec(std::integral_constant<int, CF_EPI_RESIDUAL>{}); break;
@@ -1053,9 +1026,6 @@ __global__ __launch_bounds__(256) void conv3x3_few_cout_kernel(const ConvArgsExt
 // the thread keeps the 27 float4 weight rows of ITS channel quad in registers for all sixteen pixels it computes: the LDS-resident
 // weights cost one ds_read_b128 per tap and pixel, 3456 LDS wave-instructions per tile = 0.31 of the kernel's 0.39 ms per 16 faces.
 // The FMA chain (channel-major, then taps) and with it every bit of the output is unchanged.
-#ifndef FC_ABLATE   // timing-only ablations of the first conv: 1 no output store, 2 one tap instead of 27
-#define FC_ABLATE 0
-#endif
 template <int C0, bool NT = false>   // NT: non-temporal output stores (cf_common.h: cf_store16; a compile-time choice here -- sixteen stores per thread)
 __global__ __launch_bounds__(256) void conv3x3_few_cin_kernel(const ConvArgsExt a) {
   __shared__ float s_in[4][18 * 18];
@@ -1099,9 +1069,6 @@ __global__ __launch_bounds__(256) void conv3x3_few_cin_kernel(const ConvArgsExt 
       for (int c = 0; c < C0; ++c) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-#if FC_ABLATE & 2
-          if (tap || c) continue;
-#endif
           const float v = s_in[c][(py + tap / 3) * 18 + px + tap % 3];
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[e] = fmaf(v, wreg[c * 9 + tap][e], acc[e]);
@@ -1118,9 +1085,7 @@ __global__ __launch_bounds__(256) void conv3x3_few_cin_kernel(const ConvArgsExt 
         }
       }
     }
-#if !(FC_ABLATE & 1)
     cf_store16(a.out + (((size_t)b * a.hout + (y0 + py)) * a.wout + (x0 + px)) * a.cout + n, acc, NT);
-#endif
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       ssum[e] += acc[e];

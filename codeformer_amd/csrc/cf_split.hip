@@ -48,9 +48,6 @@
 
 // SP_ABLATE: timing-only ablation builds (tools/split_ab.sh), a bit mask: 1 no epilogue, 2 no weight fetch, 4 no weight LDS write,
 // 8 no fragment reads, 16 no per-step barrier, 32 no MFMA, 64 no activation gather, 128 no prologue/split; 0 in every product build.
-#ifndef SP_ABLATE
-#define SP_ABLATE 0
-#endif
 // SP_DESYNC: start skew of the first generation of workgroups, in sixteenths of (SP_DESYNC x main-loop steps x ~210 cycles); 0 = none
 #ifndef SP_DESYNC
 #define SP_DESYNC 0
@@ -455,24 +452,14 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 && TAPS != 1 && !(S2 &
       const int slot2 = slot1 == 2 ? 0 : slot1 + 1;
       const bool zero_cur = is_zero(tap);                                // (wave-uniform)
       const bool zero_next = tap != TAPS - 1 ? is_zero(tap + 1) : false;   // (the next slab's first tap always exists)
-#if !(SP_ABLATE & 2)
       load_B(step + 2 < nsteps ? step + 2 : nsteps - 1);  // clamped: the tail prefetches are harmless re-reads
-#endif
-#if !(SP_ABLATE & 64)
       if (tap == 0) load_A(ra, chunk + 1 < a.nchunks ? chunk + 1 : chunk);
-#endif
-#if !(SP_ABLATE & 8)
       if (!zero_cur) read_frags(fy, tap, slot, 1);
-#endif
       constexpr int NMF = MI * NI * 3;  // MFMAs per half step
       const bool weave = SP_WEAVE && !S2 && NMF >= 2 * (MI + NI) + C::BPT && tap != CONV_TAP && tap != 0;   // (the stride-2 form branches around its MFMA blocks: no weave)
       if (!weave) __builtin_amdgcn_sched_barrier(0);  // pin the fetches above the MFMA block (hipcc would sink them next to their use)
-#if !(SP_ABLATE & 32)
       if (!zero_cur) mma(fx);
-#endif
-#if !(SP_ABLATE & (64 | 128))
       if (tap == CONV_TAP) convert(ra);
-#endif
       if (weave) {
         // MFMA-first: frags(s, k 0..15) are in registers, so the half step opens with an MFMA and every LDS read / fetch issues in
         // the shadow of one
@@ -490,16 +477,10 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 && TAPS != 1 && !(S2 &
         for (int i = 0; i < NMF - 2 * (MI + NI) - C::BPT; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-#if !(SP_ABLATE & 8)
       if (tap != TAPS - 1 && !zero_next) read_frags(fx, tap + 1, slot1, 0);
-#endif
-#if !(SP_ABLATE & 32)
       if (!zero_cur) mma(fy);
-#endif
       if (!weave) __builtin_amdgcn_sched_barrier(0);
-#if !(SP_ABLATE & 4)
       store_B(slot2);
-#endif
       if (weave) {
 #pragma unroll
         for (int i = 0; i < (tap != TAPS - 1 ? 2 * (MI + NI) : 0); ++i) {
@@ -515,17 +496,11 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 && TAPS != 1 && !(S2 &
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-#if !(SP_ABLATE & 16)
       __syncthreads();
-#endif
       if (tap == TAPS - 1 && chunk + 1 < a.nchunks) {
-#if !(SP_ABLATE & 64)
         store_A(ra);
         __syncthreads();
-#endif
-#if !(SP_ABLATE & 8)
         read_frags(fx, 0, slot1, 0);
-#endif
       }
       slot = slot1;
     }
@@ -683,19 +658,6 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 && TAPS != 1 && !(S2 &
       }
     }
   };
-#if SP_ABLATE & 1
-  {  // no epilogue: keep the accumulators live, write one value
-    float t = 0.f;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) t += acc[mi][ni][r];
-    if (t == 12345.678f) a.out[0] = t;
-    return;
-  }
-#endif
   switch (a.epilogue) {
     case CF_EPI_RESIDUAL: epilogue(std::integral_constant<int, CF_EPI_RESIDUAL>{}); break;
     case CF_EPI_SFT: epilogue(std::integral_constant<int, CF_EPI_SFT>{}); break;

@@ -62,41 +62,13 @@
 // of two does not cover L2 latency: 0.79 vs 0.72 ms on 128 -> 128 @ 256x256 x 16).  Its M interval is bound by the weight stream: 36 x 32
 // x 128 x 4 B = 590 KB per slab through the CU's 64 B/clk vector-memory path (profiles/r04_f43_k32_stage_timing.txt).
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "cf_common.h"
 
-#ifndef F4_ABLATE   // timing-only ablation builds: 1 no MFMAs, 2 no transform, 4 no prologue + store, 8 no epilogue, 16 no weight fetch
-#define F4_ABLATE 0
-#endif
 
-#ifndef F4_K32_PAIR   // 32-channel-slab form, A/B record of round 5: 1 = a wave owns 9 positions x 2 channel blocks (an A fragment read from LDS feeds
-#define F4_K32_PAIR 0  // two MFMA triples: half the A-fragment LDS reads, 295 KB less per slab), 0 = 18 positions x 1 channel block (round 4, shipped).
-#endif                 // Bitwise the same results; measured flat on every shape (0.768 vs 0.772 ms on 128 -> 128 @ 256x256 x 16: profiles/r05_f43_pair_ab.txt)
-#ifndef F4_WIDE_DEFAULT   // form of the 16-wave workgroup when CF_F43_WIDE is not set (f4_wide_mode below)
-#define F4_WIDE_DEFAULT 1
-#endif
-#ifndef F4_OVL_PRIO   // A/B: s_setprio level of waves 0..3 inside their MFMA stage of the overlapped form (0: none)
-#define F4_OVL_PRIO 0
-#endif
 
-#ifndef F4_TIMING   // experiment builds only (tools/f43_timing.py): s_memtime stamps of one workgroup in the middle of the grid
-#define F4_TIMING 0
-#endif
-#if F4_TIMING
-__device__ unsigned long long f4_timing_buf[16 * 16];
-extern "C" int cf_debug_f4_timing(unsigned long long* host16x8) {
-  return hipMemcpyFromSymbol(host16x8, HIP_SYMBOL(f4_timing_buf), sizeof(f4_timing_buf)) == hipSuccess ? 0 : -1;
-}
-#define F4_T(slot)                                                   \
-  do {                                                               \
-    const unsigned long long t__ = __builtin_amdgcn_s_memtime();     \
-    tacc[slot] += t__ - tlast;                                       \
-    tlast = t__;                                                     \
-  } while (0)
-#else
-#define F4_T(slot) ((void)0)
-#endif
 
 namespace {
 
@@ -118,7 +90,6 @@ static_assert(F4_M_FLOATS <= 2 * F4_PATCH_FLOATS + F4_V_FLOATS, "epilogue stagin
 static_assert(F4_LDS_FLOATS * 4 <= 81920, "LDS budget of two workgroups per CU");
 constexpr int F4_LDS_FLOATS_16 = 2 * F4_M_FLOATS;   // 16-wave form: its epilogue pass stages 36 x 8 tiles x 128 channels = 147,456 bytes (the slab loop needs the 80,896 above)
 static_assert(F4_LDS_FLOATS_16 >= F4_LDS_FLOATS && F4_LDS_FLOATS_16 * 4 <= 163840, "LDS budget of the 16-wave form");
-static_assert(F4_LDS_FLOATS_16 >= 2 * F4_PATCH_FLOATS + 2 * F4_V_FLOATS + 2 * F4_TAB, "the overlapped form's two V buffers fit under the epilogue staging");
 constexpr int F4_LDS_FLOATS_32 = 2 * F4_SLOTS * 32 + 36 * F4_NT * 32 + 2 * F4_TAB;   // 16 waves, 32-channel slabs: 159,744 bytes
 static_assert(F4_LDS_FLOATS_32 >= F4_LDS_FLOATS_16 && F4_LDS_FLOATS_32 * 4 <= 163840, "LDS budget of the 32-channel-slab form");
 
@@ -136,11 +107,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t f4_rsrc(const void* p, unsigne
 __device__ __forceinline__ f32x4 f4_ld128(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
-#ifndef F4_RES_AUX   // A/B: cache-policy bits of the epilogue's residual / SFT operand loads (2 = nt: read once)
-#define F4_RES_AUX 0
-#endif
 __device__ __forceinline__ f4_f32x2 f4_ld64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  return __builtin_bit_cast(f4_f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, F4_RES_AUX));
+  return __builtin_bit_cast(f4_f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
 }
 __device__ __forceinline__ void f4_st64(f4_f32x2 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(f4_u32x2, v), r, (int)voff, (int)soff, 0);
@@ -181,13 +149,13 @@ __device__ __forceinline__ unsigned f4_vu(unsigned lq, unsigned p, unsigned t) {
 // F32 = IEEE-fp32 operands on v_mfma_f32_16x16x4_f32 (precision 'fp32': BASELINE config 2 to the letter) instead of hi + lo halves: the SAME
 // data movement -- a lane's A and B fragments are 16 (32) bytes either way: four (eight) fp32 values k = 4 j + (lane >> 4) instead of
 // [4 hi halves | 4 lo halves] -- with four (eight) fp32 MFMAs per position instead of three f16 ones; no weight / activation scale.
-// OVL (round 5; NW = 16, KS = 16 only): ONE barrier interval per slab with V double-buffered -- every wave multiplies slab s FIRST, then waves
-// 0..3 transform slab s + 1 into the other V buffer while the younger waves (which lose the arbitration for the vector-memory path and
-// finish their weight stream last) are still multiplying: see "The overlapped 16-wave form" at the slab loop.
-template <int PRO, int EPI, int NW, int KS, bool F32, bool OVL = false>
+// (Round 5 also built an overlapped 16-wave form -- one barrier interval per slab, V double-buffered, the transform of slab s + 1 under the
+// weight stream of slab s: bitwise the two-interval <., ., 16, 16> form, 4-13 % fewer cycles per patch and the same launch time at the
+// power cap, split-half operands in round 5 and fp32 operands in round 6 (profiles/r05_f43_ovl_stage_timing.txt, r06_f43_fp32_stage_timing.txt).
+// It is not part of the library; commit beb776c holds its source.)
+template <int PRO, int EPI, int NW, int KS, bool F32>
 __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
   static_assert(KS == 16 || (KS == 32 && NW == 16), "32-channel slabs need the LDS of the 16-wave form");
-  static_assert(!OVL || (NW == 16 && KS == 16), "the overlapped form: 16 waves on 16-channel slabs (two V buffers of 36 KB beside two patch buffers)");
   constexpr int F4_THREADS = NW * 64;
   constexpr int F4_BN = NW * 8;                  // output channels per workgroup
   constexpr int TWV = KS / 4;                    // transform waves: 256 (tile, channel pair, xi half) items per 16 channels
@@ -200,8 +168,8 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
   constexpr int PSK = F4_NT * KS;                // floats between positions of V
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const V = smem + 2 * PATCHF;
-  constexpr int VBUF = 36 * PSK;                   // floats per V buffer (OVL: two, slab parity)
-  float* const tab = V + (OVL ? 2 : 1) * VBUF;     // [scale: F4_TAB][shift: F4_TAB]
+  constexpr int VBUF = 36 * PSK;                   // floats of V
+  float* const tab = V + VBUF;                     // [scale: F4_TAB][shift: F4_TAB]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -221,13 +189,6 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
   const int y0 = tyw * F4_TH;
   const int x0 = (rt - tyw * a.tiles_x) * F4_TW;
   const int n = a.cin / KS;   // slabs
-#if F4_TIMING
-  // slots: 0 fill, 1 T work, 2 T barrier, 3 M work, 4 M barrier, 5 epilogue load + stage, 6 epilogue barriers, 7 epilogue compute + store
-  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long tlast = __builtin_amdgcn_s_memtime();
-  const unsigned long long tstart = tlast;
-  const unsigned long long rstart = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz: cycles / realtime = the shader clock this launch ran at
-#endif
 
   constexpr bool affine = PRO == CF_PRO_AFFINE || PRO == CF_PRO_AFFINE_SWISH;
   if (affine) {  // this image's GroupNorm rows -> LDS, read per slab by the patch store (first use is behind the first barrier)
@@ -364,7 +325,6 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
   // weight fragments are requested there: the first pass's column sums are dead, the live set is at its smallest).
   auto transform = [&](int chunk, auto mid) __attribute__((always_inline)) {
     const char* const pb = reinterpret_cast<const char*>(smem + (chunk & 1) * PATCHF);
-    float* const V = smem + 2 * PATCHF + (OVL ? (chunk & 1) * VBUF : 0);   // (shadows the kernel's V: this slab's buffer)
     unsigned ln = (unsigned)lane;
     asm volatile("" : "+v"(ln));  // opaque per slab (see above)
     // 16-channel slabs: wave = (xi half, tile half), lane = (tile, 8 channel pairs); 32-channel slabs: wave = (xi half, tile row), lane = (tile column, 16 pairs)
@@ -470,9 +430,7 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
   unsigned lane16;   // (rebuilt per slab, as a_base: see the transform)
   f32x4 bq[4];  // ring of weight fragments: hi | lo
   auto load_B = [&](int chunk, int i, auto nb) __attribute__((always_inline)) {
-#if !(F4_ABLATE & 16)
     bq[i % decltype(nb)::value] = f4_ld128(rs_w, lane16, w_s0 + (unsigned)i * w_pos + (unsigned)chunk * w_chunk);
-#endif
   };
   auto set_lane16 = [&]() __attribute__((always_inline)) {
     unsigned ln = (unsigned)lane;
@@ -482,11 +440,7 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
   const float* a_base;  // row = tile l15, channels 4 lq .. + 3
   f32x4 va[4];  // A fragments: hi | lo
   auto mfma = [&](float a0, float a1, float b0, float b1, f32x4& c) __attribute__((always_inline)) {
-#if F4_ABLATE & 1
-    c[0] += a0 + b1;
-#else
     c = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f4_f16x4, f4_f32x2{a0, a1}), __builtin_bit_cast(f4_f16x4, f4_f32x2{b0, b1}), c, 0, 0, 0);
-#endif
   };
   // Two positions at a time: lo*hi + hi*lo + hi*hi (the order of the F(2,3) kernels) into each position's accumulator, the two chains
   // interleaved (an MFMA never waits for its predecessor's result).  B fragments: ring of four, positions 0..3 requested in the T
@@ -498,7 +452,7 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
       unsigned ln = (unsigned)lane;
       asm volatile("" : "+v"(ln));
       const unsigned t15 = ln & 15u;
-      a_base = V + (OVL ? (chunk & 1) * VBUF : 0) + (18 * m_g) * PSK + t15 * CF_BK + (((ln >> 4) ^ (unsigned)f4_vs((int)(t15 >> 2))) << 2);
+      a_base = V + (18 * m_g) * PSK + t15 * CF_BK + (((ln >> 4) ^ (unsigned)f4_vs((int)(t15 >> 2))) << 2);
       lane16 = ln * 16u;
     }
     auto read_A = [&](int i) __attribute__((always_inline)) { va[i % NA] = *reinterpret_cast<const f32x4*>(a_base + i * PSK); };
@@ -515,13 +469,8 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
       if (F32) {  // k groups 0..3 in order, the two positions interleaved
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-#if F4_ABLATE & 1
-          acc[i][0] += a0[j] + b0[j];
-          acc[i + 1][0] += a1[j] + b1[j];
-#else
           acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b0[j], acc[i], 0, 0, 0);
           acc[i + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b1[j], acc[i + 1], 0, 0, 0);
-#endif
         }
       } else {
         mfma(a0[2], a0[3], b0[0], b0[1], acc[i]);
@@ -549,17 +498,15 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
   // one A register set, B ring of three positions (what 128 registers hold beside 72 accumulators), positions 0..2 requested in the T interval
   typedef _Float16 f4_f16x8 __attribute__((ext_vector_type(8)));
   f32x4 xb[3][2], xa[1][2];
-  // Unit i of a wave (F4_K32_PAIR): position p_g + (i >> 1) of its group of nine, channel block 2 (wave & 3) + (i & 1); accumulator i.
-  constexpr bool PAIR = F4_K32_PAIR && KS == 32;
-  const int p_g = PAIR ? 9 * (wave >> 2) : 18 * m_g;                     // first position of this wave
-  const int p_nb = PAIR ? 2 * (wave & 3) : m_nb;                        // first (only) 16-channel block
+  // (round 5 also measured a form in which a wave owns 9 positions x 2 channel blocks -- half the A-fragment LDS reads, bitwise the same, flat on
+  //  every shape: profiles/r05_f43_pair_ab.txt; the switch lives in tools/experiments/ablation_and_timing_macros.patch)
+  const int p_g = 18 * m_g;                     // first position of this wave
+  const int p_nb = m_nb;                        // its 16-channel block
   const unsigned w_s32 = (unsigned)p_g * w_pos + (unsigned)(n0 / 16 + p_nb) * (unsigned)(64 * KS);
   auto load_B32 = [&](int chunk, int i) __attribute__((always_inline)) {
-#if !(F4_ABLATE & 16)
-    const unsigned so = w_s32 + (PAIR ? (unsigned)(i >> 1) * w_pos + (unsigned)(i & 1) * (unsigned)(64 * KS) : (unsigned)i * w_pos) + (unsigned)chunk * w_chunk;
+    const unsigned so = w_s32 + (unsigned)i * w_pos + (unsigned)chunk * w_chunk;
     xb[i % 3][0] = f4_ld128(rs_w, lane16, so);
     xb[i % 3][1] = f4_ld128(rs_w, lane16 + 16u, so);
-#endif
   };
   auto mma_stage32 = [&](int chunk) __attribute__((always_inline)) {
     unsigned ao[4];
@@ -579,11 +526,7 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
       xa[0][1] = f32x4{p2[0], p2[1], p3[0], p3[1]};
     };
     auto mf = [&](f32x4 av, f32x4 bv, f32x4& c) __attribute__((always_inline)) {
-#if F4_ABLATE & 1
-      c[0] += av[0] + bv[1];
-#else
       c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f4_f16x8, av), __builtin_bit_cast(f4_f16x8, bv), c, 0, 0, 0);
-#endif
     };
     read_A(0);
 #pragma unroll
@@ -592,23 +535,15 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
       if (F32) {  // eight k groups: xa / xb [0] = j 0..3, [1] = j 4..7
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-#if F4_ABLATE & 1
-          acc[i][0] += xa[0][j >> 2][j & 3] + xb[i % 3][j >> 2][j & 3];
-#else
           acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0][j >> 2][j & 3], xb[i % 3][j >> 2][j & 3], acc[i], 0, 0, 0);
-#endif
         }
       } else {
         mf(xa[0][1], xb[i % 3][0], acc[i]);
         mf(xa[0][0], xb[i % 3][1], acc[i]);
         mf(xa[0][0], xb[i % 3][0], acc[i]);
       }
-      // (one register set: the next fragment is read once this position's MFMAs are issued -- 128 registers; PAIR: after its second channel block)
-      if (PAIR) {
-        if ((i & 1) && i + 1 < 18) read_A((i + 1) >> 1);
-      } else if (i + 1 < 18) {
-        read_A(i + 1);
-      }
+      // (one register set: the next fragment is read once this position's MFMAs are issued -- 128 registers)
+      if (i + 1 < 18) read_A(i + 1);
       if (i + 3 < 18) load_B32(chunk, i + 3);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -622,9 +557,7 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
   constexpr std::integral_constant<int, 4> na_gather{};   // (12 gather registers at most cross the M interval: room for the A prefetch)
   auto feed = [&](int s) __attribute__((always_inline)) {  // waves 4..7: prologue + store of slab s (if any); its successor is requested inside the M interval
     if (s < n) {
-#if !(F4_ABLATE & 4)
       store_patch(s);
-#endif
     }
   };
 
@@ -636,9 +569,7 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
     if (wave < TWV) {
       __syncthreads();
       __syncthreads();  // patch(0) visible
-      F4_T(0);
       for (int s = 0; s < n; ++s) {
-#if !(F4_ABLATE & 2)
         transform(s, [&]() __attribute__((always_inline)) {
           set_lane32();
           load_B32(s, 0);
@@ -646,19 +577,11 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
         __builtin_amdgcn_sched_barrier(0);
         load_B32(s, 1);
         load_B32(s, 2);
-#else
-        set_lane32();
-        for (int i = 0; i < 3; ++i) load_B32(s, i);
-#endif
         __builtin_amdgcn_sched_barrier(0);
-        F4_T(1);
         __syncthreads();  // V(s) and patch(s + 1) visible
-        F4_T(2);
         mma_stage32(s);
         __builtin_amdgcn_sched_barrier(0);
-        F4_T(3);
         __syncthreads();  // V and patch(s) are free
-        F4_T(4);
       }
     } else {
       // the gather of a slab in two halves of three items (12 registers): half 0 is requested behind the M interval (12 registers beside the fragment rings), half 1 at the top of the
@@ -670,13 +593,9 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
         if (s < n) {
           load_A_range(s, h1, h2);   // (its own registers: no fragment ring is live in the T interval)
           __builtin_amdgcn_sched_barrier(0);
-#if !(F4_ABLATE & 4)
           store_patch_range(s, h0, h1);
-#endif
           __builtin_amdgcn_sched_barrier(0);
-#if !(F4_ABLATE & 4)
           store_patch_range(s, h1, h2);
-#endif
         }
       };
       load_A_range(0, h0, h1);
@@ -684,7 +603,6 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
       feed2(0);
       if (n > 1) load_A_range(1, h0, h1);
       __syncthreads();
-      F4_T(0);
       for (int s = 0; s < n; ++s) {
         feed2(s + 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -692,132 +610,18 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) load_B32(s, i);
         __builtin_amdgcn_sched_barrier(0);
-        F4_T(1);
         __syncthreads();
-        F4_T(2);
         mma_stage32(s);
         __builtin_amdgcn_sched_barrier(0);
         if (s + 2 < n) load_A_range(s + 2, h0, h1);
         __builtin_amdgcn_sched_barrier(0);
-        F4_T(3);
         __syncthreads();
-        F4_T(4);
-      }
-    }
-  } else if constexpr (OVL) {
-    // ---- The overlapped 16-wave form.  The two-interval loop below leaves the vector-memory path idle while the patch is transformed
-    // (T, 25 % of a patch's cycles) and the matrix / LDS side idle while the weight fragments stream (M: 295 KB per 16-channel slab
-    // at ~57 B/clk; the OLD waves win the arbitration and finish their 18 positions in a third of the interval, then wait at the
-    // barrier -- profiles/r04_f43_k32_stage_timing.txt).  Here an interval is  M(s) | transform(s + 1)  for waves 0..3 and
-    // store(patch s + 2) | M(s)  for waves 4..15: V(s + 1) goes to the other V buffer, patch(s + 2) into the buffer transform(s) freed
-    // one interval ago.  Round 4 measured the opposite order (transform first: its waves then stream alone, latency-bound) as no gain.
-    // Arithmetic and summation order are those of the two-interval <., ., 16, 16> form: results are bitwise equal.
-    if (wave < 4) {
-      __syncthreads();  // (the GroupNorm rows are in LDS)
-      __syncthreads();  // patch(0) visible
-      transform(0, [&]() __attribute__((always_inline)) {
-        set_lane16();
-        load_B(0, 0, nb4);
-        load_B(0, 1, nb4);
-      });
-      __builtin_amdgcn_sched_barrier(0);
-      load_B(0, 2, nb4);
-      load_B(0, 3, nb4);
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();  // V(0) and patch(1) visible
-      F4_T(0);
-      int s = 0;
-      for (; s + 1 < n; ++s) {
-#if F4_OVL_PRIO
-        __builtin_amdgcn_s_setprio(F4_OVL_PRIO);
-#endif
-        mma_stage(s, na4, []() __attribute__((always_inline)) {});
-#if F4_OVL_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        F4_T(3);
-        transform(s + 1, [&]() __attribute__((always_inline)) {
-          set_lane16();
-          load_B(s + 1, 0, nb4);
-          load_B(s + 1, 1, nb4);
-        });
-        __builtin_amdgcn_sched_barrier(0);
-        load_B(s + 1, 2, nb4);
-        load_B(s + 1, 3, nb4);
-        __builtin_amdgcn_sched_barrier(0);
-        F4_T(1);
-        __syncthreads();  // V(s + 1) and patch(s + 2) visible; V(s) and patch(s + 1) are free
-        F4_T(4);
-      }
-      mma_stage(s, na4, []() __attribute__((always_inline)) {});
-      __builtin_amdgcn_sched_barrier(0);
-      F4_T(3);
-      __syncthreads();
-      F4_T(4);
-    } else {
-      constexpr std::integral_constant<int, 0> h0{};
-      constexpr std::integral_constant<int, F4_APT> h2{};
-      static_assert(!HALVES, "two gather items per thread");
-      load_A_range(0, h0, h2);
-      __syncthreads();  // (the GroupNorm rows are in LDS)
-#if !(F4_ABLATE & 4)
-      store_patch(0);
-#endif
-      if (n > 1) load_A_range(1, h0, h2);
-      __syncthreads();  // patch(0) visible
-#if !(F4_ABLATE & 4)
-      if (n > 1) store_patch(1);
-#endif
-      if (n > 2) load_A_range(2, h0, h2);
-      __builtin_amdgcn_sched_barrier(0);
-      set_lane16();
-#pragma unroll
-      for (int i = 0; i < 4; ++i) load_B(0, i, nb4);
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();  // V(0) and patch(1) visible
-      F4_T(0);
-      int s = 0;
-      for (; s + 3 < n; ++s) {   // (its own loop: the gather request must not sit under a condition, see the two-interval loop)
-#if !(F4_ABLATE & 4)
-        store_patch(s + 2);   // requested one interval ago
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        F4_T(1);
-        mma_stage(s, na_gather, [&]() __attribute__((always_inline)) { load_A_range(s + 3, h0, h2); });
-        __builtin_amdgcn_sched_barrier(0);
-        set_lane16();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) load_B(s + 1, i, nb4);
-        __builtin_amdgcn_sched_barrier(0);
-        F4_T(3);
-        __syncthreads();
-        F4_T(4);
-      }
-      for (; s < n; ++s) {   // the last three slabs: nothing left to request; the fragment prefetch of a slab past the end re-reads the last one (unused)
-#if !(F4_ABLATE & 4)
-        if (s + 2 < n) store_patch(s + 2);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        F4_T(1);
-        mma_stage(s, na_gather, []() __attribute__((always_inline)) {});
-        __builtin_amdgcn_sched_barrier(0);
-        set_lane16();
-        const int sn = s + 1 < n ? s + 1 : s;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) load_B(sn, i, nb4);
-        __builtin_amdgcn_sched_barrier(0);
-        F4_T(3);
-        __syncthreads();
-        F4_T(4);
       }
     }
   } else if (wave < 4) {
     __syncthreads();
     __syncthreads();  // patch(0) visible
-    F4_T(0);
     for (int s = 0; s < n; ++s) {
-#if !(F4_ABLATE & 2)
       transform(s, [&]() __attribute__((always_inline)) {
         set_lane16();
         load_B(s, 0, nb4);
@@ -826,19 +630,11 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
       __builtin_amdgcn_sched_barrier(0);
       load_B(s, 2, nb4);
       load_B(s, 3, nb4);
-#else
-      set_lane16();
-      for (int i = 0; i < 4; ++i) load_B(s, i, nb4);
-#endif
       __builtin_amdgcn_sched_barrier(0);
-      F4_T(1);
       __syncthreads();  // V(s) and patch(s + 1) visible
-      F4_T(2);
       mma_stage(s, na4, []() __attribute__((always_inline)) {});
       __builtin_amdgcn_sched_barrier(0);
-      F4_T(3);
       __syncthreads();  // V and patch(s) are free
-      F4_T(4);
     }
   } else {
     // With six items per thread (the 8-wave form) a slab's gather goes in two halves of three, as in the 32-channel-slab form: half 0
@@ -851,13 +647,9 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
       if (s < n) {
         if (HALVES) load_A_range(s, h1, h2);
         __builtin_amdgcn_sched_barrier(0);
-#if !(F4_ABLATE & 4)
         store_patch_range(s, h0, h1);
-#endif
         __builtin_amdgcn_sched_barrier(0);
-#if !(F4_ABLATE & 4)
         if (HALVES) store_patch_range(s, h1, h2);
-#endif
       }
     };
     load_A_range(0, h0, h1);
@@ -865,7 +657,6 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
     feedh(0);
     if (n > 1) load_A_range(1, h0, h1);
     __syncthreads();
-    F4_T(0);
     // (two loops: with the gather request under a condition inside one loop, hipcc's wait for the weight fragments requested before
     //  it must also be right for the path without the request -- and then waits for the gather as well)
     int s = 0;
@@ -876,14 +667,10 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) load_B(s, i, nb4);
       __builtin_amdgcn_sched_barrier(0);
-      F4_T(1);
       __syncthreads();
-      F4_T(2);
       mma_stage(s, na_gather, [&]() __attribute__((always_inline)) { load_A_range(s + 2, h0, h1); });
       __builtin_amdgcn_sched_barrier(0);
-      F4_T(3);
       __syncthreads();
-      F4_T(4);
     }
     for (; s < n; ++s) {  // the last two slabs: nothing left to request
       feedh(s + 1);
@@ -892,20 +679,13 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) load_B(s, i, nb4);
       __builtin_amdgcn_sched_barrier(0);
-      F4_T(1);
       __syncthreads();
-      F4_T(2);
       mma_stage(s, na_gather, []() __attribute__((always_inline)) {});
       __builtin_amdgcn_sched_barrier(0);
-      F4_T(3);
       __syncthreads();
-      F4_T(4);
     }
   }
 
-#if F4_ABLATE & 8
-  if (a.sft_w != 12345.f) return;
-#endif
   // ---- epilogue: two passes (tile columns 2 th, 2 th + 1) through LDS: M[36 positions][8 tiles][64 channels] over the patch buffers + V ----
   // staging: accumulator register r of position i is tile 4 lq + r (tile row lq = lane >> 4, tile column r), channel 16 m_nb + (lane & 15); pass th takes
   // r = 2 th, 2 th + 1 as staging tile tp = 2 lq + (r & 1).  item = (tp = wave, channel pair e_cp, output-row half e_rh).
@@ -943,13 +723,10 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
         if (EPI == CF_EPI_RESIDUAL || EPI == CF_EPI_SFT) r0[aa][c] = f4_ld64(rs_res, voff0, soff0 + aa * e_rowc + c * e_px);
       }
     __builtin_amdgcn_sched_barrier(0);
-    F4_T(5);
     if (th > 0) __syncthreads();  // the previous pass's reads are complete (first pass: the slab loop ended with a barrier)
-    F4_T(6);
 #pragma unroll
     for (int i = 0; i < 18; ++i) {
-      float* mp = PAIR ? Mst + ((p_g + (i >> 1)) * 8 + 2 * (lane >> 4)) * F4_BN + (p_nb + (i & 1)) * 16 + (lane & 15)
-                       : Mst + ((18 * m_g + i) * 8 + 2 * (lane >> 4)) * F4_BN + m_nb * 16 + (lane & 15);
+      float* mp = Mst + ((18 * m_g + i) * 8 + 2 * (lane >> 4)) * F4_BN + m_nb * 16 + (lane & 15);
       mp[0] = acc[i][2 * th];
       mp[F4_BN] = acc[i][2 * th + 1];
     }
@@ -959,9 +736,7 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) r1[aa][c] = f4_ld64(rs_sft, voff0, soff0 + aa * e_rowc + c * e_px);
     }
-    F4_T(5);
     __syncthreads();
-    F4_T(6);
     const float* mq = Mst + e_tp * F4_BN + 2 * e_cp;
     auto col = [&](int nu, f4_f32x2& tA, f4_f32x2& tB) __attribute__((always_inline)) {
       auto m = [&](int xi) __attribute__((always_inline)) { return *reinterpret_cast<const f4_f32x2*>(mq + ((xi * 6 + nu) * 8) * F4_BN); };
@@ -1047,7 +822,6 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
       psum = th == 0 ? dsum : psum + dsum;
       psq = th == 0 ? dsq : psq + dsq;
     }
-    F4_T(7);
   }
   if (a.stats_out) {
     // the waves' partials -> LDS (over the staging area: every wave is past its reads behind this barrier), summed in wave order by
@@ -1074,15 +848,6 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
       op[1] = s1;
     }
   }
-#if F4_TIMING
-  if (blockIdx.x == gridDim.x / 2 + 8 && lane == 0) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) f4_timing_buf[wave * 16 + k] = tacc[k];
-    f4_timing_buf[wave * 16 + 8] = tlast - tstart;
-    f4_timing_buf[wave * 16 + 9] = (unsigned long long)n;
-    f4_timing_buf[wave * 16 + 10] = __builtin_amdgcn_s_memrealtime() - rstart;
-  }
-#endif
 }
 
 // U' = scale * G' g G'^T (fp64, rounded once to fp32) as hi = f16(U'), lo = f16(U' - hi), in MFMA-operand order
@@ -1161,14 +926,15 @@ __global__ void pack_weight_wf43_kernel(const float* __restrict__ w, int cout, i
 
 // Form of the 16-wave (128-output-channel) workgroup; packing and launch agree through this one function:
 //   1  32-channel slabs, two barrier intervals per slab (rounds 4: v_mfma_f32_16x16x32_f16)            CF_F43_WIDE=k32
-//   2  16-channel slabs, ONE interval per slab with the transform under the weight stream (round 5)     CF_F43_WIDE=ovl
-//   0  16-channel slabs, two intervals (A/B only; also what cin % 32 != 0 runs in mode 1)                CF_F43_WIDE=k16 (or CF_F43_K32=0)
+//   0  16-channel slabs, two intervals (A/B only; also what cin % 32 != 0 runs in mode 1)                CF_F43_WIDE=k16
 static int f4_wide_mode() {
   static const int v = [] {
     const char* w = getenv("CF_F43_WIDE");
-    if (w) return w[0] == 'o' ? 2 : (w[0] == 'k' && w[1] == '1') ? 0 : 1;
-    const char* e = getenv("CF_F43_K32");
-    return e && atoi(e) == 0 ? 0 : F4_WIDE_DEFAULT;
+    if (!w || !strcmp(w, "k32")) return 1;
+    if (!strcmp(w, "k16")) return 0;
+    // (an A/B switch read once per process: a mistyped value must not silently measure another form)
+    fprintf(stderr, "libcodeformer_hip: CF_F43_WIDE=%s is not a form of the 16-wave F(4,3) workgroup (k32 | k16): using k32\n", w);
+    return 1;
   }();
   return v;
 }
@@ -1255,7 +1021,6 @@ int cf_wf43_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query) 
   a.nparts = a.tiles_per_img;
   const bool wide = d->cout % 128 == 0;                      // 16 waves x 128 channels where the layer has them ...
   const bool k32 = wide && (d->c0 + d->c1) % 32 == 0 && f4_k32_enabled();   // ... on 32-channel slabs where cin allows: the rule the pack functions lay the weight out by
-  const bool ovl = wide && f4_wide_mode() == 2;                             // ... or on 16-channel slabs with the transform under the weight stream
   CF_REQUIRE(!k32 || d->c0 % 32 == 0, "cf_conv2d(winograd 2): with cout %% 128 == 0 and cin %% 32 == 0 the concat boundary must be a multiple of 32 (c0 = %d)", d->c0);
   a.ntn = d->cout / (wide ? 128 : 64);
   a.nt_out = cf_nt_store((long)d->batch * d->hout * d->wout * d->cout * 4);
@@ -1263,17 +1028,15 @@ int cf_wf43_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query) 
     *parts_query = a.nparts;
     return CF_OK;
   }
-  const size_t lds = (k32 ? F4_LDS_FLOATS_32 : wide ? F4_LDS_FLOATS_16 : F4_LDS_FLOATS) * sizeof(float) + (F4_TIMING && !wide && getenv("CF_F43_ONE_WG") ? 32768 : 0);   // (timing builds: one workgroup per CU)
+  const size_t lds = (k32 ? F4_LDS_FLOATS_32 : wide ? F4_LDS_FLOATS_16 : F4_LDS_FLOATS) * sizeof(float);
   const dim3 grid(a.tiles_per_img * d->batch * a.ntn), block(wide ? 1024 : 512);
   // (cf_device_init sets the dynamic-LDS attribute of every instantiation on each device)
 #define F4_LAUNCH_OP(P, E, O)                                                                                                 \
   do {                                                                                                                        \
-    CF_LDS_ATTR((wf43_kernel<P, E, 8, 16, O>), F4_LDS_FLOATS * sizeof(float) + (F4_TIMING ? 32768 : 0));                      \
+    CF_LDS_ATTR((wf43_kernel<P, E, 8, 16, O>), F4_LDS_FLOATS * sizeof(float));                                            \
     CF_LDS_ATTR((wf43_kernel<P, E, 16, 16, O>), F4_LDS_FLOATS_16 * sizeof(float));                                            \
     CF_LDS_ATTR((wf43_kernel<P, E, 16, 32, O>), F4_LDS_FLOATS_32 * sizeof(float));                                            \
-    CF_LDS_ATTR((wf43_kernel<P, E, 16, 16, O, true>), F4_LDS_FLOATS_16 * sizeof(float));                                      \
     if (k32) hipLaunchKernelGGL((wf43_kernel<P, E, 16, 32, O>), grid, block, lds, stream, a);                                 \
-    else if (ovl) hipLaunchKernelGGL((wf43_kernel<P, E, 16, 16, O, true>), grid, block, lds, stream, a);                      \
     else if (wide) hipLaunchKernelGGL((wf43_kernel<P, E, 16, 16, O>), grid, block, lds, stream, a);                           \
     else hipLaunchKernelGGL((wf43_kernel<P, E, 8, 16, O>), grid, block, lds, stream, a);                                      \
   } while (0)

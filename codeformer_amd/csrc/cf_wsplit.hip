@@ -36,13 +36,6 @@
 
 // WS_ABLATE: timing-only ablation builds (tools/split_ab.sh); 0 / undefined in every product build.
 // 1 no MFMAs, 2 no MMA stage at all, 4 no transform, 8 no prologue + patch store, 16 no epilogue, 32 no weight fetch
-#ifndef WS_ABLATE
-#define WS_ABLATE 0
-#endif
-// WS_STORE_FIRST = 0: the feed stage in its first order (transform, then store) -- A/B timing only, same bits
-#ifndef WS_STORE_FIRST
-#define WS_STORE_FIRST 1
-#endif
 
 namespace {
 
@@ -281,10 +274,6 @@ __global__ __launch_bounds__(WS_THREADS, 1) void wsplit_kernel(const WsArgs a) {
       const f32x4 ah = va[nu & 1][0], al = va[nu & 1][NPART - 1];
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
-#if WS_ABLATE & 1
-        acc[nu][ni][0] += al[0] + ah[1] + bq[nu][ni][0][0] + bq[nu][ni][NPART - 1][1];
-        continue;
-#endif
         acc[nu][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ws_f16x8, al), __builtin_bit_cast(ws_f16x8, bq[nu][ni][0]),
                                                              acc[nu][ni], 0, 0, 0);
         acc[nu][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ws_f16x8, ah), __builtin_bit_cast(ws_f16x8, bq[nu][ni][NPART - 1]),
@@ -295,19 +284,13 @@ __global__ __launch_bounds__(WS_THREADS, 1) void wsplit_kernel(const WsArgs a) {
     }
   };
   auto mma_stage = [&](const float* V, int next_chunk) __attribute__((always_inline)) {
-#if !(WS_ABLATE & 2)
     read_A(V, 0);
-#endif
 #pragma unroll
     for (int nu = 0; nu < 4; ++nu) {
-#if !(WS_ABLATE & 2)
       if (nu < 3) read_A(V, nu + 1);
       __builtin_amdgcn_sched_barrier(0);
       mma(nu);
-#endif
-#if !(WS_ABLATE & 32)
       load_B(next_chunk, nu);  // refill for the next slab (clamped on the last one): a whole iteration of cover
-#endif
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -316,18 +299,9 @@ __global__ __launch_bounds__(WS_THREADS, 1) void wsplit_kernel(const WsArgs a) {
     // The store comes first: it retires the sixteen registers of the activation prefetch (values + GroupNorm rows) before the transform
     // takes its thirty-two (the two stages touch different buffers: patch[buf] / patch[buf ^ 1] -> V[buf ^ 1]).  In the other order the
     // GN-swish instantiations spilled ten registers: 0.877 -> 0.841 ms on 128->128 @256^2, 0.598 -> 0.543 ms on 64->128 (same bits).
-#if WS_STORE_FIRST
-#if !(WS_ABLATE & 8)
     if (k + 2 < n) store_patch(patch0 + buf * WS_PATCH_FLOATS);
-#endif
     __builtin_amdgcn_sched_barrier(0);
-#if !(WS_ABLATE & 4)
     if (k + 1 < n) transform(patch0 + (buf ^ 1) * WS_PATCH_FLOATS, V0 + (buf ^ 1) * WS_V_FLOATS);
-#endif
-#else
-    if (k + 1 < n) transform(patch0 + (buf ^ 1) * WS_PATCH_FLOATS, V0 + (buf ^ 1) * WS_V_FLOATS);
-    if (k + 2 < n) store_patch(patch0 + buf * WS_PATCH_FLOATS);
-#endif
     load_A(k + 3 < n ? k + 3 : n - 1);
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -426,9 +400,6 @@ __global__ __launch_bounds__(WS_THREADS, 1) void wsplit_kernel(const WsArgs a) {
         }
       }
     }
-#if WS_ABLATE & 16
-  if (a.sft_w != 12345.f) return;
-#endif
 #pragma unroll
   for (int pass = 0; pass < NI; ++pass) {
     f32x4 o[4];

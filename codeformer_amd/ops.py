@@ -247,7 +247,13 @@ def act_scale(x, x2=None, growth=4.0):
     them, from x itself; one launch (cf_act_scale_fused).  x2: the second half of a concatenated input -- the table then covers both.
     Cached on the tensor under (growth, tensor version): one table serves every conv that reads the tensor, and an in-place write
     (out= reuse, a user-held buffer) or another growth factor gets a fresh table; pairs are not cached."""
-    ver = tensor_version(x)   # None under torch.inference_mode(): no version to key the cache on, every call computes its table
+    ver = tensor_version(x)   # None under torch.inference_mode(): inference tensors keep no version counter
+    if ver is None and getattr(x, '_cf_stats', None) is not None:
+        # ... but a tensor that carries its producer's statistics is a conv2d output of THIS forward (a fresh torch.empty per launch, never
+        # written again): keyed on the object itself, one table serves all its consumers -- without this every consumer relaunched the
+        # kernel under inference_mode (and baked the extra launches into captured graphs).  User-held inference tensors (no statistics
+        # attached) still compute their table on every call.
+        ver = 'inference'
     if x2 is None and ver is not None:
         cached = getattr(x, '_cf_act', None)
         if cached is not None and cached[0] == (float(growth), ver):

@@ -178,7 +178,7 @@ typedef struct cf_conv_desc {
    * tile (cf_conv2d_tiles(d)), left at zero by every launch.
    * ABI v21: CF_SPLITK_IN_WORKGROUP (-1), taps == 1 with CF_OPERAND_F16X2 only (token GEMMs of one to a few faces): the K chunks of a
    * 32 x 32 output tile are shared by the four waves of ONE workgroup and added in chunk order through LDS -- the same bits as every
-   * other split count, no workspace / counters (K <= 1024, M % 32 == 0, N % 32 == 0). */
+   * other split count, no workspace / counters (K <= 1024, M % 32 == 0; N % 64 == 0 as for every form: the weight packing). */
   int32_t split_k;
   float* workspace;
   uint32_t* counters;

@@ -384,9 +384,10 @@ def test_winograd_f43_forms_against_fp64(sc):
 
 
 def test_process_level_ab_forms_are_bitwise_equal(sc):
-    """Forms that a process-level switch selects (read once per process by the library): the overlapped 16-wave F(4,3) form (CF_F43_WIDE=ovl)
-    against the two-interval form on the same 16-channel slabs (=k16), split-half and fp32 operands, and the stride-2 form with / without its
-    zero (tap, parity) blocks (CF_S2_SKIP=1 / 0): digests of outputs + GroupNorm partials from sub-processes must agree."""
+    """Forms that a process-level switch selects (read once per process by the library): the 16-wave F(4,3) workgroup on 32-channel slabs
+    (CF_F43_WIDE=k32, shipped) against 16-channel slabs (=k16) with IEEE-fp32 operands -- the same k groups in the same order on
+    v_mfma_f32_16x16x4_f32, so the bits agree (split-half operands use another MFMA per slab width and do not) -- and the stride-2 form with /
+    without its zero (tap, parity) blocks (CF_S2_SKIP=1 / 0): digests of outputs + GroupNorm partials from sub-processes must agree."""
     import re
     import subprocess
     import sys
@@ -399,9 +400,8 @@ def test_process_level_ab_forms_are_bitwise_equal(sc):
         assert len(d) >= 4 and all('False' not in x for x in d), r.stdout
         return d
 
-    for extra in ((), ('fp32',)):
-        assert digests('f43_ovl_ab.py', {'CF_F43_WIDE': 'ovl', 'F43_AB_DIGESTS_ONLY': '1'}, *extra) == \
-            digests('f43_ovl_ab.py', {'CF_F43_WIDE': 'k16', 'F43_AB_DIGESTS_ONLY': '1'}, *extra)
+    assert digests('f43_ovl_ab.py', {'CF_F43_WIDE': 'k32', 'F43_AB_DIGESTS_ONLY': '1'}, 'fp32') == \
+        digests('f43_ovl_ab.py', {'CF_F43_WIDE': 'k16', 'F43_AB_DIGESTS_ONLY': '1'}, 'fp32')
     assert digests('s2_skip_ab.py', {'CF_S2_SKIP': '1'}) == digests('s2_skip_ab.py', {'CF_S2_SKIP': '0'})
 
 

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs tools/experiments/ablation_and_timing_macros.patch applied to a scratch copy of csrc/: the scaffolds left the product sources in round 6)
 # Stage ablations of the F(4x4,3x3) kernel: gpurun_ablate/lib_ab*.so built by tools/split_ab.sh with -DF4_ABLATE=n (1 no MFMAs, 2 no
 # transform, 4 no prologue + store, 8 no epilogue, 16 no weight fetch).  Usage (GPU box, repo root): bash tools/f43_ablate.sh <tag>
 tag=${1:-1}

@@ -1,5 +1,6 @@
-"""A/B of the forms of the 16-wave F(4x4,3x3) workgroup (CF_F43_WIDE = k32 | k16 | ovl, read once per process by cf_wf43.hip):
-digests of outputs + GroupNorm partials on a few wide-layer shapes (k16 and ovl share arithmetic and summation order: equal digests)
+"""A/B of the forms of the 16-wave F(4x4,3x3) workgroup (CF_F43_WIDE = k32 | k16, read once per process by cf_wf43.hip; `ovl`, the overlapped
+form of round 5, needs a library built with tools/experiments/ablation_and_timing_macros.patch): digests of outputs + GroupNorm partials on a
+few wide-layer shapes (k16 and ovl share arithmetic and summation order: equal digests; with fp32 operands k32 agrees too)
 and launch times.  GPU box only.    usage: CF_F43_WIDE=<mode> python tools/f43_ovl_ab.py [fp32]"""
 import hashlib
 import importlib.util

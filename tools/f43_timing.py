@@ -1,4 +1,5 @@
-"""Per-stage shader-cycle sums of one workgroup of the F(4x4,3x3) kernel (library built with -DF4_TIMING=1, CF_LIB_PATH).
+"""Per-stage shader-cycle sums of one workgroup of the F(4x4,3x3) kernel (library built with -DF4_TIMING=1 from a scratch copy of csrc/ with
+tools/experiments/ablation_and_timing_macros.patch applied -- the stamps are not in the product sources since round 6; CF_LIB_PATH).
 usage: CF_LIB_PATH=gpurun_ablate/lib_timing.so python tools/f43_timing.py [cin cout H] [fp32]     (fp32: the IEEE-fp32-operand form)"""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

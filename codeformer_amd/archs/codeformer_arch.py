@@ -28,9 +28,14 @@ from .hip_module import PACK_EPOCH, HipModule
 from .vqgan_arch import ResBlock, VQAutoEncoder
 
 
+# The q | k and v projections of a Transformer layer as one split-half token GEMM (round 6; CODEFORMER_HIP_QKV_ONE_LAUNCH=0: two launches, A/B --
+# the same bits either way)
+QKV_ONE_LAUNCH = os.environ.get('CODEFORMER_HIP_QKV_ONE_LAUNCH', '1') != '0'
+
 # Graphed forwards share static input / output buffers per captured shape, so capture and replay are serialised (one lock for the
 # process: module attributes must stay picklable / deep-copyable).  The eager path (more than `graph_max_batch` faces) is re-entrant.
 _GRAPH_LOCK = threading.RLock()
+_CAPTURE_STREAMS = {}    # device -> the stream every graph of this process is captured on (its scratch words exist before the first capture)
 
 
 def calc_mean_std(feat, eps=1e-5):
@@ -91,17 +96,26 @@ class TransformerSALayer(HipModule):
         # a bound from the norm's parameters and one weight matrix (bounded_code); `code` (gemm_precision='f16x2') overrides the check
         c_o = code or bounded_code(self, 'o', code_ln, self.norm1, w[2 * E:], b[2 * E:])
         c_d = code or bounded_code(self, 'd', code_ln, self.norm2, self.linear1.weight, self.linear1.bias)
-        pw_qk = self._packed(('qk', c1), lambda: ops.pack_weight(w[:2 * E], b[:2 * E], bf16=c1), w, b)
-        pw_v = self._packed(('v', c1), lambda: ops.pack_weight(w[2 * E:], b[2 * E:], bf16=c1), w, b)
         pw_o = self._pw_conv(sa.out_proj, bf16=c_o)
         if pos is not None:
             t2, t2p = ops.layernorm(X, self.norm1.weight, self.norm1.bias, self.norm1.eps, pos=pos)
         else:
             t2 = t2p = ops.layernorm(X, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        qk = ops.linear(t2p, pw_qk)                      # q | k share the (LN(x)+pos) input
-        v = ops.linear(t2, pw_v)                         # v = LN(x) without pos (codeformer_arch.py:125-126)
+        if c1 == ops.GSPLIT and QKV_ONE_LAUNCH and (2 * E) % 128 == 0:
+            # split-half token GEMM: the whole in_proj (3 E rows) in ONE launch -- the q | k columns contract LN(x) + pos, the v columns LN(x)
+            # (cf_conv_desc.in0_alt; per output element the arithmetic of the two launches below -- with ONE power-of-two pack scale for the whole
+            #  in_proj instead of one per part, so q, k, v agree with the two-launch form to the last bits of the 22-bit operands, not bitwise)
+            pw_qkv = self._packed(('qkv', c1), lambda: ops.pack_weight(w, b, bf16=c1), w, b)
+            qkv = ops.linear(t2p, pw_qkv, x_alt=t2, alt_from=2 * E)
+            q, k, v = qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:]
+        else:
+            pw_qk = self._packed(('qk', c1), lambda: ops.pack_weight(w[:2 * E], b[:2 * E], bf16=c1), w, b)
+            pw_v = self._packed(('v', c1), lambda: ops.pack_weight(w[2 * E:], b[2 * E:], bf16=c1), w, b)
+            qk = ops.linear(t2p, pw_qk)                      # q | k share the (LN(x)+pos) input
+            v = ops.linear(t2, pw_v)                         # v = LN(x) without pos (codeformer_arch.py:125-126)
+            q, k = qk[:, :E], qk[:, E:]
         hd = E // H
-        a = ops.attention(qk[:, :E], qk[:, E:], v, batch, H, hd, float(hd) ** -0.5)
+        a = ops.attention(q, k, v, batch, H, hd, float(hd) ** -0.5)
         X = ops.linear(a, pw_o, epilogue=EPI_RESIDUAL, res=X)
         t2 = ops.layernorm(X, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         h = ops.linear(t2, self._pw_conv('linear1', bf16=c2), epilogue=EPI_GELU)
@@ -186,11 +200,19 @@ class Fuse_sft_block(HipModule):
         pws = [self._pw_conv(m, bf16, hw=hw) for m in (self.scale[0], self.scale[2], self.shift[0], self.shift[2])]
         rs = [ops.needs_act_scale(p) for p in pws]
         act_e = ops.act_scale(e) if (rs[0] or rs[2]) else None
-        s = ops.conv2d(e, pws[0], act=act_e, emit_stats=rs[1])
-        s = ops.conv2d(s, pws[1], prologue=PRO_LEAKY, act=ops.act_scale(s) if rs[1] else None)
-        h = ops.conv2d(e, pws[2], act=act_e, emit_stats=rs[3])
-        return ops.conv2d(h, pws[3], prologue=PRO_LEAKY, epilogue=EPI_SFT, res=dec, sft_scale=s, sft_w=float(w), emit_stats=True,
-                          act=ops.act_scale(h) if rs[3] else None)
+        if rs[1] and rs[3] and ops.ACT_FUSED:
+            # both second convolutions want a table: the two first convolutions write their statistics into one buffer and ONE launch turns
+            # them into both tables (bitwise act_scale of each) -- 4 launches fewer per forward
+            pair = ops.StatsPair()
+            s0 = ops.conv2d(e, pws[0], act=act_e, emit_stats=True, stats_into=pair)
+            h = ops.conv2d(e, pws[2], act=act_e, emit_stats=True, stats_into=pair)
+            act_s, act_h = ops.act_scale_pair(pair, e.shape[0])
+        else:
+            s0 = ops.conv2d(e, pws[0], act=act_e, emit_stats=rs[1])
+            h = ops.conv2d(e, pws[2], act=act_e, emit_stats=rs[3])
+            act_s, act_h = (ops.act_scale(s0) if rs[1] else None), (ops.act_scale(h) if rs[3] else None)
+        s = ops.conv2d(s0, pws[1], prologue=PRO_LEAKY, act=act_s)
+        return ops.conv2d(h, pws[3], prologue=PRO_LEAKY, epilogue=EPI_SFT, res=dec, sft_scale=s, sft_w=float(w), emit_stats=True, act=act_h)
 
     def forward(self, enc_feat, dec_feat, w=1):
         if enc_feat.is_cuda:
@@ -424,7 +446,16 @@ class CodeFormer(VQAutoEncoder):
                     self._forward_hip(static_x, w, code_only, adain)
                 torch.cuda.synchronize(x.device)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                # The zero-initialised scratch words of the range-scale / split-K kernels are kept per (device, stream).  Created inside the
+                # capture they would be two fill launches of every replay: create them for the capture stream first, outside the capture.
+                cap = _CAPTURE_STREAMS.get(str(x.device))
+                if cap is None:
+                    cap = _CAPTURE_STREAMS[str(x.device)] = torch.cuda.Stream(device=x.device)
+                with torch.cuda.stream(cap):
+                    ops._act_cells(x.device, 4 * max(int(x.shape[0]), 1))
+                    ops._counters(x.device, 4096)
+                cap.synchronize()
+                with torch.cuda.graph(graph, stream=cap):
                     outs = self._forward_hip(static_x, w, code_only, adain)
                 ent = {'graph': graph, 'x': static_x, 'outs': outs, 'epoch': PACK_EPOCH[0], 'sig': sig, 'idx': getattr(self, 'last_indices', None)}
                 self._graphs.pop(key, None)

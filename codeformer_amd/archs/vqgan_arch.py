@@ -32,8 +32,8 @@ def swish(x):
     return x * torch.sigmoid(x)
 
 
-def _gn_tables(norm, *xs):
-    return ops.groupnorm_tables(list(xs), norm.weight, norm.bias, norm.eps, norm.num_groups)
+def _gn_tables(norm, *xs, act_growth=None):
+    return ops.groupnorm_tables(list(xs), norm.weight, norm.bias, norm.eps, norm.num_groups, act_growth=act_growth)
 
 
 class VectorQuantizer(HipModule):
@@ -164,7 +164,8 @@ class ResBlock(HipModule):
         """bf16: operand code of the two 3x3 convs (fp32 accumulate / storage); the 1x1 skip follows it only for split-half codes on images
         (_skip_nhwc), otherwise it stays on the fp32 GEMM."""
         xs = (x,) if x2 is None else (x, x2)
-        sc, sh = _gn_tables(self.norm1, *xs)
+        # (a channel-changing block: the skip convolution's range-scale table of the same input rides in the finalize launch)
+        sc, sh = _gn_tables(self.norm1, *xs, act_growth=4.0 if self._skip_streams(x, x2, bf16) else None)
         hw = x.shape[1:3]
         npix = hw[0] * hw[1]
         code1 = self._range_code(self.norm1, bf16, npix * self.in_channels // GN_GROUPS)
@@ -178,16 +179,22 @@ class ResBlock(HipModule):
         return ops.conv2d(h, self._pw_conv('conv2', code2, hw=hw), prologue=PRO_AFFINE_SWISH, scale=sc, shift=sh,
                           epilogue=EPI_RESIDUAL, res=skip, emit_stats=True)
 
+    def _skip_streams(self, x, x2, code):
+        """True when the 1x1 skip convolution of this block runs on the streaming split-half kernel (and therefore wants act_scale(x, x2))."""
+        if self.in_channels == self.out_channels:
+            return False
+        c_split = None if x2 is None else x.shape[3]
+        stored = x.dtype == torch.bfloat16 and getattr(x, '_cf_stats', None) is not None and (x2 is None or getattr(x2, '_cf_stats', None) is not None)
+        return bool((int(code) in (2,) + ops.SPLIT_CODES or stored) and ops.RANGE_SCALE and
+                    ops.split_1x1_ok(self.in_channels, self.out_channels, x.shape[1], x.shape[2], c_split))
+
     def _skip_nhwc(self, x, x2, code):
         """The 1x1 skip convolution.  With split-half operands requested and an image of more than ops.TOKEN_IMAGE_MAX pixels it streams
         through the split-half convolution kernel (these layers are HBM-bound; the fp32 MFMA GEMM holds them at 2-4 TB/s); the input
         is the un-normalised block input, so it carries a range scale -- one table for both halves of a concatenated input."""
-        c_split = None if x2 is None else x.shape[3]
         # bf16 storage (x is a bf16 tensor that carries its producer's statistics): the same streaming kernel -- a bf16 value is its own hi
         # half, so the product is exact on the activation side; the fp32-MFMA GEMM ran these HBM-bound layers at 0.9 ms (128 -> 64 @512^2 x16)
-        stored = x.dtype == torch.bfloat16 and getattr(x, '_cf_stats', None) is not None and (x2 is None or getattr(x2, '_cf_stats', None) is not None)
-        if (int(code) in (2,) + ops.SPLIT_CODES or stored) and ops.RANGE_SCALE and \
-                ops.split_1x1_ok(self.in_channels, self.out_channels, x.shape[1], x.shape[2], c_split):
+        if self._skip_streams(x, x2, code):
             pw = self._packed(('conv_out', 'f16x2'), lambda: ops.pack_weight(self.conv_out.weight, self.conv_out.bias, bf16=ops.SPLIT),
                               self.conv_out.weight, self.conv_out.bias)
             return ops.conv2d(x, pw, x2=x2, act=ops.act_scale(x, x2))

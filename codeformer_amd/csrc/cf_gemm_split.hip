@@ -35,7 +35,13 @@ struct GsArgs {
   float* ws;
   unsigned* counters;
   int nsplit;
+  // Two token matrices in one launch (ABI v22, cf_conv_desc.in0_alt): output columns >= n_alt are contracted against the rows of a_alt
+  // instead of a -- the q|k projections read LayerNorm(x) + pos, the v projection LayerNorm(x) (codeformer_arch.py:125-126), one GEMM of
+  // N = 3 E.  A tile never straddles n_alt (a multiple of 128); per output element nothing changes.  a_alt == nullptr: one matrix.
+  const float* a_alt;
+  int n_alt;
 };
+__device__ __forceinline__ const float* gs_rows(const GsArgs& g, int n0) { return (g.a_alt && n0 >= g.n_alt) ? g.a_alt : g.a; }
 
 constexpr int GS_GROUP = 4;  // k steps (of 16) per prefetch group; a virtual chunk of 128 values = two groups
 
@@ -54,7 +60,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GsArgs g) {
   const int nv = V / g.nsplit;       // ... of this workgroup (host-checked: nsplit divides V)
   const int c0 = split * nv;
 
-  const float* const arow = g.a + (size_t)(m0 + l31) * g.K + half * 8 + (size_t)c0 * 128;
+  const float* const arow = gs_rows(g, n0) + (size_t)(m0 + l31) * g.K + half * 8 + (size_t)c0 * 128;
   const size_t kstride = (size_t)(g.N >> 5) * 512;  // floats between consecutive k steps of the packed weights
   const float* const wl = g.w + (size_t)(n0 >> 5) * 512 + lane * 4 + (size_t)c0 * 8 * kstride;
 
@@ -163,7 +169,7 @@ __global__ __launch_bounds__(256) void gemm_split_tile_kernel(const GsArgs g) {
   const int nst = g.K >> 5;  // stages of 32 K values
 
   // staging: item j of this thread is float4 #q of row (tid + 256 j) >> 3 of the tile's stage (k = 4 q .. 4 q + 3)
-  const float* const asrc = g.a + (size_t)(m0 + (tid >> 3)) * g.K + (tid & 7) * 4;
+  const float* const asrc = gs_rows(g, n0) + (size_t)(m0 + (tid >> 3)) * g.K + (tid & 7) * 4;
   // Operands in flight: THREE stages ahead in a ring of four register sets (a stage's MFMAs last ~0.2 us, a load 1-2 us: with one
   // stage ahead every stage waited for its operands -- 29.6 us on 4096 x 512 x 512, no better than the untiled kernel)
   f32x4 rg[4][4];
@@ -321,7 +327,7 @@ __global__ __launch_bounds__(256, MI * NI == 1 ? 1 : 2) void gemm_split_chunk_ke
   const int nt = blockIdx.x % ntn, mt = blockIdx.x / ntn;
   const int m0 = mt * (32 * MI), n0 = nt * (32 * NI);
   const int V = g.K >> 7;
-  const float* const arow = g.a + (size_t)(m0 + l31) * g.K + half * 8;
+  const float* const arow = gs_rows(g, n0) + (size_t)(m0 + l31) * g.K + half * 8;
   const size_t kstride = (size_t)(g.N >> 5) * 512;  // floats between consecutive k steps of the packed weights
   const float* const wl = g.w + (size_t)(n0 >> 5) * 512 + lane * 4;
   for (int c = wave; c < V; c += 4) {
@@ -424,7 +430,7 @@ __global__ __launch_bounds__(256) void gemm_f32_tile_kernel(const GsArgs g) {
   const int nst = g.K >> 5;  // stages of 32 K values
 
   // staging: item j of this thread is float4 #q of row (tid >> 3) + 32 j of the tile's stage (k = 4 q .. 4 q + 3)
-  const float* const asrc = g.a + (size_t)(m0 + (tid >> 3)) * g.K + (tid & 7) * 4;
+  const float* const asrc = gs_rows(g, n0) + (size_t)(m0 + (tid >> 3)) * g.K + (tid & 7) * 4;
   f32x4 rg[4][4];
   auto load_stage = [&](int st, auto buf) __attribute__((always_inline)) {
     constexpr int BUF = decltype(buf)::value;
@@ -600,12 +606,16 @@ int cf_gemm_split_launch(const cf_conv_desc* d, hipStream_t stream) {
   CF_REQUIRE(d->epilogue == CF_EPI_NONE || d->epilogue == CF_EPI_GELU || d->epilogue == CF_EPI_RESIDUAL,
              "cf_conv2d(1x1, f16x2): epilogues are none / GELU / residual");
   CF_REQUIRE(d->acc_scale > 0.f, "cf_conv2d(1x1, f16x2): acc_scale must be the inverse of the pack-time weight scale (got %g)", (double)d->acc_scale);
+  CF_REQUIRE(!d->in0_alt || (d->alt_cout0 > 0 && d->alt_cout0 < d->cout && d->alt_cout0 % 128 == 0),
+             "cf_conv2d(1x1, f16x2): in0_alt needs 0 < alt_cout0 < cout, a multiple of 128 (got %d of %d)", d->alt_cout0, d->cout);
   const int V = d->c0 / 128;
   if (d->split_k == CF_SPLITK_IN_WORKGROUP) {   // the chunks of a tile shared by the waves of one workgroup (same bits)
     const long m = (long)d->batch * d->hout * d->wout;
     CF_REQUIRE(V >= 1 && V <= GS_CHUNK_MAXV && m % 32 == 0,
                "cf_conv2d(1x1, f16x2, in-workgroup split): K %d must be a multiple of 128 up to %d, M a multiple of 32 (N %% 64 == 0: the packing)", d->c0, GS_CHUNK_MAXV * 128);
     GsArgs g;
+    g.a_alt = d->in0_alt;
+    g.n_alt = d->alt_cout0;
     g.a = d->in0;
     g.w = d->weight;
     g.bias = d->bias;
@@ -630,6 +640,8 @@ int cf_gemm_split_launch(const cf_conv_desc* d, hipStream_t stream) {
   CF_REQUIRE(V % nsplit == 0, "cf_conv2d(1x1, f16x2): split_k %d must divide K/128 = %d", nsplit, V);
   CF_REQUIRE(nsplit == 1 || (d->workspace && d->counters), "cf_conv2d(1x1, f16x2): split_k > 1 needs workspace and counters");
   GsArgs g;
+  g.a_alt = d->in0_alt;
+  g.n_alt = d->alt_cout0;
   g.a = d->in0;
   g.w = d->weight;
   g.bias = d->bias;
@@ -678,6 +690,8 @@ int cf_gemm_f32_tile_try(const cf_conv_desc* d, hipStream_t stream) {
   // 256 -> 512 19.0 -> 16.4 us, 512 -> 1024 52.7 -> 45.8, 1024 -> 512 54.7 -> 51.0).  A per-shape choice between bitwise-equal kernels.
   if (k == 512 && d->cout == 512) return 1;
   GsArgs g;
+  g.a_alt = nullptr;   // (fp32 operands: one token matrix per launch)
+  g.n_alt = 0;
   g.a = d->in0;
   g.w = d->weight;
   g.bias = d->bias;

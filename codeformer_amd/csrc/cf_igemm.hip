@@ -1399,6 +1399,8 @@ static int conv_dispatch(const cf_conv_desc* d, hipStream_t stream, int* pq) {
   CF_REQUIRE(d->cout_pad >= d->cout && d->cout_pad % 32 == 0, "cf_conv2d: cout_pad %d invalid for cout %d", d->cout_pad,
              d->cout);
 
+  CF_REQUIRE(!d->in0_alt || (d->taps == 1 && d->bf16_mfma == CF_OPERAND_F16X2 && (long)d->hout * d->wout <= CF_TOKEN_IMAGE_MAX && !d->io_bf16),
+             "cf_conv2d: in0_alt (a second token matrix for the columns >= alt_cout0) belongs to the split-half token GEMM");
   if (d->io_bf16) {   // bf16 tensors (ABI v22): exactly the launches the bf16 mode makes from 64x64 pixels up; anything else is refused, never reinterpreted
     const bool dense = ld0 == d->c0 && ld1 == d->c1 && ldo == d->cout && d->pad_mode == CF_PAD_ZERO && !d->in_nchw && d->stride == 1 && d->split_k < 1;
     const bool wino_bf16 = d->winograd == 1 && d->bf16_mfma == CF_OPERAND_BF16;

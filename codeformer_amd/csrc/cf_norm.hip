@@ -369,6 +369,123 @@ extern "C" int cf_act_scale_from_tensor(const float* x, int batch, int64_t n_per
   return CF_OK;
 }
 
+// ---- finalize of up to TWO tensors' partials (the halves of a concatenated GroupNorm input, codeformer_arch.py:152) and, optionally, the
+// range-scale table of the same tensor(s) in ONE launch (round 6).  A workgroup owns one (image, merged group) of tensor a or b and runs
+// gn_finalize_kernel's arithmetic on it -- the same loads in the same order, the same fixed-order sums: bitwise the tables of two
+// cf_groupnorm_finalize launches.  While it walks its partials it also keeps their largest sum of squares; with `act` set the workgroups
+// of an image meet in cells[2b] (atomic maximum of the non-negative float bits) / cells[2b + 1] (tickets) exactly as the workgroups of
+// act_scale_fused_kernel do, and the last arriver writes (s, 1 / s): maxima are order-independent and sqrt / rounding are monotone, so
+// the table is bitwise cf_act_scale_fused's.  One-face calls: 11 launches fewer per forward.
+__global__ __launch_bounds__(256) void gn_finalize2_kernel(const double* __restrict__ part_a, int nparts_a, int c_a, int cpg_a, int gmerge_a,
+                                                           const double* __restrict__ part_b, int nparts_b, int c_b, int cpg_b, int gmerge_b,
+                                                           double inv_count, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                           float* __restrict__ scale, float* __restrict__ shift, int ld, float growth,
+                                                           unsigned* __restrict__ cells, float* __restrict__ act) {
+  __shared__ double red[4][2];
+  __shared__ float redm[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int GMa = c_a / (cpg_a * gmerge_a), GMb = part_b ? c_b / (cpg_b * gmerge_b) : 0;
+  const int per_img = GMa + GMb;
+  const int b = blockIdx.x / per_img;
+  int m = blockIdx.x - b * per_img;
+  const bool second = m >= GMa;
+  if (second) m -= GMa;
+  const int nparts = second ? nparts_b : nparts_a, C = second ? c_b : c_a, cpg = second ? cpg_b : cpg_a, gmerge = second ? gmerge_b : gmerge_a;
+  const int coff = second ? c_a : 0;
+  const int G = C / cpg;
+  const double2* p = reinterpret_cast<const double2*>(second ? part_b : part_a) + ((size_t)b * G + (size_t)m * gmerge) * nparts;
+  const int n = gmerge * nparts;
+  double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0}, qm = 0;
+  bool bad = false;
+  int j = tid;
+  for (; j + 768 < n; j += 1024) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const double2 v = p[j + 256 * u];
+      s[u] += v.x;
+      q[u] += v.y;
+      bad |= !(v.y == v.y) || v.y > 3.0e38;
+      qm = v.y > qm ? v.y : qm;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (j + 256 * u < n) {
+      const double2 v = p[j + 256 * u];
+      s[u] += v.x;
+      q[u] += v.y;
+      bad |= !(v.y == v.y) || v.y > 3.0e38;
+      qm = v.y > qm ? v.y : qm;
+    }
+  }
+  double ss = (s[0] + s[1]) + (s[2] + s[3]), qq = (q[0] + q[1]) + (q[2] + q[3]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ss += __shfl_xor(ss, o, 64);
+    qq += __shfl_xor(qq, o, 64);
+  }
+  float mx = (float)sqrt(qm) * 1.0000002f;   // (act_scale_fused_kernel's bound of this slice)
+  if (bad) mx = __builtin_inff();
+  mx = cf_wave_max(mx);
+  if (lane == 0) {
+    red[wave][0] = ss;
+    red[wave][1] = qq;
+    redm[wave] = mx;
+  }
+  __syncthreads();
+  ss = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+  qq = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+  const double mean = ss * inv_count;
+  double var = qq * inv_count - mean * mean;
+  if (var < 0) var = 0;
+  const float fmean = (float)mean;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const int cpm = cpg * gmerge;
+  for (int i = tid; i < cpm; i += 256) {
+    const int c = coff + m * cpm + i;
+    const float sc = rstd * gamma[c];
+    scale[(size_t)b * ld + c] = sc;
+    shift[(size_t)b * ld + c] = -sc * fmean + beta[c];
+  }
+  if (act && tid == 0) {
+    const float mm0 = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+    const unsigned before = __hip_atomic_fetch_max(cells + 2 * b, __builtin_bit_cast(unsigned, mm0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::"v"(before) : "memory");  // the maximum has been applied before the ticket is drawn
+    const unsigned ticket = __hip_atomic_fetch_add(cells + 2 * b + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ticket == (unsigned)per_img - 1u) {
+      const unsigned bits = __hip_atomic_exchange(cells + 2 * b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(cells + 2 * b + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float mm = __builtin_bit_cast(float, bits) * growth;
+      int k = 0;
+      if (mm > 0.f && mm < __builtin_inff()) {
+        int e;
+        (void)frexpf(mm, &e);
+        k = 14 - e;
+        k = k < -100 ? -100 : (k > 100 ? 100 : k);
+      }
+      act[2 * b] = ldexpf(1.f, k);
+      act[2 * b + 1] = ldexpf(1.f, -k);
+    }
+  }
+}
+
+extern "C" int cf_groupnorm_finalize2(const double* partial_a, int parts_a, int c_a, int cpg_a, int gmerge_a, const double* partial_b, int parts_b,
+                                      int c_b, int cpg_b, int gmerge_b, int batch, int64_t count, const float* gamma, const float* beta, float eps,
+                                      float* scale, float* shift, int ld, float act_growth, uint32_t* cells, float* act, cf_stream_t stream) {
+  CF_REQUIRE(partial_a && gamma && beta && scale && shift && batch >= 1, "cf_groupnorm_finalize2: null pointer");
+  CF_REQUIRE(cpg_a >= 1 && c_a % cpg_a == 0 && gmerge_a >= 1 && (c_a / cpg_a) % gmerge_a == 0 && parts_a >= 1 && count > 0,
+             "cf_groupnorm_finalize2: bad dims of the first tensor (c=%d cpg=%d gmerge=%d parts=%d)", c_a, cpg_a, gmerge_a, parts_a);
+  CF_REQUIRE(!partial_b || (cpg_b >= 1 && c_b % cpg_b == 0 && gmerge_b >= 1 && (c_b / cpg_b) % gmerge_b == 0 && parts_b >= 1 && cpg_a * gmerge_a == cpg_b * gmerge_b),
+             "cf_groupnorm_finalize2: bad dims of the second tensor (c=%d cpg=%d gmerge=%d parts=%d; both halves share the output group size)", c_b, cpg_b, gmerge_b, parts_b);
+  CF_REQUIRE(ld >= c_a + (partial_b ? c_b : 0), "cf_groupnorm_finalize2: ld %d smaller than the channel count", ld);
+  CF_REQUIRE(!act || (cells && act_growth > 0.f), "cf_groupnorm_finalize2: the range-scale table needs the cells and a positive growth");
+  const int per_img = c_a / (cpg_a * gmerge_a) + (partial_b ? c_b / (cpg_b * gmerge_b) : 0);
+  hipLaunchKernelGGL(gn_finalize2_kernel, dim3((unsigned)(batch * per_img)), dim3(256), 0, (hipStream_t)stream, partial_a, parts_a, c_a, cpg_a, gmerge_a,
+                     partial_b, parts_b, c_b, cpg_b, gmerge_b, 1.0 / (double)count, gamma, beta, eps, scale, shift, ld, act_growth, cells, act);
+  CF_CHECK_LAUNCH("cf_groupnorm_finalize2");
+  return CF_OK;
+}
+
 extern "C" int cf_groupnorm_finalize(const double* partial, int batch, int parts, int c, int cpg, int gmerge,
                                      int64_t count, const float* gamma, const float* beta, float eps, float* scale,
                                      float* shift, int ld, cf_stream_t stream) {

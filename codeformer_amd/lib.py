@@ -43,6 +43,7 @@ class ConvDesc(ctypes.Structure):
         ('split_k', ctypes.c_int32), ('workspace', ctypes.c_void_p), ('counters', ctypes.c_void_p),
         ('act_scale', ctypes.c_void_p),
         ('io_bf16', ctypes.c_int32),
+        ('in0_alt', ctypes.c_void_p), ('alt_cout0', ctypes.c_int32),
     ]
 
 
@@ -77,6 +78,7 @@ SIGNATURES = {
     'cf_act_scale_from_tensor': (_I, [_P, _I, _L, _F, _P, _P, _P]),
     'cf_act_scale_fused': (_I, [_P, _I, _P, _I, _P, _L, _I, _F, _P, _P, _P]),
     'cf_groupnorm_finalize': (_I, [_P, _I, _I, _I, _I, _I, _L, _P, _P, _F, _P, _P, _I, _P]),
+    'cf_groupnorm_finalize2': (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _L, _P, _P, _F, _P, _P, _I, _F, _P, _P, _P]),
     'cf_layernorm': (_I, [_P, _I, _I, _P, _P, _F, _P, _I, _P, _P, _P]),
     'cf_attention': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
     'cf_argmax_rows': (_I, [_P, _I, _I, _P, _P]),

@@ -211,7 +211,7 @@ HALF_LIMIT = 65504.0 / 4.0    # largest |activation| a Winograd-domain IEEE-half
 
 def switches():
     """The module-level A/B switches a captured forward depends on (part of the graph-replay key of the arch modules)."""
-    return (SPLIT_WINOGRAD, F43_LAYERS, F43_WIDE_MIN_PIXELS, F43_WIDE_MIN_PIXELS_FP32, WINOGRAD_16BIT, RANGE_SCALE, ACT_FUSED, SPLITK_MAX, GEMM_IN_WG_MAX_OUTPUTS)
+    return (SPLIT_WINOGRAD, F43_LAYERS, F43_WIDE_MIN_PIXELS, F43_WIDE_MIN_PIXELS_FP32, WINOGRAD_16BIT, RANGE_SCALE, ACT_FUSED, SPLITK_MAX, GEMM_IN_WG_MAX_OUTPUTS, FINALIZE_FUSED)
 
 
 def needs_act_scale(pw):
@@ -258,6 +258,10 @@ def act_scale(x, x2=None, growth=4.0):
         cached = getattr(x, '_cf_act', None)
         if cached is not None and cached[0] == (float(growth), ver):
             return cached[1]
+    if x2 is not None:      # a table groupnorm_tables([x, x2], act_growth=...) wrote in its own launch
+        cached = getattr(x, '_cf_act_pair', None)
+        if cached is not None and cached[2] == id(x2) and cached[0] == _act_key(x, growth) and cached[1] == _act_key(x2, growth):
+            return cached[3]
     lib = L.load()
     B = x.shape[0]
     act = torch.empty(B, 2, dtype=torch.float32, device=x.device)
@@ -291,6 +295,35 @@ def act_scale(x, x2=None, growth=4.0):
     if x2 is None and ver is not None:
         x._cf_act = ((float(growth), ver), act)
     return act
+
+
+class StatsPair:
+    """Shared statistics buffer of TWO sibling convolutions of equal shape (the scale.0 / shift.0 convolutions of a fusion block,
+    codeformer_arch.py:153-154): conv2d(..., stats_into=pair) places each launch's partials in one half, and act_scale_pair(pair, batch)
+    turns both into their range-scale tables with ONE cf_act_scale_fused launch over 2 x batch "images"."""
+
+    def __init__(self):
+        self.buf, self.n, self.used = None, 0, 0
+
+    def take(self, n, device):
+        if self.buf is None:
+            self.buf, self.n = torch.empty(2 * n, dtype=torch.float64, device=device), n
+        if n != self.n or self.used >= 2:
+            raise ValueError('StatsPair: two launches of equal statistics size')
+        self.used += 1
+        return self.buf[(self.used - 1) * n:self.used * n]
+
+
+def act_scale_pair(pair, batch, growth=4.0):
+    """((B, 2), (B, 2)) range-scale tables of the two tensors whose statistics share `pair` -- bitwise act_scale() of each, one launch."""
+    if pair.used != 2:
+        raise ValueError('act_scale_pair: the pair has not been filled by two launches')
+    lib = L.load()
+    act = torch.empty(2 * batch, 2, dtype=torch.float32, device=pair.buf.device)
+    cells = L.ptr(_act_cells(pair.buf.device, 2 * batch), dtype=torch.int32)
+    L.check(lib.cf_act_scale_fused(L.ptr(pair.buf, dtype=torch.float64), pair.n // (2 * batch), None, 0, None, 0, 2 * batch, float(growth), cells, L.ptr(act),
+                                   L.stream_ptr()), 'cf_act_scale_fused')
+    return act[:batch], act[batch:]
 
 
 def gn_range_ok(gmax, bmax, n):
@@ -490,7 +523,7 @@ def _counters(device, n):
 
 def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale=None, shift=None,
            epilogue=EPI_NONE, res=None, sft_scale=None, sft_w=0.0, in_nchw=False, out_nchw=False, emit_stats=False,
-           out=None, pad_mode=PAD_ZERO, pad_lo=0, split_k=None, act=None):
+           out=None, pad_mode=PAD_ZERO, pad_lo=0, split_k=None, act=None, x_alt=None, alt_from=0, stats_into=None):
     """Implicit-GEMM conv (3x3 / 1x1).  x: (B,H,W,C0) [x2: (B,H,W,C1) concatenated after x]; returns (B,Ho,Wo,cout)
     (or (B,cout,Ho,Wo) when out_nchw).  With in_nchw, x is (B,C<=4,H,W).
     emit_stats: also write the GroupNorm(32) partial statistics of the output in the epilogue and attach them to the
@@ -500,7 +533,11 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
     EPI_LEAKY / EPI_AXPY / EPI_AXPY2 use sft_w as alpha (see cf_epilogue in the header).
     pad_mode: PAD_ZERO, PAD_REFLECT (ReflectionPad2d(1) + unpadded 3x3) or PAD_EDGE (with upsample: reflection padding of the
     upsampled image); pad_lo=1 with stride 2: one padded row / column on every side instead of right / bottom only.
-    act: (B, 2) range-scale table of an un-normalised input (act_scale(x)); dropped when the layer's kernel has fp32 operands."""
+    act: (B, 2) range-scale table of an un-normalised input (act_scale(x)); dropped when the layer's kernel has fp32 operands.
+    stats_into: a StatsPair -- the statistics partials of this launch go into its shared buffer (two sibling convolutions whose range-scale
+    tables are then ONE launch: act_scale_pair).
+    x_alt / alt_from (split-half token GEMMs only): output columns >= alt_from read their rows from x_alt (same shape as x) -- two Linear
+    layers on two token matrices in one launch (q|k on LN(x) + pos, v on LN(x))."""
     lib = L.load()
     io = _act_dtype(x, 'x')            # float32, or bfloat16 = bf16 storage of every activation of the launch (io_bf16)
     if in_nchw:
@@ -564,6 +601,10 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
         sft_scale=L.ptr(sft_scale, True, dtype=io), sft_w=float(sft_w), out=L.ptr(out, not out_nchw, dtype=odt), bf16_mfma=int(pw.bf16),
         ld_in0=ld0, ld_in1=ld1, ld_out=ldo, pad_mode=int(pad_mode), pad_lo=int(pad_lo), winograd=int(pw.wino),
         acc_scale=1.0 / pw.scale, io_bf16=int(io == torch.bfloat16))
+    if x_alt is not None:
+        if tuple(x_alt.shape) != tuple(x.shape) or x_alt.dtype != torch.float32 or int(pw.bf16) != OPERAND_F16X2 or pw.taps != 1 or pw.conv1 or x2 is not None:
+            raise ValueError('x_alt: a second float32 token matrix of the same shape, for a split-half token GEMM (bf16=GSPLIT weight)')
+        d.in0_alt, d.alt_cout0 = L.ptr(x_alt), int(alt_from)
     if act is not None and needs_act_scale(pw):
         if tuple(act.shape) != (B, 2) or prologue not in (PRO_NONE, PRO_LEAKY):
             raise ValueError('act: expected a (B, 2) table and a none / leaky prologue')
@@ -584,7 +625,8 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
         parts = lib.cf_conv2d_stats_parts(ctypes.byref(d))
         if parts <= 0:
             raise RuntimeError(f'cf_conv2d_stats_parts failed ({parts}): {L.last_error()}')
-        part = torch.empty(B * GN_GROUPS * parts * 2, dtype=torch.float64, device=x.device)
+        n_part = B * GN_GROUPS * parts * 2
+        part = torch.empty(n_part, dtype=torch.float64, device=x.device) if stats_into is None else stats_into.take(n_part, x.device)
         d.stats_out = L.ptr(part, dtype=torch.float64)
         out._cf_stats = GNStats(part, parts, d.stats_cpg)
     if PROFILE is None:
@@ -618,23 +660,30 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
     return out
 
 
-def linear(x, pw, *, epilogue=EPI_NONE, res=None):
-    """x: (M, K) -> (M, N) through the 1x1 path of the same kernel (M must be a multiple of 256)."""
+def linear(x, pw, *, epilogue=EPI_NONE, res=None, x_alt=None, alt_from=0):
+    """x: (M, K) -> (M, N) through the 1x1 path of the same kernel (M must be a multiple of 256).
+    x_alt / alt_from: see conv2d (columns >= alt_from are x_alt @ W^T: two Linear layers, two inputs, one launch)."""
     M, K = x.shape
     if M % 256:
         raise ValueError(f'linear: rows {M} must be a multiple of 256')
     # present the token matrix as (M/256) "images" of 16x16 tokens: tile selection keys on the per-image shape only
     r4 = None if res is None else res.view(M // 256, 16, 16, pw.cout)
-    y = conv2d(x.view(M // 256, 16, 16, K), pw, epilogue=epilogue, res=r4)
+    y = conv2d(x.view(M // 256, 16, 16, K), pw, epilogue=epilogue, res=r4, x_alt=None if x_alt is None else x_alt.view(M // 256, 16, 16, K), alt_from=alt_from)
     return y.view(M, pw.cout)
 
 
-def groupnorm_tables(xs, gamma, beta, eps=GN_EPS, groups=GN_GROUPS):
+FINALIZE_FUSED = os.environ.get('CODEFORMER_HIP_FINALIZE_FUSED', '1') != '0'   # 0: one cf_groupnorm_finalize per tensor + separate range-scale launches (A/B; same bits)
+
+
+def groupnorm_tables(xs, gamma, beta, eps=GN_EPS, groups=GN_GROUPS, act_growth=None):
     """GroupNorm(groups) statistics of the channel-concatenation of xs (each (B,H,W,Ci)) folded with the affine
     parameters into per-(b,c) scale / shift tables (B, sum Ci), to be applied by a conv prologue.
 
     Tensors that carry epilogue statistics (`._cf_stats`, see conv2d(emit_stats=True)) are not read again; the others
-    go through the stand-alone statistics pass."""
+    go through the stand-alone statistics pass.
+    act_growth: the caller will also ask act_scale(*xs, growth=act_growth) (the block input that feeds both norm1 and the 1x1 skip
+    convolution): when every tensor carries statistics the SAME launch writes that table (cf_groupnorm_finalize2) and parks it where
+    act_scale finds it -- bitwise the table of the separate launch."""
     lib = L.load()
     B, H, W, _ = xs[0].shape
     ctot = sum(t.shape[3] for t in xs)
@@ -646,7 +695,7 @@ def groupnorm_tables(xs, gamma, beta, eps=GN_EPS, groups=GN_GROUPS):
     scale = torch.empty(B, ctot, dtype=torch.float32, device=dev)
     shift = torch.empty_like(scale)
     g_ptr, b_ptr, sc_ptr, sh_ptr = L.ptr(gamma), L.ptr(beta), L.ptr(scale), L.ptr(shift)
-    coff = 0
+    stats = []
     for t in xs:
         _act_dtype(t)
         c = t.shape[3]
@@ -660,11 +709,52 @@ def groupnorm_tables(xs, gamma, beta, eps=GN_EPS, groups=GN_GROUPS):
             _f32(t)   # (the stand-alone pass reads fp32 tensors; bf16 tensors always carry the partials of their producer)
             L.check(lib.cf_groupnorm_stats(L.ptr(t), B, hw, c, cpg, L.ptr(part, dtype=torch.float64), nblk, L.stream_ptr()), 'cf_groupnorm_stats')
             st = GNStats(part, nblk, cpg)
+            stats.append((st, False))
+        else:
+            stats.append((st, True))
+    if FINALIZE_FUSED and len(xs) <= 2:
+        # one launch for the tensor (or both halves of the concatenation), and the range-scale table with it when every half carries
+        # its producer's statistics (that is where act_scale would take the bound from as well)
+        want_act = act_growth is not None and RANGE_SCALE and ACT_FUSED and all(own for _, own in stats)
+        act = torch.empty(B, 2, dtype=torch.float32, device=dev) if want_act else None
+        cells = L.ptr(_act_cells(dev, B), dtype=torch.int32) if want_act else None
+        sa, ca = stats[0][0], xs[0].shape[3]
+        sb, cb = (stats[1][0], xs[1].shape[3]) if len(xs) == 2 else (None, 0)
+        L.check(lib.cf_groupnorm_finalize2(L.ptr(sa.part, dtype=torch.float64), sa.parts, ca, sa.cpg, cpg // sa.cpg,
+                                           None if sb is None else L.ptr(sb.part, dtype=torch.float64), 0 if sb is None else sb.parts, cb,
+                                           1 if sb is None else sb.cpg, 1 if sb is None else cpg // sb.cpg, B, hw * cpg, g_ptr, b_ptr, float(eps),
+                                           sc_ptr, sh_ptr, ctot, float(act_growth or 0.0), cells, L.ptr(act), L.stream_ptr()), 'cf_groupnorm_finalize2')
+        if want_act:
+            _park_act(xs, float(act_growth), act)
+        return scale, shift
+    coff = 0
+    for t, (st, _) in zip(xs, stats):
+        c = t.shape[3]
         L.check(lib.cf_groupnorm_finalize(L.ptr(st.part, dtype=torch.float64), B, st.parts, c, st.cpg, cpg // st.cpg, hw * cpg,
                                           g_ptr + 4 * coff, b_ptr + 4 * coff, float(eps), sc_ptr + 4 * coff,
                                           sh_ptr + 4 * coff, ctot, L.stream_ptr()), 'cf_groupnorm_finalize')
         coff += c
     return scale, shift
+
+
+def _act_key(x, growth):
+    ver = tensor_version(x)
+    if ver is None and getattr(x, '_cf_stats', None) is not None:
+        ver = 'inference'     # (see act_scale: a conv output of this forward)
+    return None if ver is None else (float(growth), ver)
+
+
+def _park_act(xs, growth, act):
+    """Leave a range-scale table computed elsewhere (groupnorm_tables) where act_scale(x[, x2]) looks first."""
+    k0 = _act_key(xs[0], growth)
+    if k0 is None:
+        return
+    if len(xs) == 1:
+        xs[0]._cf_act = (k0, act)
+    else:
+        k1 = _act_key(xs[1], growth)
+        if k1 is not None:
+            xs[0]._cf_act_pair = (k0, k1, id(xs[1]), act)
 
 
 def layernorm(x, gamma, beta, eps=1e-5, pos=None):

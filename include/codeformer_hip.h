@@ -198,6 +198,12 @@ typedef struct cf_conv_desc {
    * kernels the bf16 mode runs from 64x64 pixels up: winograd == 1 with CF_OPERAND_BF16 (cout % 128 == 0), the direct CF_OPERAND_BF16
    * 3x3 (cout_pad 64) and folded upsample (cout_pad % 128 == 0) forms, fp32 1x1 on images (no split_k), the <= 4-channel NCHW head. */
   int32_t io_bf16;
+  /* ABI v22: a second token matrix for the output columns >= alt_cout0 (taps == 1 with CF_OPERAND_F16X2 on token matrices only; NULL: none).
+   * The q|k projections of nn.MultiheadAttention read LayerNorm(x) + pos and the v projection LayerNorm(x) (codeformer_arch.py:124-126):
+   * with in0 = LN(x) + pos, in0_alt = LN(x), alt_cout0 = 2 E and the whole in_proj weight (3 E rows) they are ONE launch instead of two.
+   * in0_alt has in0's shape; alt_cout0 is a multiple of 128.  Per output element the arithmetic is that of the separate launches. */
+  const float* in0_alt;
+  int32_t alt_cout0;
 } cf_conv_desc;
 
 int cf_conv2d(const cf_conv_desc* d, cf_stream_t stream);
@@ -297,6 +303,14 @@ int cf_act_scale_fused(const double* partial_a, int nper_a, const double* partia
 int cf_groupnorm_finalize(const double* partial, int batch, int parts, int c, int cpg, int gmerge, int64_t count,
                           const float* gamma, const float* beta, float eps, float* scale, float* shift, int ld,
                           cf_stream_t stream);
+/* ABI v22: the same for up to TWO tensors in one launch -- the halves [enc, dec] of a concatenated GroupNorm input (codeformer_arch.py:152;
+ * partial_b NULL: one tensor) -- whose tables land side by side (tensor b's channels start at c_a; gamma / beta / scale / shift address the
+ * concatenated channel axis, ld >= c_a + c_b), bitwise the tables of two cf_groupnorm_finalize launches.  With `act` set ([batch][2], and
+ * `cells` as for cf_act_scale_fused) the launch also writes the range-scale table of the same tensor(s) -- bitwise cf_act_scale_fused's on the
+ * same partials: the ResBlock input that feeds both norm1 and the 1x1 skip convolution (vqgan_arch.py:153-164) needs one launch, not three. */
+int cf_groupnorm_finalize2(const double* partial_a, int parts_a, int c_a, int cpg_a, int gmerge_a, const double* partial_b, int parts_b, int c_b,
+                           int cpg_b, int gmerge_b, int batch, int64_t count, const float* gamma, const float* beta, float eps, float* scale,
+                           float* shift, int ld, float act_growth, uint32_t* cells, float* act, cf_stream_t stream);
 
 /* ---- LayerNorm over the last dim (codeformer_arch.py:108-109,124,131,191; eps 1e-5) ----------
  * y = LN(x)*gamma+beta ; optional ypos = y + pos[row % npos]   (with_pos_embed, codeformer_arch.py:113-116) */

@@ -189,6 +189,82 @@ def test_fp32_token_tile_gemm_is_bitwise_the_splitk_gemm(sc):
         assert float((y1.double().view(-1, N) - ref).abs().max()) <= 2e-5 + 1e-5 * float(ref.abs().max())
 
 
+def test_two_token_matrices_in_one_split_half_gemm(sc):
+    """cf_conv_desc.in0_alt (round 6): the columns >= alt_from of a split-half token GEMM contract a second token matrix -- q | k on LN(x) + pos
+    and v on LN(x) as ONE launch.  Bitwise the two single-matrix launches with the same packed weight, in every kernel the host may pick
+    (in-workgroup split: few tokens; token tiles: many; cross-workgroup split), and refused where it does not belong."""
+    import pytest
+    import torch
+    from codeformer_amd import ops
+    g = torch.Generator().manual_seed(21)
+    E = 512
+    w = (torch.randn(3 * E, E, generator=g) / E ** 0.5).cuda()
+    b = torch.randn(3 * E, generator=g).cuda()
+    pw = ops.pack_weight(w, b, bf16=ops.GSPLIT)
+    for B, sk in ((1, None), (16, None), (2, 2), (8, None)):
+        xa = torch.randn(B * 256, E, generator=g).cuda()
+        xb = torch.randn(B * 256, E, generator=g).cuda()
+        v4 = lambda t: t.view(B, 16, 16, E)
+        both = ops.conv2d(v4(xa), pw, x_alt=v4(xb), alt_from=2 * E, split_k=sk).view(B * 256, 3 * E)
+        ya = ops.conv2d(v4(xa), pw, split_k=sk).view(B * 256, 3 * E)
+        yb = ops.conv2d(v4(xb), pw, split_k=sk).view(B * 256, 3 * E)
+        assert torch.equal(both[:, :2 * E], ya[:, :2 * E]) and torch.equal(both[:, 2 * E:], yb[:, 2 * E:]), (B, sk)
+        ref = torch.cat([xa.double() @ w[:2 * E].double().t(), xb.double() @ w[2 * E:].double().t()], dim=1) + b.double()
+        assert float((both.double() - ref).abs().max()) <= 2e-5 + 1e-5 * float(ref.abs().max())
+    with pytest.raises((RuntimeError, ValueError)):
+        ops.conv2d(xa.view(8, 16, 16, E), ops.pack_weight(w, b), x_alt=xb.view(8, 16, 16, E), alt_from=2 * E)      # fp32 operands: no such form
+    with pytest.raises(RuntimeError):
+        ops.conv2d(xa.view(8, 16, 16, E), pw, x_alt=xb.view(8, 16, 16, E), alt_from=100)                            # not a multiple of 128
+
+
+def test_fused_finalize_is_bitwise_the_separate_launches(sc):
+    """cf_groupnorm_finalize2 (round 6): GroupNorm tables of one tensor or of a concatenated pair, and the range-scale table of the same
+    tensor(s), in one launch -- bitwise the tables of cf_groupnorm_finalize per tensor + cf_act_scale_fused (ops.FINALIZE_FUSED = False)."""
+    import torch
+    from codeformer_amd import ops
+    g = torch.Generator().manual_seed(31)
+    B = 3
+
+    def producer(cin, cout, H, scale):
+        x = (torch.randn(B, H, H, cin, generator=g) * scale).cuda()
+        w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).cuda()
+        return ops.conv2d(x, ops.pack_weight(w, torch.randn(cout, generator=g).cuda(), bf16=ops.WINOGRAD), emit_stats=True)
+
+    for (ca, cb, H, sa, sb) in ((128, 0, 32, 1.0, 0.0), (256, 256, 32, 3.0, 1e-3), (128, 128, 64, 1e4, 2.0), (64, 0, 64, 1e-6, 0.0)):
+        ya = producer(64, ca, H, sa)
+        yb = producer(64, cb, H, sb) if cb else None
+        xs = [ya] if yb is None else [ya, yb]
+        gamma = (torch.rand(ca + cb, generator=g) + 0.5).cuda()
+        beta = torch.randn(ca + cb, generator=g).cuda()
+        old = ops.FINALIZE_FUSED
+        try:
+            ops.FINALIZE_FUSED = False
+            for t in xs:
+                t.__dict__.pop('_cf_act', None)
+                t.__dict__.pop('_cf_act_pair', None)
+            sc0, sh0 = ops.groupnorm_tables(xs, gamma, beta, act_growth=4.0)
+            act0 = ops.act_scale(ya, yb)
+            for t in xs:
+                t.__dict__.pop('_cf_act', None)
+            ops.FINALIZE_FUSED = True
+            sc1, sh1 = ops.groupnorm_tables(xs, gamma, beta, act_growth=4.0)
+            parked = getattr(ya, '_cf_act_pair' if yb is not None else '_cf_act', None)
+            assert parked is not None                            # the table came with the finalize launch ...
+            act1 = ops.act_scale(ya, yb)
+            assert act1 is parked[-1]                              # ... and act_scale found it instead of launching
+            sc2, sh2 = ops.groupnorm_tables(xs, gamma, beta)      # tables only
+        finally:
+            ops.FINALIZE_FUSED = old
+        assert torch.equal(sc0, sc1) and torch.equal(sh0, sh1) and torch.equal(sc0, sc2) and torch.equal(sh0, sh2), (ca, cb, H)
+        assert torch.equal(act0, act1), (act0, act1)
+        # and they are the right statistics
+        full = torch.cat([t.double() for t in xs], dim=3).view(B, H * H, 32, (ca + cb) // 32)
+        mean, var = full.mean((1, 3)), full.var((1, 3), unbiased=False)
+        rstd = 1.0 / torch.sqrt(var + 1e-6)
+        want = (rstd[:, :, None] * gamma.double().view(32, -1)[None]).view(B, -1)
+        assert float(((sc1.double() - want).abs() / want.abs().clamp_min(1e-12)).max()) < 1e-5
+
+
 def test_splitk_winograd_bits_do_not_depend_on_the_split_count(sc):
     """The Winograd kernel on images of at most 32x32 pixels: virtual chunks of 128 channels are taken to the output domain and added
     in a fixed order -- 1, 2 or 4 workgroups per patch give the same bits; errors vs fp64 as the unsplit kernel's."""

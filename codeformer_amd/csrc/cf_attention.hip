@@ -12,9 +12,6 @@
 // k-major in LDS as the B operand; output columns are processed 128 at a time (32 per wave).
 #include "cf_common.h"
 
-#ifndef CF_ATTN64_GENERIC
-#define CF_ATTN64_GENERIC 0  // 1: timing builds with the generic kernel for head_dim 64
-#endif
 
 namespace {
 
@@ -22,108 +19,9 @@ constexpr int NKEY = 256;
 constexpr int BQ = 32;
 constexpr int PS = NKEY + 4;  // padded row stride of the score tile
 
-template <int DH>
-__global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ K,
-                                                   int ldk, const float* __restrict__ V, int ldv, float* __restrict__ O,
-                                                   int ldo, float scale) {
-  constexpr int BNV = (DH >= 128) ? 128 : DH;  // output columns per phase-3 pass
-  constexpr int VWAVES = BNV / 32;             // waves with work in phase 3
-  __shared__ __attribute__((aligned(16))) float Ps[BQ * PS];
-  __shared__ __attribute__((aligned(16))) float stage[(BQ + NKEY) * CF_LDK];  // Q|K slabs, later the V slab
-  float* const Qs = stage;
-  float* const Ks = stage + BQ * CF_LDK;
-  float* const Vs = stage;  // [16][BNV]
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int half = lane >> 5, l31 = lane & 31;
-  const int q0 = blockIdx.x * BQ;
-  const int h = blockIdx.y;
-  const int b = blockIdx.z;
-  const size_t rowbase = (size_t)b * NKEY;
-  const int colbase = h * DH;
-
-  // ---------------- phase 1: S[32][256] = Q K^T ; wave w owns keys [64w, 64w+64) ----------------
-  f32x16 acc[1][2];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[0][0][r] = acc[0][1][r] = 0.f;
-  for (int c0 = 0; c0 < DH; c0 += CF_BK) {
-    if (tid < BQ * 4) {
-      const int row = tid >> 2, k4 = tid & 3;
-      *reinterpret_cast<f32x4*>(Qs + row * CF_LDK + k4 * 4) =
-          *reinterpret_cast<const f32x4*>(Q + (rowbase + q0 + row) * ldq + colbase + c0 + k4 * 4);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int f = tid + 256 * j;
-      const int row = f >> 2, k4 = f & 3;
-      *reinterpret_cast<f32x4*>(Ks + row * CF_LDK + k4 * 4) =
-          *reinterpret_cast<const f32x4*>(K + (rowbase + row) * ldk + colbase + c0 + k4 * 4);
-    }
-    __syncthreads();
-    const float* ap[1] = {Qs + l31 * CF_LDK + half * 4};
-    const float* bp[2] = {Ks + (wave * 64 + l31) * CF_LDK + half * 4, Ks + (wave * 64 + 32 + l31) * CF_LDK + half * 4};
-    cf_mma_slab<1, 2>(acc, ap, bp);
-    __syncthreads();
-  }
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) Ps[cf_acc_row(r, lane) * PS + wave * 64 + ni * 32 + l31] = acc[0][ni][r] * scale;
-  __syncthreads();
-
-  // ---------------- phase 2: row softmax (F.softmax over keys), 8 rows per wave ----------------
-#pragma unroll
-  for (int i = 0; i < BQ / 4; ++i) {
-    float* pr = Ps + (wave * (BQ / 4) + i) * PS + lane * 4;
-    f32x4 v = *reinterpret_cast<f32x4*>(pr);
-    const float m = cf_wave_max(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = expf(v[e] - m);
-    const float s = cf_wave_sum((v[0] + v[1]) + (v[2] + v[3]));
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = v[e] / s;
-    *reinterpret_cast<f32x4*>(pr) = v;
-  }
-  __syncthreads();
-
-  // ---------------- phase 3: O[32][DH] = P V, BNV columns per pass, wave w owns 32 of them -------
-  for (int col0 = 0; col0 < DH; col0 += BNV) {
-    f32x16 o;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] = 0.f;
-    for (int key0 = 0; key0 < NKEY; key0 += CF_BK) {
-      constexpr int NF4 = CF_BK * BNV / 4;  // float4 items in the V slab
-#pragma unroll
-      for (int j = 0; j < (NF4 + 255) / 256; ++j) {
-        const int f = tid + 256 * j;
-        if (f < NF4) {
-          const int key = f / (BNV / 4), c4 = f % (BNV / 4);
-          *reinterpret_cast<f32x4*>(Vs + key * BNV + c4 * 4) =
-              *reinterpret_cast<const f32x4*>(V + (rowbase + key0 + key) * ldv + colbase + col0 + c4 * 4);
-        }
-      }
-      __syncthreads();
-      if (wave < VWAVES) {
-#pragma unroll
-        for (int kg = 0; kg < CF_BK / 8; ++kg) {
-          // same k permutation as cf_mma_slab: lane half hh contracts keys kg*8 + hh*4 + j in MFMA step j
-          const f32x4 af = *reinterpret_cast<const f32x4*>(Ps + l31 * PS + key0 + kg * 8 + half * 4);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float bv = Vs[(kg * 8 + half * 4 + j) * BNV + wave * 32 + l31];
-            o = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], bv, o, 0, 0, 0);
-          }
-        }
-      }
-      __syncthreads();
-    }
-    if (wave < VWAVES) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        O[(rowbase + q0 + cf_acc_row(r, lane)) * ldo + colbase + col0 + wave * 32 + l31] = o[r];
-    }
-  }
-}
+// (The generic kernel of round 1 -- any head_dim, both operands through LDS slabs as described above -- served head_dim 64 until round 3 and
+//  stayed as a timing fallback; it left the product in round 6: tools/experiments/ablation_and_timing_macros.patch.  The two kernels below
+//  keep its phases and its arithmetic.)
 
 // ---- head_dim 64 (the Transformer's nn.MultiheadAttention core) -------------------------------------------------------------------
 // The generic kernel walks 4 + 16 barrier-separated slabs, each opening with a fetch it waits for, and half its waves idle in phase 3:
@@ -369,10 +267,7 @@ extern "C" int cf_attention(const float* q, int ldq, const float* k, int ldk, co
   const dim3 grid(NKEY / BQ, heads, batch), block(256);
   if (head_dim == 64) {
     CF_LDS_ATTR(attn64_kernel, A6_LDS_BYTES);  // (cf_device_init sets the dynamic-LDS attribute on each device)
-    if (CF_ATTN64_GENERIC)
-      hipLaunchKernelGGL(attn_kernel<64>, grid, block, 0, (hipStream_t)stream, q, ldq, k, ldk, v, ldv, out, ldo, scale);
-    else
-      hipLaunchKernelGGL(attn64_kernel, grid, block, A6_LDS_BYTES, (hipStream_t)stream, q, ldq, k, ldk, v, ldv, out, ldo, scale);
+    hipLaunchKernelGGL(attn64_kernel, grid, block, A6_LDS_BYTES, (hipStream_t)stream, q, ldq, k, ldk, v, ldv, out, ldo, scale);
   } else if (head_dim == 512) {
     CF_LDS_ATTR(attn512_kernel, A5_LDS_BYTES);
     hipLaunchKernelGGL(attn512_kernel, dim3(NKEY / BQ, heads * 2, batch), dim3(A5_THREADS), A5_LDS_BYTES, (hipStream_t)stream, q, ldq,

@@ -48,10 +48,6 @@
 
 // SP_ABLATE: timing-only ablation builds (tools/split_ab.sh), a bit mask: 1 no epilogue, 2 no weight fetch, 4 no weight LDS write,
 // 8 no fragment reads, 16 no per-step barrier, 32 no MFMA, 64 no activation gather, 128 no prologue/split; 0 in every product build.
-// SP_DESYNC: start skew of the first generation of workgroups, in sixteenths of (SP_DESYNC x main-loop steps x ~210 cycles); 0 = none
-#ifndef SP_DESYNC
-#define SP_DESYNC 0
-#endif
 #ifndef SP_FAST_RCP
 #define SP_FAST_RCP 1   // 1: swish reciprocal on the raw v_rcp_f32 (1 ulp) instead of the IEEE-rounded division sequence: +4..8 %
 #endif
@@ -399,16 +395,6 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? (NI == 1 && TAPS != 1 && !(S2 &
   // barrier, patch write, barrier -- but the next slab's activations were fetched at tap 0 and converted (prologue + split) in
   // the shadow of the MFMAs of a middle tap, so only the LDS stores sit between the two barriers.
   const int nsteps = a.nchunks * TAPS;
-#if SP_DESYNC
-  // Workgroups of one launch all take the same time, so the two co-resident on a CU -- and all 512 on the chip -- would run in
-  // lock-step: everybody in the MFMA loop (HBM idle), then everybody in the store phase (HBM-bound, matrix pipe idle).  A start
-  // skew of the FIRST generation (dispatch ids < 2 x 256 CUs; later ones inherit the phase of the slot they take over) spreads
-  // the phases over the tile time.
-  if (blockIdx.x < 512 && gridDim.x >= 1024) {
-    const int units = (blockIdx.x >> 3) & 15;
-    for (int i = 0; i < units * nsteps * SP_DESYNC / 64; ++i) __builtin_amdgcn_s_sleep(13);  // 13 x 64 cycles per iteration
-  }
-#endif
   [[maybe_unused]] ASet rn;  // 1x1: the second activation set (slabs alternate between ra and rn, two slabs in flight)
   load_A(ra, 0);
   load_B(0);

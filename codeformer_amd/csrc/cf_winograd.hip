@@ -41,13 +41,6 @@
 
 #include "cf_common.h"
 
-#ifndef CF_W64_EXPERIMENT
-#define CF_W64_EXPERIMENT 0
-#endif
-// CF_WABLATE: timing-only ablation builds (tools/ab_variants.sh); 0 / undefined in every product build.
-#ifndef CF_WABLATE
-#define CF_WABLATE 0
-#endif
 namespace {
 
 constexpr int WG_TH = 8, WG_TW = 16;                      // output patch of a workgroup
@@ -377,31 +370,23 @@ __global__ __launch_bounds__(256, 2) void winograd_kernel(const std::conditional
     load_B(chunk, 0);
     load_B(chunk, 1);
     __builtin_amdgcn_sched_barrier(0);  // keep the fetches up here (hipcc would sink them next to their first use)
-#if CF_WABLATE != 2 && CF_WABLATE != 7
     store_patch(ra, chunk);
-#endif
     __syncthreads();
     // slot 1: next slab's activations are requested (a whole slab of cover), then the transform
     load_A(c + 1 < n ? chunk + 1 : chunk, ra);  // unconditional (clamped): a load under a branch makes hipcc drain vmcnt
     __builtin_amdgcn_sched_barrier(0);
-#if CF_WABLATE != 1 && CF_WABLATE != 7
     transform();
-#endif
     __builtin_amdgcn_sched_barrier(0);
     load_B(chunk, 2);  // the transform's registers are free again; consumed two barriers later
     load_B(chunk, 3);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     // slot 2
-#if CF_WABLATE != 3
     mma(0);
     mma(1);
-#endif
     // slot 3
-#if CF_WABLATE != 3
     mma(2);
     mma(3);
-#endif
     // (the barrier after the next gather-store separates these reads of V from its rewrite)
     if constexpr (SK) {
       if ((c + 1) % CF_SK_SLABS == 0) {  // a virtual chunk is complete: fold its output-domain sum (one workgroup) or park it (split)
@@ -651,10 +636,6 @@ extern "C" int cf_pack_conv_weight_winograd(const float* w, int cout, int cin, i
 
 bool cf_wsplit_covers(const cf_conv_desc* d);                                        // cf_wsplit.hip: the eight-wave,
 int cf_wsplit_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query);  // 128-channel split-half form
-#if CF_W64_EXPERIMENT  // tools/experiments/cf_w64.hip (persistent, DMA-fed 64-output-channel form; measured, not shipped)
-bool cf_w64_covers(const cf_conv_desc* d);
-int cf_w64_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query);
-#endif
 
 // Called by cf_conv2d (cf_igemm.hip) for descriptors with winograd != 0; the common argument checks have run there.
 int cf_winograd_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query) {
@@ -676,9 +657,6 @@ int cf_winograd_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_que
                  (d->ld_out == 0 || d->ld_out == d->cout),
              "cf_conv2d: winograd reads / writes dense tensors with zero padding");
   if (h2 && cf_wsplit_covers(d)) return cf_wsplit_launch(d, stream, parts_query);
-#if CF_W64_EXPERIMENT
-  if (h2 && !h1 && cf_w64_covers(d)) return cf_w64_launch(d, stream, parts_query);
-#endif
   CF_REQUIRE(!h1, "cf_conv2d(winograd, single 16-bit operands): not covered");
   WinoArgs a;
   a.in0 = d->in0;

@@ -18,8 +18,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'codeformer_amd', 'csrc')
 MACROS = {'F4_ABLATE': 0, 'F4_TIMING': 0, 'WS_ABLATE': 0, 'SP_ABLATE': 0, 'CF_ABLATE': 0, 'FC_ABLATE': 0, 'F4_K32_PAIR': 0, 'F4_OVL_PRIO': 0,
-          'F4_RES_AUX': 0, 'WS_STORE_FIRST': 1, 'GS_CHUNK_PIN': 1}
-FILES = ['cf_wf43.hip', 'cf_wsplit.hip', 'cf_split.hip', 'cf_igemm.hip', 'cf_gemm_split.hip']
+          'F4_RES_AUX': 0, 'WS_STORE_FIRST': 1, 'GS_CHUNK_PIN': 1,
+          # second pass (same round): the remaining timing / experiment hooks
+          'CF_WABLATE': 0, 'CF_W64_EXPERIMENT': 0, 'SP_DESYNC': 0, 'CF_ATTN64_GENERIC': 0}
+FILES = ['cf_wf43.hip', 'cf_wsplit.hip', 'cf_split.hip', 'cf_igemm.hip', 'cf_gemm_split.hip', 'cf_winograd.hip', 'cf_attention.hip']
 TOK = re.compile(r'[A-Za-z_][A-Za-z_0-9]*')
 
 

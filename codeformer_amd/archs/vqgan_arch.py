@@ -134,6 +134,12 @@ class Upsample(HipModule):
     def forward_nhwc(self, x, bf16=False):
         if int(bf16) == 2:
             bf16 = ops.SPLIT   # the input is the un-normalised residual stream: single IEEE halves have no range scaling on the direct kernel
+        c = self.conv.in_channels
+        if int(bf16) == ops.WINOGRAD_F43 and x.dtype == torch.float32 and ops.f43_up_ok(c, self.conv.out_channels, 2 * x.shape[1], 2 * x.shape[2]):
+            # precision 'fp32': Winograd F(4x4,3x3) on the virtually upsampled image (the gather reads source pixel (y >> 1, x >> 1)):
+            # 2.25 fp32 products per output instead of the 4 of the folded sub-pixel form
+            pw = self._packed(('conv', 'f43up'), lambda: ops.pack_weight(self.conv.weight, self.conv.bias, bf16=ops.WF43F), self.conv.weight, self.conv.bias)
+            return ops.conv2d(x, pw, upsample=True, emit_stats=True)
         pw = self._pw_conv('conv', bf16, up2x=True, hw=x.shape[1:3])
         return ops.conv2d(x, pw, upsample=True, emit_stats=True, act=ops.act_scale(x) if ops.needs_act_scale(pw) else None)
 

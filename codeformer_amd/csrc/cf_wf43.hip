@@ -153,8 +153,13 @@ __device__ __forceinline__ unsigned f4_vu(unsigned lq, unsigned p, unsigned t) {
 // weight stream of slab s: bitwise the two-interval <., ., 16, 16> form, 4-13 % fewer cycles per patch and the same launch time at the
 // power cap, split-half operands in round 5 and fp32 operands in round 6 (profiles/r05_f43_ovl_stage_timing.txt, r06_f43_fp32_stage_timing.txt).
 // It is not part of the library; commit beb776c holds its source.)
-template <int PRO, int EPI, int NW, int KS, bool F32>
+// UP (round 6; fp32 operands, no prologue / epilogue operand: the Upsample blocks of precision 'fp32', vqgan_arch.py:129-138): the convolution reads
+// the NEAREST-x2 UPSAMPLED image without it ever existing -- halo pixel (iy, ix) of the (h x w) grid is source pixel (iy >> 1, ix >> 1) of the
+// (h/2 x w/2) tensor; zero padding, patch layout, transforms and everything behind the gather are those of the plain form.  2.25 products per
+// output and input channel instead of the 4 of the folded sub-pixel form (cf_igemm.hip TAPS = 4), which the fp32 pipe executes one by one.
+template <int PRO, int EPI, int NW, int KS, bool F32, bool UP = false>
 __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
+  static_assert(!UP || (F32 && PRO == CF_PRO_NONE && EPI == CF_EPI_NONE), "the upsampling gather: fp32 operands, no prologue, no epilogue operand");
   static_assert(KS == 16 || (KS == 32 && NW == 16), "32-channel slabs need the LDS of the 16-wave form");
   constexpr int F4_THREADS = NW * 64;
   constexpr int F4_BN = NW * 8;                  // output channels per workgroup
@@ -218,13 +223,20 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
     const unsigned hx = p - 18u * hy;
     const int iy = y0 - 1 + (int)hy, ix = x0 - 1 + (int)hx;
     valid = (int)(p < (unsigned)F4_NPIX) & (int)((unsigned)iy < (unsigned)a.h) & (int)((unsigned)ix < (unsigned)a.w);  // (no short circuit: no branches)
-    rel = valid ? hy * (unsigned)a.w + hx : (unsigned)(9 * a.w + 9);
+    if constexpr (UP) {   // `rel` = the SOURCE pixel's index in its (h/2 x w/2) image (the patch's centre pixel for padding items)
+      const unsigned sy = valid ? (unsigned)iy : (unsigned)(y0 + 8), sx = valid ? (unsigned)ix : (unsigned)(x0 + 8);
+      rel = (sy >> 1) * ((unsigned)a.w >> 1) + (sx >> 1);
+    } else {
+      rel = valid ? hy * (unsigned)a.w + hx : (unsigned)(9 * a.w + 9);
+    }
   };
   const size_t img0 = (size_t)b * a.h * a.w;
   const unsigned img_px = (unsigned)(a.h * a.w);
+  const size_t img0_in = UP ? img0 / 4 : img0;          // (the source of the upsampling form has a quarter of the pixels)
+  const unsigned img_px_in = UP ? img_px / 4 : img_px;
   // one descriptor per concatenated input, based at this image (the launch checks that an image stays below 2^31 bytes)
-  const __amdgpu_buffer_rsrc_t rs_in0 = f4_rsrc(a.in0 + img0 * a.c0, img_px * (unsigned)a.c0 * 4u);
-  const __amdgpu_buffer_rsrc_t rs_in1 = f4_rsrc(a.c1 ? a.in1 + img0 * a.c1 : a.in0, img_px * (unsigned)a.c1 * 4u);
+  const __amdgpu_buffer_rsrc_t rs_in0 = f4_rsrc(a.in0 + img0_in * a.c0, img_px_in * (unsigned)a.c0 * 4u);
+  const __amdgpu_buffer_rsrc_t rs_in1 = f4_rsrc(a.c1 ? a.in1 + img0_in * a.c1 : a.in0, img_px_in * (unsigned)a.c1 * 4u);
   constexpr bool HALVES = F4_APT >= 6;                   // six items per gather thread: a slab's items are requested and stored in two halves
   constexpr int RAN = HALVES ? F4_APT / 2 : F4_APT;     // gather registers that cross the M interval
   f32x4 ra[RAN], rb[HALVES ? RAN : 1];                   // (rb: the second half, live inside the T interval only)
@@ -244,7 +256,7 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
       unsigned rel;
       bool valid;
       item(tl / (unsigned)QPP, j, rel, valid);
-      const unsigned voff = (__umul24((unsigned)(pix_origin + (int)rel), cs) + k4x) * 4u;
+      const unsigned voff = (__umul24(UP ? rel : (unsigned)(pix_origin + (int)rel), cs) + k4x) * 4u;
       (HALVES && j >= RAN ? rb[j % RAN] : ra[j % RAN]) = first ? f4_ld128(rs_in0, voff, soff) : f4_ld128(rs_in1, voff, soff);
     }
   };
@@ -970,10 +982,15 @@ extern "C" int cf_pack_conv_weight_winograd43(const float* w, int cout, int cin,
 
 // Called by cf_conv2d (cf_igemm.hip) for descriptors with winograd == 2; the common argument checks have run there.
 int cf_wf43_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query) {
-  CF_REQUIRE(d->taps == 9 && d->stride == 1 && !d->upsample && !d->in_nchw && !d->out_nchw &&
+  CF_REQUIRE(d->taps == 9 && d->stride == 1 && !d->in_nchw && !d->out_nchw &&
                  (d->bf16_mfma == CF_OPERAND_F16X2 || d->bf16_mfma == CF_OPERAND_F32),
              "cf_conv2d(winograd 2): F(4x4,3x3) covers 3x3 stride-1 NHWC convolutions with split-half or fp32 operands");
   const bool f32 = d->bf16_mfma == CF_OPERAND_F32;
+  // nearest-x2 + 3x3 (cf_conv_desc.upsample) with fp32 operands: the upsampling gather of the 16-wave form on 32-channel slabs (weights: the
+  // plain cf_pack_conv_weight_winograd43 packing of the 3x3 kernel, not the folded one)
+  CF_REQUIRE(!d->upsample || (f32 && d->prologue == CF_PRO_NONE && d->epilogue == CF_EPI_NONE && d->c1 == 0 && d->cout % 128 == 0 && d->c0 % 32 == 0 &&
+                              f4_k32_enabled()),
+             "cf_conv2d(winograd 2, upsample): fp32 operands, one input with c0 %% 32 == 0, cout %% 128 == 0, no prologue / epilogue operand");
   CF_REQUIRE(f32 || d->acc_scale > 0.f, "cf_conv2d(winograd 2): acc_scale must be the inverse of the pack-time weight scale (got %g)", (double)d->acc_scale);
   CF_REQUIRE(!f32 || !d->act_scale, "cf_conv2d(winograd 2): fp32 operands take no activation range scale");
   CF_REQUIRE(d->hout % F4_TH == 0 && d->wout % F4_TW == 0, "cf_conv2d(winograd 2): needs an output of %dx%d multiples (got %dx%d)", F4_TH,
@@ -1051,6 +1068,12 @@ int cf_wf43_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query) 
     else if (d->epilogue == CF_EPI_SFT) F4_LAUNCH(P, CF_EPI_SFT);                  \
     else F4_LAUNCH(P, CF_EPI_NONE);                                                \
   } while (0)
+  if (d->upsample) {
+    CF_LDS_ATTR((wf43_kernel<CF_PRO_NONE, CF_EPI_NONE, 16, 32, true, true>), F4_LDS_FLOATS_32 * sizeof(float));
+    hipLaunchKernelGGL((wf43_kernel<CF_PRO_NONE, CF_EPI_NONE, 16, 32, true, true>), grid, block, lds, stream, a);
+    CF_CHECK_LAUNCH("cf_conv2d(winograd F(4,3) fp32, upsampling gather)");
+    return CF_OK;
+  }
   switch (d->prologue) {
     case CF_PRO_AFFINE: F4_LAUNCH_EPI(CF_PRO_AFFINE); break;
     case CF_PRO_AFFINE_SWISH: F4_LAUNCH_EPI(CF_PRO_AFFINE_SWISH); break;

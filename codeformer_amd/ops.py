@@ -148,6 +148,19 @@ def f43_ok(cin, cout, hout, wout, fp32=False):
     return cin % 16 == 0 and cin <= 256 and cout % 64 == 0 and hout % 16 == 0 and wout % 16 == 0
 
 
+# precision 'fp32': the Upsample blocks (nearest x2 + 3x3) on the fp32 F(4x4,3x3) kernel with an UPSAMPLING gather (round 6) instead of the folded
+# sub-pixel form on the direct fp32 kernel, which executes every one of its 4 products per output (0.82 of the fp32 MFMA peak: nothing left
+# to schedule) -- F(4,3) needs 2.25.  CODEFORMER_HIP_F43_UPSAMPLE=0: the folded form everywhere (A/B).
+F43_UPSAMPLE = os.environ.get('CODEFORMER_HIP_F43_UPSAMPLE', '1') != '0'
+
+
+def f43_up_ok(cin, cout, hout, wout):
+    """Shapes the upsampling form of the fp32 F(4x4,3x3) kernel covers ((hout, wout) = the OUTPUT size): the 16-wave workgroup on
+    32-channel slabs, GroupNorm-table limit of 256 input channels, whole 16x16 output patches, from the size where the 16-wave form pays."""
+    return F43_UPSAMPLE and F43_LAYERS in ('auto', 'all') and cin % 32 == 0 and cin <= 256 and cout % 128 == 0 and hout % 16 == 0 and wout % 16 == 0 and \
+        hout * wout >= F43_WIDE_MIN_PIXELS_FP32
+
+
 # Smallest per-image input of the DIRECT split-half kernel and of the eight-wave Winograd kernel.  The 16x16 latents are below it: with
 # SPLIT they run the four-wave Winograd kernel on split halves with split-K (conv_code -> WSPLIT: measured on the reference's crops
 # before it became the default, profiles/r02_encoder_split_check.txt), with SPLIT_DIRECT they stay on the exact fp32 kernel.
@@ -211,7 +224,7 @@ HALF_LIMIT = 65504.0 / 4.0    # largest |activation| a Winograd-domain IEEE-half
 
 def switches():
     """The module-level A/B switches a captured forward depends on (part of the graph-replay key of the arch modules)."""
-    return (SPLIT_WINOGRAD, F43_LAYERS, F43_WIDE_MIN_PIXELS, F43_WIDE_MIN_PIXELS_FP32, WINOGRAD_16BIT, RANGE_SCALE, ACT_FUSED, SPLITK_MAX, GEMM_IN_WG_MAX_OUTPUTS, FINALIZE_FUSED)
+    return (SPLIT_WINOGRAD, F43_LAYERS, F43_UPSAMPLE, F43_WIDE_MIN_PIXELS, F43_WIDE_MIN_PIXELS_FP32, WINOGRAD_16BIT, RANGE_SCALE, ACT_FUSED, SPLITK_MAX, GEMM_IN_WG_MAX_OUTPUTS, FINALIZE_FUSED)
 
 
 def needs_act_scale(pw):
@@ -559,8 +572,9 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
         ld1 = _nhwc_ld(x2, 'x2')
     if c0 + c1 != pw.cin and not (c1 == 0 and c0 == pw.cin_pad):
         raise ValueError(f'input channels {c0}+{c1} != weight cin {pw.cin}')
-    if bool(upsample) != bool(pw.up2x):
-        raise ValueError('conv2d(upsample=True) needs a weight packed with up2x=True (and vice versa)')
+    f43_up = bool(upsample) and pw.wino == 2 and not pw.bf16     # fp32 F(4,3) with the upsampling gather: the PLAIN 3x3 packing (WF43F), not the folded one
+    if bool(upsample) != bool(pw.up2x) and not f43_up:
+        raise ValueError('conv2d(upsample=True) needs a weight packed with up2x=True, or the fp32 F(4,3) packing (and vice versa)')
     if pw.taps == 1 and int(pw.bf16) == OPERAND_F16X2 and bool(pw.conv1) != (H * W > TOKEN_IMAGE_MAX):
         raise ValueError(f'1x1 with f16x2 operands: images of more than {TOKEN_IMAGE_MAX} pixels take a weight packed with bf16=SPLIT, '
                          'token matrices one packed with bf16=GSPLIT')
@@ -637,7 +651,7 @@ def conv2d(x, pw, *, x2=None, stride=1, upsample=False, prologue=PRO_NONE, scale
     L.check(lib.cf_conv2d(ctypes.byref(d), L.stream_ptr()), 'cf_conv2d')
     e1.record()
     cin = c0 + c1
-    flops = 2.0 * B * Ho * Wo * pw.cout * cin * (4 if upsample else pw.taps)   # executed MACs (folded taps for up2x); Winograd
+    flops = 2.0 * B * Ho * Wo * pw.cout * cin * (4 if (upsample and not pw.wino) else pw.taps)   # executed MACs (folded taps for up2x); Winograd
     # launches are booked at the direct convolution's 9 taps (the algorithmic work), not at their 4 MFMA multiplies per output
     esz = x.element_size()
     nbytes = float(esz * (x.numel() + (0 if x2 is None else x2.numel()) + (0 if res is None else res.numel()) + (0 if sft_scale is None else sft_scale.numel()))

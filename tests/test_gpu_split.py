@@ -501,3 +501,38 @@ def test_winograd_f43_fp32_operands_against_fp64(sc):
         y = ops.conv2d(x, pw, emit_stats=True)
         y1 = ops.conv2d(x[1:2].contiguous(), pw, emit_stats=True)
         assert torch.equal(y[1:2], y1) and torch.equal(y._cf_stats.part.view(3, -1)[1:2], y1._cf_stats.part.view(1, -1))
+
+
+def test_winograd_f43_fp32_upsampling_gather(sc):
+    """Round 6: nearest x2 + 3x3 (Upsample, vqgan_arch.py:129-138) on the fp32 F(4x4,3x3) kernel whose gather reads source pixel (y >> 1, x >> 1):
+    against fp64 within the fp32-operand bound of the plain form (4e-5 * max(|ref| / 4, 1)), next to the folded sub-pixel kernel it replaces in
+    precision 'fp32'; GroupNorm partials of the output; batch invariance; refusals."""
+    import pytest
+    import torch
+    import torch.nn.functional as F
+    from codeformer_amd import ops
+    g = torch.Generator().manual_seed(17)
+    for (B, H, W, cin, cout) in ((2, 32, 32, 128, 128), (1, 64, 48, 256, 256), (3, 16, 32, 64, 128)):
+        x = torch.randn(B, H, W, cin, generator=g)
+        w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+        b = torch.randn(cout, generator=g) * 0.1
+        ref = F.conv2d(F.interpolate(x.double().permute(0, 3, 1, 2), scale_factor=2.0, mode='nearest'), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+        pw = ops.pack_weight(w.cuda(), b.cuda(), bf16=ops.WF43F)
+        y = ops.conv2d(x.cuda(), pw, upsample=True, emit_stats=True)
+        folded = ops.conv2d(x.cuda(), ops.pack_weight(w.cuda(), b.cuda(), up2x=True), upsample=True, emit_stats=True)
+        scale = float(ref.abs().max())
+        err, err_f = float((y.cpu().double() - ref).abs().max()), float((folded.cpu().double() - ref).abs().max())
+        print(f'F(4,3) upsampling gather {H}x{W} {cin}->{cout}: max err {err:.2e} (folded direct kernel {err_f:.2e}), |ref| max {scale:.2f}')
+        assert tuple(y.shape) == (B, 2 * H, 2 * W, cout) and err <= 4e-5 * max(scale / 4.0, 1.0)
+        st = y._cf_stats
+        got = st.part.view(B, 32, st.parts, 2).sum(2).cpu()
+        r = y.cpu().double().view(B, 4 * H * W, 32, st.cpg)
+        want = torch.stack([r.sum((1, 3)), (r * r).sum((1, 3))], -1)
+        room = torch.stack([r.abs().sum((1, 3)), (r * r).sum((1, 3))], -1)      # (a group's sum may cancel: measure against the sum of magnitudes)
+        assert float(((got - want).abs() / room).max()) < 1e-6
+        if B > 1:
+            assert torch.equal(ops.conv2d(x[1:2].contiguous().cuda(), pw, upsample=True), y[1:2])
+    assert ops.f43_up_ok(128, 128, 512, 512) and ops.f43_up_ok(256, 256, 64, 64) and not ops.f43_up_ok(512, 512, 32, 32) and not ops.f43_up_ok(128, 64, 512, 512)
+    xs = torch.randn(1, 32, 32, 128, device='cuda')
+    with pytest.raises((RuntimeError, ValueError)):      # split-half operands have no upsampling gather (their folded form is the faster one)
+        ops.conv2d(xs, ops.pack_weight(torch.randn(128, 128, 3, 3, device='cuda') * 0.03, None, bf16=ops.WF43), upsample=True, act=ops.act_scale(xs))

@@ -17,4 +17,6 @@ for prec in f16x2 bf16; do
   echo "== pmc, precision $prec"; bash tools/pmc_bench.sh $tag $prec > gpurun_out/pmc_bench_${tag}_$prec.log 2>&1; echo "rc=$?"; tail -3 gpurun_out/pmc_bench_${tag}_$prec.log | cut -c1-300
 done
 echo "== one-face timeline"; bash tools/b1_timeline.sh 1 $tag | head -12
-echo "== latency"; timeout 300 python tools/latency.py f16x2 2>&1 | grep -v amdgpu.ids | tee gpurun_out/latency_$tag.txt
+echo "== latency"; timeout 300 python tools/latency.py f16x2,fp32 2>&1 | grep -v amdgpu.ids | tee gpurun_out/latency_$tag.txt
+# the N > 1 launch path with one rank (torchrun, RCCL initialised, gather to rank 0): what the driver's scaling bench runs per rank
+echo "== torchrun, one rank"; HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-f16x2-leg --no-config3-leg 2>&1 | grep -v amdgpu.ids | tail -1 | cut -c1-300 | tee gpurun_out/torchrun_n1_$tag.txt

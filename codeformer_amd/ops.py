@@ -7,6 +7,7 @@ libcodeformer_hip.so.  Nothing here has a CPU/eager fallback.
 import ctypes
 import math
 import os
+import weakref
 
 import torch
 
@@ -273,7 +274,7 @@ def act_scale(x, x2=None, growth=4.0):
             return cached[1]
     if x2 is not None:      # a table groupnorm_tables([x, x2], act_growth=...) wrote in its own launch
         cached = getattr(x, '_cf_act_pair', None)
-        if cached is not None and cached[2] == id(x2) and cached[0] == _act_key(x, growth) and cached[1] == _act_key(x2, growth):
+        if cached is not None and cached[2]() is x2 and cached[0] == _act_key(x, growth) and cached[1] == _act_key(x2, growth):
             return cached[3]
     lib = L.load()
     B = x.shape[0]
@@ -768,7 +769,7 @@ def _park_act(xs, growth, act):
     else:
         k1 = _act_key(xs[1], growth)
         if k1 is not None:
-            xs[0]._cf_act_pair = (k0, k1, id(xs[1]), act)
+            xs[0]._cf_act_pair = (k0, k1, weakref.ref(xs[1]), act)    # (a weak reference, not an id: ids are recycled)
 
 
 def layernorm(x, gamma, beta, eps=1e-5, pos=None):

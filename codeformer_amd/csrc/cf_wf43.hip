@@ -84,13 +84,14 @@ constexpr int F4_PATCH_FLOATS = F4_SLOTS * CF_BK;   // 5248 floats = 20992 bytes
 constexpr int F4_PS = F4_NT * CF_BK;             // 256 floats between positions of V
 constexpr int F4_V_FLOATS = 36 * F4_PS;          // 9216
 constexpr int F4_M_FLOATS = 36 * 8 * 64;         // 18432: one pass of the epilogue of the 8-wave form (36 positions x 8 tiles x 64 channels)
-constexpr int F4_TAB = 256;                      // GroupNorm scale / shift rows of the image (cin <= 256)
+constexpr int F4_TAB = 256;                      // GroupNorm scale / shift rows of the image (cin <= 256) ...
+constexpr int F4_TAB_32 = 512;                   // ... cin <= 512 on 32-channel slabs (round 6: the 512 -> 256 fusion convolution at 64x64 in precision 'fp32'; its LDS has the room)
 constexpr int F4_LDS_FLOATS = 2 * F4_PATCH_FLOATS + F4_V_FLOATS + 2 * F4_TAB;   // 80,896 bytes: two workgroups per CU
 static_assert(F4_M_FLOATS <= 2 * F4_PATCH_FLOATS + F4_V_FLOATS, "epilogue staging must fit the patch buffers + V");
 static_assert(F4_LDS_FLOATS * 4 <= 81920, "LDS budget of two workgroups per CU");
 constexpr int F4_LDS_FLOATS_16 = 2 * F4_M_FLOATS;   // 16-wave form: its epilogue pass stages 36 x 8 tiles x 128 channels = 147,456 bytes (the slab loop needs the 80,896 above)
 static_assert(F4_LDS_FLOATS_16 >= F4_LDS_FLOATS && F4_LDS_FLOATS_16 * 4 <= 163840, "LDS budget of the 16-wave form");
-constexpr int F4_LDS_FLOATS_32 = 2 * F4_SLOTS * 32 + 36 * F4_NT * 32 + 2 * F4_TAB;   // 16 waves, 32-channel slabs: 159,744 bytes
+constexpr int F4_LDS_FLOATS_32 = 2 * F4_SLOTS * 32 + 36 * F4_NT * 32 + 2 * F4_TAB_32;   // 16 waves, 32-channel slabs: 161,792 bytes
 static_assert(F4_LDS_FLOATS_32 >= F4_LDS_FLOATS_16 && F4_LDS_FLOATS_32 * 4 <= 163840, "LDS budget of the 32-channel-slab form");
 
 typedef _Float16 f4_f16x4 __attribute__((ext_vector_type(4)));
@@ -174,7 +175,8 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const V = smem + 2 * PATCHF;
   constexpr int VBUF = 36 * PSK;                   // floats of V
-  float* const tab = V + VBUF;                     // [scale: F4_TAB][shift: F4_TAB]
+  constexpr int TABN = KS == 32 ? F4_TAB_32 : F4_TAB;
+  float* const tab = V + VBUF;                     // [scale: TABN][shift: TABN]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
   if (affine) {  // this image's GroupNorm rows -> LDS, read per slab by the patch store (first use is behind the first barrier)
     for (int i = tid; i < a.cin; i += F4_THREADS) {
       tab[i] = a.pro_scale[(size_t)b * a.cin + i];
-      tab[F4_TAB + i] = a.pro_shift[(size_t)b * a.cin + i];
+      tab[TABN + i] = a.pro_shift[(size_t)b * a.cin + i];
     }
   }
   float act_s = 1.f, act_is = 1.f;
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(NW * 64, 4) void wf43_kernel(const F4Args a) {
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (affine) {
       sc = *reinterpret_cast<const f32x4*>(tab + chunk * KS + k4 * 4);
-      sh = *reinterpret_cast<const f32x4*>(tab + F4_TAB + chunk * KS + k4 * 4);
+      sh = *reinterpret_cast<const f32x4*>(tab + TABN + chunk * KS + k4 * 4);
     }
 #pragma unroll
     for (int j = J0; j < J1; ++j) {
@@ -1000,7 +1002,8 @@ int cf_wf43_launch(const cf_conv_desc* d, hipStream_t stream, int* parts_query) 
   CF_REQUIRE((long)d->hout * d->wout <= (1L << 21), "cf_conv2d(winograd 2): at most 2^21 pixels per image (got %dx%d)", d->hout, d->wout);
   CF_REQUIRE((long)d->hout * d->wout * (d->c0 > d->cout ? d->c0 : d->cout) * 4 < (1L << 31) && (long)d->hout * d->wout * d->c1 * 4 < (1L << 31),
              "cf_conv2d(winograd 2): an image of a tensor must stay below 2^31 bytes (%dx%d, %d / %d / %d channels)", d->hout, d->wout, d->c0, d->c1, d->cout);
-  CF_REQUIRE(d->c0 + d->c1 <= F4_TAB, "cf_conv2d(winograd 2): at most %d input channels (got %d)", F4_TAB, d->c0 + d->c1);
+  const int tab_max = (d->cout % 128 == 0 && (d->c0 + d->c1) % 32 == 0 && f4_k32_enabled()) ? F4_TAB_32 : F4_TAB;   // (the 32-channel-slab form holds 512 GroupNorm rows)
+  CF_REQUIRE(d->c0 + d->c1 <= tab_max, "cf_conv2d(winograd 2): at most %d input channels in this form (got %d)", tab_max, d->c0 + d->c1);
   CF_REQUIRE(d->epilogue == CF_EPI_NONE || d->epilogue == CF_EPI_RESIDUAL || d->epilogue == CF_EPI_SFT,
              "cf_conv2d(winograd 2): epilogues are none / residual / SFT");
   CF_REQUIRE(d->pad_mode == CF_PAD_ZERO && (d->ld_in0 == 0 || d->ld_in0 == d->c0) && (d->ld_in1 == 0 || d->ld_in1 == d->c1) &&

@@ -141,12 +141,14 @@ F43_WIDE_MIN_PIXELS_FP32 = int(os.environ.get('CODEFORMER_HIP_F43_MINPIX_FP32', 
 
 def f43_ok(cin, cout, hout, wout, fp32=False):
     """Shapes the F(4x4,3x3) kernel covers (3x3 stride-1 dense NHWC): whole 16x16 output patches, 64-wide channel tiles, at most 256
-    input channels (the GroupNorm rows of an image sit in LDS) -- narrowed by F43_LAYERS to where it pays (fp32: the operand type)."""
+    input channels (512 in the 16-wave form on 32-channel slabs: the GroupNorm rows of an image sit in LDS) -- narrowed by F43_LAYERS to
+    where it pays (fp32: the operand type)."""
     if F43_LAYERS == '0' or (F43_LAYERS == 'c64' and cout != 64):
         return False
     if F43_LAYERS == 'auto' and cout != 64 and (cout % 128 or hout * wout < (F43_WIDE_MIN_PIXELS_FP32 if fp32 else F43_WIDE_MIN_PIXELS)):
         return False
-    return cin % 16 == 0 and cin <= 256 and cout % 64 == 0 and hout % 16 == 0 and wout % 16 == 0
+    cin_max = 512 if (cout % 128 == 0 and cin % 32 == 0) else 256     # GroupNorm rows in LDS: 512 in the 16-wave form on 32-channel slabs (round 6), else 256
+    return cin % 16 == 0 and cin <= cin_max and cout % 64 == 0 and hout % 16 == 0 and wout % 16 == 0
 
 
 # precision 'fp32': the Upsample blocks (nearest x2 + 3x3) on the fp32 F(4x4,3x3) kernel with an UPSAMPLING gather (round 6) instead of the folded

@@ -134,13 +134,13 @@ def test_winograd_eligibility_rule():
 
 def test_f43_eligibility_rule(monkeypatch):
     """Which generator / fusion layers a SPLIT_F43 request puts on the F(4x4,3x3) kernel (ops.f43_ok): a pure function of the layer
-    shape -- whole 16x16 patches, cin % 16 == 0 and <= 256, cout % 64 == 0 -- narrowed by CODEFORMER_HIP_F43 ('auto': 64 output channels,
+    shape -- whole 16x16 patches, cin % 16 == 0 and <= 256 (<= 512 in the 16-wave form on 32-channel slabs, round 6), cout % 64 == 0 -- narrowed by CODEFORMER_HIP_F43 ('auto': 64 output channels,
     or a multiple of 128 from 128x128 pixels up (fp32 operands: 64x64); 'c64'; 'all'; '0'); conv_code falls back to the F(2x2,3x3) split-half kernel elsewhere
     and never returns WF43 for a plain SPLIT request (the encoder)."""
     from codeformer_amd import ops
     monkeypatch.setattr(ops, 'F43_LAYERS', 'auto')
     for cin, cout, h, want in ((64, 64, 512, True), (128, 64, 512, True), (128, 128, 256, True), (256, 128, 256, True), (128, 128, 128, True),
-                               (256, 256, 128, True), (256, 256, 32, False), (512, 256, 128, False), (64, 128, 24, False), (128, 192, 256, False),
+                               (256, 256, 128, True), (256, 256, 32, False), (512, 256, 128, True), (512, 64, 128, False), (768, 256, 128, False), (64, 128, 24, False), (128, 192, 256, False),
                                (48, 64, 32, True), (40, 64, 32, False)):
         assert ops.f43_ok(cin, cout, h, h) == want, (cin, cout, h)
         assert (ops.conv_code(ops.SPLIT_F43, cin, cout, h, h) == ops.WF43) == want
@@ -159,7 +159,7 @@ def test_f43_eligibility_rule(monkeypatch):
     monkeypatch.setattr(ops, 'F43_LAYERS', 'c64')
     assert ops.f43_ok(64, 64, 512, 512) and not ops.f43_ok(128, 128, 256, 256)
     monkeypatch.setattr(ops, 'F43_LAYERS', 'all')
-    assert ops.f43_ok(256, 256, 32, 32) and not ops.f43_ok(512, 256, 64, 64)
+    assert ops.f43_ok(256, 256, 32, 32) and ops.f43_ok(512, 256, 64, 64) and not ops.f43_ok(512, 64, 64, 64) and not ops.f43_ok(768, 256, 64, 64)
     monkeypatch.setattr(ops, 'F43_LAYERS', '0')
     assert not ops.f43_ok(64, 64, 512, 512)
     assert ops.conv_code(ops.SPLIT_F43, 64, 64, 512, 512) == ops.WSPLIT

@@ -536,3 +536,32 @@ def test_winograd_f43_fp32_upsampling_gather(sc):
     xs = torch.randn(1, 32, 32, 128, device='cuda')
     with pytest.raises((RuntimeError, ValueError)):      # split-half operands have no upsampling gather (their folded form is the faster one)
         ops.conv2d(xs, ops.pack_weight(torch.randn(128, 128, 3, 3, device='cuda') * 0.03, None, bf16=ops.WF43), upsample=True, act=ops.act_scale(xs))
+
+
+def test_winograd_f43_with_512_input_channels(sc):
+    """Round 6: the 16-wave form on 32-channel slabs keeps 512 GroupNorm rows in LDS (F4_TAB_32), so the 512 -> 256 fusion convolution at 64x64
+    (concatenated [enc, dec], codeformer_arch.py:152) runs F(4x4,3x3) in precision 'fp32'.  Against fp64; the products of twice as many channels
+    are summed, so the bound is sqrt(2) x the 4e-5 (fp32 operands) / 2e-5 (split halves) of the <= 256-channel cases; the 8-wave form still refuses."""
+    import pytest
+    import torch
+    import torch.nn.functional as F
+    from codeformer_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for (B, H, cin, cout, cs) in ((2, 64, 512, 256, 256), (1, 32, 512, 128, 256)):
+        x = torch.randn(B, H, H, cin, generator=g)
+        w = torch.randn(cout, cin, 3, 3, generator=g) * (2 / (9 * cin)) ** 0.5
+        b = torch.randn(cout, generator=g) * 0.1
+        sc_, sh_ = torch.rand(B, cin, generator=g) + 0.5, torch.randn(B, cin, generator=g) * 0.1
+        xd = x.double() * sc_.double()[:, None, None, :] + sh_.double()[:, None, None, :]
+        ref = F.conv2d((xd * torch.sigmoid(xd)).permute(0, 3, 1, 2), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+        scale = max(float(ref.abs().max()) / 4.0, 1.0)
+        for code, bound in ((ops.WF43F, 4e-5), (ops.WF43, 2e-5)):
+            pw = ops.pack_weight(w.cuda(), b.cuda(), bf16=code)
+            xc = x.cuda()
+            y = ops.conv2d(xc[..., :cs].contiguous(), pw, x2=xc[..., cs:].contiguous(), prologue=ops.PRO_AFFINE_SWISH, scale=sc_.cuda(), shift=sh_.cuda(), emit_stats=True)
+            err = float((y.cpu().double() - ref).abs().max())
+            assert err <= 2 ** 0.5 * bound * scale, (code, cin, cout, err)
+    assert ops.f43_ok(512, 256, 64, 64, fp32=True) and not ops.f43_ok(512, 64, 64, 64, fp32=True)
+    pw64 = ops.pack_weight(torch.randn(64, 512, 3, 3, device='cuda') * 0.01, None, bf16=ops.WF43F)
+    with pytest.raises(RuntimeError, match='input channels'):
+        ops.conv2d(torch.randn(1, 64, 64, 512, device='cuda'), pw64)

@@ -176,7 +176,7 @@ def roofline_leg(net, x, w):
                   'algorithmic_gflop_per_step': round(c[0] / reps / 1e9, 1), 'ms_per_step': round(c[2] / reps * 1e3, 2),
                   'alg_bytes_per_launch': round(c[1] / c[3]), 'frac_hbm_peak_alg_bytes': round(c[1] / c[2] / 1e9 / HBM_PEAK_GBS, 4),
                   'traffic_recorded': tr['bytes_per_launch'] if tr else None, 'traffic': tr['bytes_per_launch'] if tr else None,
-                  'traffic_source': ('recorded: ' + tr['source'] + ' (builder box, same build id)') if tr else None,
+                  'traffic_source': tr['source'] if tr else None,    # (recorded on the builder's box by tools/pmc_bench.sh; quoted because its build id is the loaded library's)
                   'traffic_per_alg_bytes': round(tr['bytes_per_launch'] / (c[1] / c[3]), 3) if tr else None}
         if ratio == 0.0:   # no MFMA: algorithmic bytes / duration against the HBM peak
             gbs = c[1] / c[2] / 1e9
@@ -300,8 +300,8 @@ SHORT_KERNEL = {   # <= 110 characters: the driver's record truncates longer str
 def compact_roofline(r):
     """The line's `roofline`: scalars and short strings only (the full record, `other_kernels` included, goes to --details)."""
     keep = ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_recorded', 'traffic_source', 'traffic_per_alg_bytes', 'avg_launch_ms',
-            'launches_per_step', 'ms_per_step', 'alg_bytes_per_launch', 'frac_hbm_peak_alg_bytes', 'effective_tflops', 'frac_algorithmic',
-            'executed_tflops', 'frac_executed')
+            'launches_per_step', 'ms_per_step', 'alg_bytes_per_launch', 'frac_hbm_peak_alg_bytes', 'effective_tflops', 'frac_algorithmic')
+    # (executed_tflops / frac_executed of the long form equal achieved / frac for the Winograd classes: not repeated in the line)
     out = {'kernel': SHORT_KERNEL.get(r.get('kind'), r['kernel'])[:110]}
     out.update({k: r[k] for k in keep if k in r})
     return out

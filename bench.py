@@ -283,7 +283,7 @@ def cpu_baseline_leg(sd_cpu, w, budget_s=25.0):
         n += 1
     dt = time.perf_counter() - t0
     return {'value': round(n / dt, 4), 'unit': 'faces/s', 'cores': cores, 'kind': 'port',
-            'sample_short': f'{n} batch-1 forwards of the CPU oracle, torch CPU fp32, {cores} threads, seeded 512x512 face, w={w}',
+            'sample_short': f'{n} batch-1 oracle forwards, torch CPU fp32, {cores} threads, w={w}',
             'sample': f'{n} batch-1 forward(s) of the CPU oracle (torch {torch.__version__} CPU fp32, {cores} threads of {avail} '
                       f'available) on the seeded 512x512 input, w={w}, adain=True, after 1 warm-up ({warm:.1f} s)'}
 
@@ -300,7 +300,7 @@ SHORT_KERNEL = {   # <= 110 characters: the driver's record truncates longer str
 def compact_roofline(r):
     """The line's `roofline`: scalars and short strings only (the full record, `other_kernels` included, goes to --details)."""
     keep = ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_recorded', 'traffic_source', 'traffic_per_alg_bytes', 'avg_launch_ms',
-            'launches_per_step', 'ms_per_step', 'alg_bytes_per_launch', 'frac_hbm_peak_alg_bytes', 'effective_tflops', 'frac_algorithmic')
+            'launches_per_step', 'ms_per_step', 'alg_bytes_per_launch', 'effective_tflops')
     # (executed_tflops / frac_executed of the long form equal achieved / frac for the Winograd classes: not repeated in the line)
     out = {'kernel': SHORT_KERNEL.get(r.get('kind'), r['kernel'])[:110]}
     out.update({k: r[k] for k in keep if k in r})
@@ -410,6 +410,8 @@ def main():
             if args.precision == 'fp32':                             # every product on the fp32 pipe: a whole-path fraction makes sense
                 line['whole_path']['executed_tflops_fp32'] = round(faces_per_s * ex / 1e3, 2)
                 line['whole_path']['frac_fp32_mfma_peak'] = round(faces_per_s * ex / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world), 4)
+            details['whole_path'] = dict(line['whole_path'])
+            line['whole_path'] = {k: v for k, v in line['whole_path'].items() if k in ('frac_fp32_mfma_peak', 'frac_hbm_peak_fused_min_bytes')}
 
         def timed(w):
             for _ in range(args.warmup):
@@ -426,9 +428,10 @@ def main():
             r.pop('executed_gflop_per_face_whole_path')
             return r
 
-        def mirror(key, val):   # secondary-leg scalars: top level AND inside `config` (the driver's parsed record keeps that object whole)
+        def mirror(key, val):   # secondary-leg scalars at top level; the four throughput figures also inside `config` (the driver's parsed record keeps that object whole)
             line[key] = val
-            line['config'][key] = val
+            if key.endswith(('_faces_per_s', '_ms_per_step')):
+                line['config'][key] = val
 
         secondary = world == 1 and args.precision == 'fp32' and config2
         if secondary and not args.no_f16x2_leg:

@@ -158,10 +158,11 @@ def test_inpainting_config(chk):
 
 
 # ---- size-independent properties at BASELINE config-2 sizes (the CPU oracle is too slow there) -------------------------
-@pytest.mark.parametrize('precision', ['f16x2', 'fp32'])
+@pytest.mark.parametrize('precision', ['f16x2', 'fp32', 'bf16'])
 def test_full_size_batch16_is_bitwise_batch_invariant(chk, precision):
     """Config 2 shape (16 faces): every face of the batch equals the same face restored alone / in a 2-rank shard -- in the product's default
-    mode and in the IEEE-fp32 mode bench.py's headline runs (whose token GEMMs take another kernel at sixteen faces than at one)."""
+    mode, in the IEEE-fp32 mode bench.py's headline runs (whose token GEMMs take another kernel at sixteen faces than at one) and in the bf16
+    storage mode of configs 3 / 5."""
     import torch
     from oracle.synth import seeded_input
     net = chk.build_net().cuda()
